@@ -1,0 +1,328 @@
+/*
+ * sda_hip.h - C ABI of the MI355X (gfx950) secure-aggregation compute core.
+ *
+ * This is the drop-in boundary for the one hot path of snipsco/sda: the crate-private
+ * `client::crypto` sharing / masking traits (reference: client/src/crypto/sharing/mod.rs:10-33,
+ * client/src/crypto/masking/mod.rs:9-31).  Every entry point below replaces exactly one trait
+ * method or factory of the reference and cites it.  The Rust-side binding a maintainer would add
+ * is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - All scalars are 64-bit signed integers, like the reference's `Secret = Mask = MaskedSecret =
+ *    Share = i64` (client/src/crypto/mod.rs:33-36).  There is no floating point anywhere.
+ *  - Value domain: inputs may be ANY i64 (the reference does not range-check);
+ *    they are canonicalised on load.  Outputs are canonical residues in [0, modulus).  The
+ *    reference's intermediates live in (-q, q) (Rust truncated `%`); equality with the reference is
+ *    therefore modulo q for intermediates and bit-for-bit after `RecipientOutput::positive`
+ *    (client/src/receive.rs:13-21), which is the identity on canonical values.
+ *  - Every function returns an `int` status: 0 = ok, negative = error (enum sda_status).  Nothing
+ *    throws or aborts across the ABI.  The message of the last failure on the calling thread is
+ *    available from sda_last_error().
+ *  - Ownership: the caller allocates every input and output buffer; the library owns only the
+ *    handle (device scratch, stream, precomputed matrices).  No pointer is retained after return.
+ *  - Handles are NOT thread-safe (the reference traits carry no Send/Sync bound); use one per thread.
+ *  - All host-buffer calls are blocking.  The *_dev calls take device pointers and a hipStream_t
+ *    (passed as void*; NULL = the handle's own stream) and are asynchronous on that stream.
+ *  - There is NO CPU fallback: every compute entry point returns SDA_ERR_NO_DEVICE when no gfx950
+ *    device is usable.
+ *  - Randomness: the reference draws from OsRng inside generate()/mask() (additive.rs:42-44,
+ *    full.rs:24-26, chacha.rs:29-33, tss::share).  Here it is injectable: pass `rand` to reproduce a
+ *    given draw sequence (parity tests), or NULL to use the handle's on-device CSPRNG (ChaCha20
+ *    keyed from OS entropy; spec in DESIGN.md "sda-drbg-v1").
+ */
+#ifndef SDA_HIP_H
+#define SDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDA_HIP_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+enum sda_status {
+    SDA_OK = 0,
+    /* mirrors of the reference's error strings (SdaClientResult `Err("...")?`) */
+    SDA_ERR_BATCH_INPUT_WRONG_LENGTH = -1,   /* "Batch input wrong length"            additive.rs:33      */
+    SDA_ERR_SHARING_FAILED = -2,             /* "Sharing failed for packed secret sharing scheme" packed_shamir.rs:41 */
+    SDA_ERR_INPUTS_MUST_HAVE_SAME_LENGTH = -3, /* "Inputs must have same length"      packed_shamir.rs:74 */
+    SDA_ERR_NOT_ENOUGH_SHARES = -4,          /* "Not enough shares to reconstruct"    packed_shamir.rs:75 */
+    SDA_ERR_WRONG_DIMENSION = -5,            /* "Wrong dimension"                     combiner.rs:21      */
+    SDA_ERR_MISMATCHING_DIMENSION = -6,      /* "Mismatching dimension"               additive.rs:64      */
+    /* the masking traits are infallible and panic via assert!/assert_eq!
+     * (chacha.rs:26,83; full.rs:43,58; none.rs:23,30); a Rust shim maps this code to panic!() */
+    SDA_ERR_ASSERTION = -7,
+    /* conditions with no counterpart in the reference */
+    SDA_ERR_INVALID_ARGUMENT = -8,           /* NULL pointer, bad scheme parameters, short buffer  */
+    SDA_ERR_UNSUPPORTED = -9,                /* parameters outside what the kernels implement      */
+    SDA_ERR_NO_DEVICE = -10,                 /* no usable gfx950 device - there is no CPU fallback */
+    SDA_ERR_HIP = -11,                       /* a HIP runtime call or kernel launch failed         */
+    SDA_ERR_ALLOC = -12,                     /* host or device allocation failed                   */
+    SDA_ERR_STATE = -13                      /* streaming call out of order (update before begin)  */
+};
+
+/* ---- scheme parameters (the wire enums stay intact) ---------------------------------------- */
+
+/* LinearSecretSharingScheme - protocol/src/crypto.rs:79-114 */
+enum sda_sharing_kind {
+    SDA_SHARING_ADDITIVE = 0,       /* Additive { share_count, modulus }                                   */
+    SDA_SHARING_PACKED_SHAMIR = 1   /* PackedShamir { secret_count, share_count, privacy_threshold,
+                                                      prime_modulus, omega_secrets, omega_shares }         */
+};
+
+typedef struct sda_sharing_scheme {
+    int32_t  kind;               /* enum sda_sharing_kind                                         */
+    uint64_t share_count;        /* both variants                                                 */
+    int64_t  modulus;            /* Additive.modulus | PackedShamir.prime_modulus  (2 <= m < 2^62) */
+    uint64_t secret_count;       /* PackedShamir only (Additive: ignored, input_size() == 1)      */
+    uint64_t privacy_threshold;  /* PackedShamir only                                             */
+    int64_t  omega_secrets;      /* PackedShamir only                                             */
+    int64_t  omega_shares;       /* PackedShamir only                                             */
+} sda_sharing_scheme_t;
+
+/* LinearMaskingScheme - protocol/src/crypto.rs:43-75 */
+enum sda_masking_kind {
+    SDA_MASKING_NONE = 0,    /* None                                       */
+    SDA_MASKING_FULL = 1,    /* Full { modulus }                           */
+    SDA_MASKING_CHACHA = 2   /* ChaCha { modulus, dimension, seed_bitsize } */
+};
+
+typedef struct sda_masking_scheme {
+    int32_t  kind;          /* enum sda_masking_kind */
+    int64_t  modulus;       /* Full, ChaCha          */
+    uint64_t dimension;     /* ChaCha                */
+    uint64_t seed_bitsize;  /* ChaCha                */
+} sda_masking_scheme_t;
+
+/* derived sizes - protocol/src/crypto.rs:120-153 */
+uint64_t sda_scheme_input_size(const sda_sharing_scheme_t* s);               /* :120-126 */
+uint64_t sda_scheme_output_size(const sda_sharing_scheme_t* s);              /* :129-135 */
+uint64_t sda_scheme_privacy_threshold(const sda_sharing_scheme_t* s);        /* :138-144 */
+uint64_t sda_scheme_reconstruction_threshold(const sda_sharing_scheme_t* s); /* :147-153 */
+int      sda_masking_has_mask(const sda_masking_scheme_t* s);                /* :67-74   */
+
+/* ---- library / device -------------------------------------------------------------------- */
+int         sda_abi_version(void);
+const char* sda_version(void);
+int         sda_device_count(void);          /* number of visible HIP devices, 0 if none      */
+int         sda_set_device(int ordinal);     /* device used by handles created afterwards     */
+const char* sda_strerror(int status);
+const char* sda_last_error(void);            /* thread-local; "" if none                      */
+
+/* device memory helpers so that a host language needs no HIP binding of its own */
+int sda_dev_malloc(void** d_ptr, size_t bytes);
+int sda_dev_free(void* d_ptr);
+int sda_dev_upload(void* d_dst, const void* h_src, size_t bytes);
+int sda_dev_download(void* h_dst, const void* d_src, size_t bytes);
+int sda_dev_memset(void* d_dst, int value, size_t bytes);
+int sda_dev_synchronize(void);
+
+/* ---- opaque handles: one per (scheme, role), like the reference's boxed trait objects ------ */
+typedef struct sda_share_generator       sda_share_generator_t;
+typedef struct sda_share_combiner        sda_share_combiner_t;
+typedef struct sda_secret_reconstructor  sda_secret_reconstructor_t;
+typedef struct sda_secret_masker         sda_secret_masker_t;
+typedef struct sda_mask_combiner         sda_mask_combiner_t;
+typedef struct sda_secret_unmasker       sda_secret_unmasker_t;
+
+/* =============================================================================================
+ * ShareGenerator  (sharing/mod.rs:10-17; impl batched.rs:18-53, additive.rs:32-51,
+ *                  packed_shamir.rs:40-43 -> tss::packed::PackedSecretSharing::share)
+ * ============================================================================================= */
+
+/* new_share_generator(&scheme) - sharing/mod.rs:35-55 */
+int  sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_share_generator_t** out);
+void sda_share_generator_free(sda_share_generator_t* g);
+
+/* batch geometry: k = batch_input_size, n = batch_output_size, B = ceil(len / k)  (batched.rs:21-23) */
+uint64_t sda_share_generator_share_count(const sda_share_generator_t* g);            /* n              */
+uint64_t sda_share_generator_batch_count(const sda_share_generator_t* g, size_t len); /* B              */
+uint64_t sda_share_generator_rand_count(const sda_share_generator_t* g, size_t len);  /* B * rand/batch */
+
+/* Key of the on-device CSPRNG used when rand == NULL (default: 32 bytes of OS entropy).  Setting
+ * it makes NULL-rand runs reproducible (tests, bench). */
+int sda_share_generator_set_drbg_key(sda_share_generator_t* g, const uint8_t key[32]);
+
+/* generate(&mut self, secrets) -> Vec<Vec<Share>>   - sharing/mod.rs:14-17, batched.rs:18-53.
+ *   secrets[len]               any i64
+ *   rand[rand_len] or NULL     the draw sequence the reference would take from OsRng: for batch
+ *                              b = 0..B-1, (n-1) values (additive.rs:42-44) or privacy_threshold
+ *                              values (tss share), each taken mod modulus.  rand_len must equal
+ *                              sda_share_generator_rand_count(g, len).
+ *   out[n * B]                 clerk-major: out[j*B + b] = share of batch b for clerk j
+ *                              (batched.rs:46-48).  The last batch is zero-padded (batched.rs:37-43). */
+int sda_share_generator_generate(sda_share_generator_t* g,
+                                 const int64_t* secrets, size_t len,
+                                 const int64_t* rand, size_t rand_len,
+                                 int64_t* out, size_t out_len);
+
+/* P participants at once, everything resident in HBM (the bench / multi-GPU form).
+ *   d_secrets : participant p at d_secrets + p*secrets_stride, `len` values each
+ *   d_rand    : NULL -> on-device CSPRNG, stream id = first_participant + p; else participant p's
+ *               draws at d_rand + p*rand_stride (rand_count values each)
+ *   d_out     : share (p, clerk j, batch b) at d_out + p*out_stride_participant
+ *                                                   + j*out_stride_clerk + b
+ *               e.g. job-major [n][P][B] (what the server's snapshot transposition produces,
+ *               server/src/stores.rs:86-101): out_stride_clerk = P*B, out_stride_participant = B.
+ *   All strides in elements.  Asynchronous on `stream`. */
+int sda_share_generator_generate_batch_dev(sda_share_generator_t* g,
+                                           const int64_t* d_secrets, size_t participants, size_t len,
+                                           size_t secrets_stride,
+                                           const int64_t* d_rand, size_t rand_stride,
+                                           uint64_t first_participant,
+                                           int64_t* d_out, size_t out_stride_participant,
+                                           size_t out_stride_clerk,
+                                           void* stream);
+
+/* =============================================================================================
+ * ShareCombiner  (sharing/mod.rs:19-25; impl combiner.rs:15-29)
+ * ============================================================================================= */
+
+/* new_share_combiner(&scheme) - sharing/mod.rs:57-73 */
+int  sda_share_combiner_new(const sda_sharing_scheme_t* scheme, sda_share_combiner_t** out);
+void sda_share_combiner_free(sda_share_combiner_t* c);
+
+/* combine(&self, &Vec<Vec<Share>>) -> Vec<Share>   - combiner.rs:15-29.
+ * rows[p] has row_lens[p] values.  dimension = row_lens[0] (0 rows -> *out_len = 0, combiner.rs:17);
+ * a row of another length -> SDA_ERR_WRONG_DIMENSION (combiner.rs:21).  out_cap >= dimension. */
+int sda_share_combiner_combine(sda_share_combiner_t* c,
+                               const int64_t* const* rows, const size_t* row_lens, size_t n_rows,
+                               int64_t* out, size_t out_cap, size_t* out_len);
+
+/* same, for a dense [n_rows][dimension] matrix with row stride `row_stride` (elements) */
+int sda_share_combiner_combine_dense(sda_share_combiner_t* c,
+                                     const int64_t* shares, size_t n_rows, size_t dimension,
+                                     size_t row_stride, int64_t* out);
+
+/* Streaming / accumulating combiner: fixes the waste the reference acknowledges at
+ * client/src/clerk.rs:71-72 (all P share vectors materialised before combining).  State is
+ * `jobs` independent accumulator vectors of `dimension` exact 128-bit sums held in HBM.
+ *   begin  : zero the state
+ *   update : add n_rows rows to every job: element (job, row, i) at
+ *            d_shares + job*job_stride + row*row_stride + i
+ *   finish : reduce mod q into d_out[jobs * dimension] (canonical); state stays valid */
+int sda_share_combiner_begin_dev(sda_share_combiner_t* c, size_t jobs, size_t dimension, void* stream);
+int sda_share_combiner_update_dev(sda_share_combiner_t* c,
+                                  const int64_t* d_shares, size_t job_stride,
+                                  size_t n_rows, size_t row_stride, void* stream);
+int sda_share_combiner_finish_dev(sda_share_combiner_t* c, int64_t* d_out, void* stream);
+
+/* host-buffer streaming form (tiles are uploaded, accumulated, discarded) */
+int sda_share_combiner_begin(sda_share_combiner_t* c, size_t dimension);
+int sda_share_combiner_update(sda_share_combiner_t* c, const int64_t* shares, size_t n_rows,
+                              size_t row_stride);
+int sda_share_combiner_finish(sda_share_combiner_t* c, int64_t* out);
+
+/* =============================================================================================
+ * SecretReconstructor  (sharing/mod.rs:27-33; impl additive.rs:55-73, batched.rs:68-97,
+ *                       packed_shamir.rs:73-77 -> tss ...::reconstruct)
+ * ============================================================================================= */
+
+/* new_secret_reconstructor(&scheme, dimension) - sharing/mod.rs:75-96 */
+int  sda_secret_reconstructor_new(const sda_sharing_scheme_t* scheme, size_t dimension,
+                                  sda_secret_reconstructor_t** out);
+void sda_secret_reconstructor_free(sda_secret_reconstructor_t* r);
+
+/* reconstruct(&self, &Vec<(usize, Vec<Share>)>) -> Vec<Secret>.
+ *   indices[i]  clerk index of rows[i] (position in committee.clerks_and_keys, receive.rs:131-136)
+ *   Additive   : column sum mod q; *out_len = row_lens[0]; ragged -> SDA_ERR_MISMATCHING_DIMENSION
+ *                (additive.rs:55-73; indices ignored, the configured dimension too).
+ *   PackedShamir: *out_len = dimension; n_rows < t+k -> SDA_ERR_NOT_ENOUGH_SHARES
+ *                (packed_shamir.rs:75); every row needs >= ceil(dimension/k) values (batched.rs:84
+ *                would panic on a short row: SDA_ERR_ASSERTION). */
+int sda_secret_reconstructor_reconstruct(sda_secret_reconstructor_t* r,
+                                         const size_t* indices,
+                                         const int64_t* const* rows, const size_t* row_lens,
+                                         size_t n_rows,
+                                         int64_t* out, size_t out_cap, size_t* out_len);
+
+/* device form: row i at d_shares + i*row_stride (row_len values each); d_out[*out_len] */
+int sda_secret_reconstructor_reconstruct_dev(sda_secret_reconstructor_t* r,
+                                             const size_t* indices, size_t n_rows,
+                                             const int64_t* d_shares, size_t row_len, size_t row_stride,
+                                             int64_t* d_out, size_t out_cap, size_t* out_len,
+                                             void* stream);
+
+/* =============================================================================================
+ * SecretMasker / MaskCombiner / SecretUnmasker  (masking/mod.rs:9-31; impl none.rs, full.rs, chacha.rs)
+ * ============================================================================================= */
+
+/* new_secret_masker(&scheme) - masking/mod.rs:33-53 */
+int  sda_secret_masker_new(const sda_masking_scheme_t* scheme, sda_secret_masker_t** out);
+void sda_secret_masker_free(sda_secret_masker_t* m);
+int  sda_secret_masker_set_drbg_key(sda_secret_masker_t* m, const uint8_t key[32]);
+
+/* length of the mask vector mask() returns for `len` secrets: None 0 (none.rs:15), Full len
+ * (full.rs:24-26), ChaCha ceil(seed_bitsize/32) seed words (chacha.rs:31,48-50) */
+uint64_t sda_secret_masker_mask_len(const sda_secret_masker_t* m, size_t len);
+
+/* mask(&mut self, secrets) -> (Vec<Mask>, Vec<MaskedSecret>)  - none.rs:13-19, full.rs:21-35,
+ * chacha.rs:24-54.
+ *   rand: Full  -> `len` mask values (the OsRng draws of full.rs:24-26), or NULL for the CSPRNG
+ *         ChaCha-> ceil(seed_bitsize/32) seed words, each used `as u32` (chacha.rs:30-33), or NULL
+ *                  for OS entropy;   None -> ignored
+ *   ChaCha with len != scheme.dimension -> SDA_ERR_ASSERTION (assert_eq!, chacha.rs:26) */
+int sda_secret_masker_mask(sda_secret_masker_t* m,
+                           const int64_t* secrets, size_t len,
+                           const int64_t* rand, size_t rand_len,
+                           int64_t* mask_out, size_t mask_cap, size_t* mask_len,
+                           int64_t* masked_out);
+
+/* new_mask_combiner(&scheme) - masking/mod.rs:55-75 */
+int  sda_mask_combiner_new(const sda_masking_scheme_t* scheme, sda_mask_combiner_t** out);
+void sda_mask_combiner_free(sda_mask_combiner_t* c);
+
+/* combine(&self, &Vec<Vec<Mask>>) -> Vec<Mask>
+ *   None  : every row must be empty (assert!, none.rs:23); *out_len = 0
+ *   Full  : column sum mod q (full.rs:37-52); ragged -> SDA_ERR_ASSERTION (assert_eq!, full.rs:43)
+ *   ChaCha: rows are seeds (words used `as u32`, chacha.rs:62-64); every seed is re-expanded with
+ *           rand-0.3 ChaChaRng + gen_range(0, modulus) and summed; *out_len = scheme.dimension
+ *           (chacha.rs:56-77) */
+int sda_mask_combiner_combine(sda_mask_combiner_t* c,
+                              const int64_t* const* rows, const size_t* row_lens, size_t n_rows,
+                              int64_t* out, size_t out_cap, size_t* out_len);
+
+/* new_secret_unmasker(&scheme) - masking/mod.rs:77-94 */
+int  sda_secret_unmasker_new(const sda_masking_scheme_t* scheme, sda_secret_unmasker_t** out);
+void sda_secret_unmasker_free(sda_secret_unmasker_t* u);
+
+/* unmask(&self, &(Vec<Mask>, Vec<MaskedSecret>)) -> Vec<Secret>   - none.rs:28-33, full.rs:54-67,
+ * chacha.rs:79-93.   None: mask_len must be 0 (none.rs:30); Full/ChaCha: mask_len == masked_len
+ * (assert_eq!, full.rs:58, chacha.rs:83) else SDA_ERR_ASSERTION.  out[masked_len]. */
+int sda_secret_unmasker_unmask(sda_secret_unmasker_t* u,
+                               const int64_t* mask, size_t mask_len,
+                               const int64_t* masked, size_t masked_len,
+                               int64_t* out);
+
+/* RecipientOutput::positive - client/src/receive.rs:13-21: v < 0 ? v + modulus : v.  Host-side,
+ * element-wise; the identity on this library's canonical outputs. */
+int sda_positive(const int64_t* values, size_t len, int64_t modulus, int64_t* out);
+
+/* =============================================================================================
+ * Cross-GPU modular reduction helper (new; no reference counterpart - SURVEY.md 8e).
+ * d_parts holds `parts` vectors of `len` canonical residues (part g at d_parts + g*part_stride);
+ * d_out[len] = sum over parts mod modulus.  Used after an all-to-all of per-GPU partial clerk sums
+ * (a plain u64 ncclSum would wrap for 8 x 62-bit residues).
+ * ============================================================================================= */
+int sda_modsum_parts_dev(int64_t modulus, const int64_t* d_parts, size_t parts, size_t part_stride,
+                         size_t len, int64_t* d_out, void* stream);
+
+/* Synthetic bench input: d_out[p*stride + i] = splitmix64(seed ^ ((first_participant+p) << 32 | i))
+ * mod modulus.  Not on the product path. */
+int sda_fill_synthetic_dev(int64_t* d_out, size_t participants, size_t len, size_t stride,
+                           uint64_t first_participant, uint64_t seed, int64_t modulus, void* stream);
+
+/* Timing hooks for bench.py: HIP events recorded on the stream the kernels are launched on
+ * (torch.cuda.Event only sees torch's current stream). */
+int sda_event_create(void** ev);
+int sda_event_destroy(void* ev);
+int sda_event_record(void* ev, void* stream);
+int sda_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDA_HIP_H */

@@ -1,0 +1,385 @@
+"""Host-side mirror of the reference's ``client::crypto`` sharing / masking interface, on top of
+the C ABI (include/sda_hip.h).  Same names, argument meaning and error behaviour as the reference:
+
+    CryptoModule.new_share_generator(scheme)         sharing/mod.rs:10-12,35-55
+    ShareGenerator.generate(secrets)                 sharing/mod.rs:14-17
+    CryptoModule.new_share_combiner(scheme)          sharing/mod.rs:19-21,57-73
+    ShareCombiner.combine(shares)                    sharing/mod.rs:23-25
+    CryptoModule.new_secret_reconstructor(scheme, d) sharing/mod.rs:27-29,75-96
+    SecretReconstructor.reconstruct(indexed_shares)  sharing/mod.rs:31-33
+    CryptoModule.new_secret_masker / new_mask_combiner / new_secret_unmasker   masking/mod.rs:9-31
+
+``SdaClientResult`` errors surface as :class:`sda_amd.capi.SdaError` carrying the reference's message;
+the masking traits' ``assert!`` panics surface as :class:`AssertionError`.  The only widening of the
+interface is the optional ``rand`` argument (the reference draws from OsRng; see sda_hip.h).
+
+Every method runs on the GPU through libsda_hip.so; nothing here computes on share data in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import capi
+from .capi import SdaError, check
+
+Secret = Mask = MaskedSecret = Share = np.int64     # client/src/crypto/mod.rs:33-36
+
+
+# ---- scheme enums (protocol/src/crypto.rs:43-155) ------------------------------------------------
+@dataclass(frozen=True)
+class Additive:
+    share_count: int
+    modulus: int
+
+    def input_size(self): return 1                                   # crypto.rs:120-126
+    def output_size(self): return self.share_count                   # crypto.rs:129-135
+    def privacy_threshold_(self): return self.share_count - 1        # crypto.rs:138-144
+    def reconstruction_threshold(self): return self.share_count      # crypto.rs:147-153
+
+    def _c(self):
+        return capi.SharingScheme(capi.SHARING_ADDITIVE, self.share_count, self.modulus, 0, 0, 0, 0)
+
+
+@dataclass(frozen=True)
+class PackedShamir:
+    secret_count: int
+    share_count: int
+    privacy_threshold: int
+    prime_modulus: int
+    omega_secrets: int
+    omega_shares: int
+
+    def input_size(self): return self.secret_count
+    def output_size(self): return self.share_count
+    def privacy_threshold_(self): return self.privacy_threshold
+    def reconstruction_threshold(self): return self.privacy_threshold + self.secret_count
+
+    def _c(self):
+        return capi.SharingScheme(capi.SHARING_PACKED_SHAMIR, self.share_count, self.prime_modulus,
+                                  self.secret_count, self.privacy_threshold, self.omega_secrets,
+                                  self.omega_shares)
+
+
+LinearSecretSharingScheme = Union[Additive, PackedShamir]
+
+
+@dataclass(frozen=True)
+class NoMask:                       # LinearMaskingScheme::None
+    def has_mask(self): return False
+    def _c(self): return capi.MaskingScheme(capi.MASKING_NONE, 0, 0, 0)
+
+
+@dataclass(frozen=True)
+class Full:
+    modulus: int
+    def has_mask(self): return True
+    def _c(self): return capi.MaskingScheme(capi.MASKING_FULL, self.modulus, 0, 0)
+
+
+@dataclass(frozen=True)
+class ChaCha:
+    modulus: int
+    dimension: int
+    seed_bitsize: int
+    def has_mask(self): return True
+    def _c(self): return capi.MaskingScheme(capi.MASKING_CHACHA, self.modulus, self.dimension, self.seed_bitsize)
+
+
+LinearMaskingScheme = Union[NoMask, Full, ChaCha]
+
+
+# ---- helpers ------------------------------------------------------------------------------------------
+def _vec(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int64).reshape(-1)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(capi.c_i64p)
+
+
+def _rows(vectors: Sequence) -> Tuple[List[np.ndarray], C.Array, C.Array]:
+    arrs = [_vec(v) for v in vectors]
+    ptrs = (capi.c_i64p * max(len(arrs), 1))(*[_ptr(a) for a in arrs])
+    lens = (C.c_size_t * max(len(arrs), 1))(*[a.size for a in arrs])
+    return arrs, ptrs, lens
+
+
+def _check_mask(status: int) -> None:
+    """masking traits are infallible in the reference and panic on assert! - mirror as AssertionError"""
+    if status == capi.ERR_ASSERTION:
+        raise AssertionError(capi.load().sda_last_error().decode())
+    check(status)
+
+
+class _Handle:
+    _free = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._lib = capi.load()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            getattr(self._lib, self._free)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- sharing ----------------------------------------------------------------------------------------------
+class ShareGenerator(_Handle):
+    """sharing/mod.rs:14-17; impl batched.rs:18-53 over additive.rs / packed_shamir.rs."""
+    _free = "sda_share_generator_free"
+
+    def __init__(self, scheme: LinearSecretSharingScheme):
+        super().__init__()
+        self.scheme = scheme
+        cs = scheme._c()
+        check(self._lib.sda_share_generator_new(C.byref(cs), C.byref(self._h)))
+
+    def set_drbg_key(self, key: bytes):
+        assert len(key) == 32
+        check(self._lib.sda_share_generator_set_drbg_key(self._h, (C.c_uint8 * 32)(*key)))
+
+    def batch_count(self, length: int) -> int:
+        return int(self._lib.sda_share_generator_batch_count(self._h, length))
+
+    def rand_count(self, length: int) -> int:
+        return int(self._lib.sda_share_generator_rand_count(self._h, length))
+
+    def generate(self, secrets, rand=None) -> np.ndarray:
+        """-> int64 array [share_count][batches], row j = the shares for clerk j (batched.rs:46-48)."""
+        s = _vec(secrets)
+        n = int(self._lib.sda_share_generator_share_count(self._h))
+        B = self.batch_count(s.size)
+        out = np.empty((n, B), dtype=np.int64)
+        if rand is None:
+            rp, rl = None, 0
+        else:
+            r = _vec(rand)
+            rp, rl = _ptr(r), r.size
+        check(self._lib.sda_share_generator_generate(self._h, _ptr(s), s.size, rp, rl, _ptr(out), out.size))
+        return out
+
+    def generate_batch_dev(self, d_secrets: int, participants: int, length: int, secrets_stride: int,
+                           d_out: int, out_stride_participant: int, out_stride_clerk: int,
+                           first_participant: int = 0, d_rand: int = 0, rand_stride: int = 0, stream: int = 0):
+        check(self._lib.sda_share_generator_generate_batch_dev(
+            self._h, d_secrets, participants, length, secrets_stride, d_rand or None, rand_stride,
+            first_participant, d_out, out_stride_participant, out_stride_clerk, stream or None))
+
+
+class ShareCombiner(_Handle):
+    """sharing/mod.rs:23-25; impl combiner.rs:15-29."""
+    _free = "sda_share_combiner_free"
+
+    def __init__(self, scheme: LinearSecretSharingScheme):
+        super().__init__()
+        self.scheme = scheme
+        cs = scheme._c()
+        check(self._lib.sda_share_combiner_new(C.byref(cs), C.byref(self._h)))
+
+    def combine(self, shares: Sequence) -> np.ndarray:
+        arrs, ptrs, lens = _rows(shares)
+        cap = arrs[0].size if arrs else 0
+        out = np.empty(max(cap, 1), dtype=np.int64)
+        n_out = C.c_size_t()
+        check(self._lib.sda_share_combiner_combine(self._h, ptrs, lens, len(arrs), _ptr(out), cap, C.byref(n_out)))
+        return out[:n_out.value].copy()
+
+    # streaming / accumulating form (fixes the FIXME at client/src/clerk.rs:71-72)
+    def begin(self, dimension: int):
+        check(self._lib.sda_share_combiner_begin(self._h, dimension))
+
+    def update(self, tile) -> None:
+        t = np.ascontiguousarray(tile, dtype=np.int64)
+        assert t.ndim == 2
+        check(self._lib.sda_share_combiner_update(self._h, _ptr(t), t.shape[0], t.shape[1]))
+
+    def finish(self, dimension: int) -> np.ndarray:
+        out = np.empty(max(dimension, 1), dtype=np.int64)
+        check(self._lib.sda_share_combiner_finish(self._h, _ptr(out)))
+        return out[:dimension]
+
+    def begin_dev(self, jobs: int, dimension: int, stream: int = 0):
+        check(self._lib.sda_share_combiner_begin_dev(self._h, jobs, dimension, stream or None))
+
+    def update_dev(self, d_shares: int, job_stride: int, n_rows: int, row_stride: int, stream: int = 0):
+        check(self._lib.sda_share_combiner_update_dev(self._h, d_shares, job_stride, n_rows, row_stride, stream or None))
+
+    def finish_dev(self, d_out: int, stream: int = 0):
+        check(self._lib.sda_share_combiner_finish_dev(self._h, d_out, stream or None))
+
+
+class SecretReconstructor(_Handle):
+    """sharing/mod.rs:31-33; impl additive.rs:55-73 | batched.rs:68-97 + packed_shamir.rs:73-77."""
+    _free = "sda_secret_reconstructor_free"
+
+    def __init__(self, scheme: LinearSecretSharingScheme, dimension: int):
+        super().__init__()
+        self.scheme = scheme
+        self.dimension = dimension
+        cs = scheme._c()
+        check(self._lib.sda_secret_reconstructor_new(C.byref(cs), dimension, C.byref(self._h)))
+
+    def reconstruct(self, indexed_shares: Sequence[Tuple[int, Sequence]]) -> np.ndarray:
+        idx = [int(i) for i, _ in indexed_shares]
+        arrs, ptrs, lens = _rows([v for _, v in indexed_shares])
+        cidx = (C.c_size_t * max(len(idx), 1))(*idx)
+        cap = max(self.dimension, arrs[0].size if arrs else 0)
+        out = np.empty(max(cap, 1), dtype=np.int64)
+        n_out = C.c_size_t()
+        check(self._lib.sda_secret_reconstructor_reconstruct(self._h, cidx, ptrs, lens, len(arrs), _ptr(out), cap,
+                                                             C.byref(n_out)))
+        return out[:n_out.value].copy()
+
+    def reconstruct_dev(self, indices: Sequence[int], d_shares: int, row_len: int, row_stride: int, d_out: int,
+                        out_cap: int, stream: int = 0) -> int:
+        cidx = (C.c_size_t * max(len(indices), 1))(*[int(i) for i in indices])
+        n_out = C.c_size_t()
+        check(self._lib.sda_secret_reconstructor_reconstruct_dev(self._h, cidx, len(indices), d_shares, row_len,
+                                                                 row_stride, d_out, out_cap, C.byref(n_out),
+                                                                 stream or None))
+        return n_out.value
+
+
+# ---- masking -------------------------------------------------------------------------------------------------
+class SecretMasker(_Handle):
+    """masking/mod.rs:13-15; impl none.rs:13-19, full.rs:21-35, chacha.rs:24-54."""
+    _free = "sda_secret_masker_free"
+
+    def __init__(self, scheme: LinearMaskingScheme):
+        super().__init__()
+        self.scheme = scheme
+        cs = scheme._c()
+        check(self._lib.sda_secret_masker_new(C.byref(cs), C.byref(self._h)))
+
+    def set_drbg_key(self, key: bytes):
+        check(self._lib.sda_secret_masker_set_drbg_key(self._h, (C.c_uint8 * 32)(*key)))
+
+    def mask(self, secrets, rand=None) -> Tuple[np.ndarray, np.ndarray]:
+        s = _vec(secrets)
+        cap = int(self._lib.sda_secret_masker_mask_len(self._h, s.size))
+        mask = np.empty(max(cap, 1), dtype=np.int64)
+        masked = np.empty(max(s.size, 1), dtype=np.int64)
+        n_mask = C.c_size_t()
+        if rand is None:
+            rp, rl = None, 0
+        else:
+            r = _vec(rand)
+            rp, rl = _ptr(r), r.size
+        _check_mask(self._lib.sda_secret_masker_mask(self._h, _ptr(s), s.size, rp, rl, _ptr(mask), cap,
+                                                     C.byref(n_mask), _ptr(masked)))
+        return mask[:n_mask.value].copy(), masked[:s.size].copy()
+
+
+class MaskCombiner(_Handle):
+    """masking/mod.rs:21-23; impl none.rs:21-26, full.rs:37-52, chacha.rs:56-77."""
+    _free = "sda_mask_combiner_free"
+
+    def __init__(self, scheme: LinearMaskingScheme):
+        super().__init__()
+        self.scheme = scheme
+        cs = scheme._c()
+        check(self._lib.sda_mask_combiner_new(C.byref(cs), C.byref(self._h)))
+
+    def combine(self, masks: Sequence) -> np.ndarray:
+        arrs, ptrs, lens = _rows(masks)
+        if isinstance(self.scheme, ChaCha):
+            cap = self.scheme.dimension
+        else:
+            cap = arrs[0].size if arrs else 0
+        out = np.empty(max(cap, 1), dtype=np.int64)
+        n_out = C.c_size_t()
+        _check_mask(self._lib.sda_mask_combiner_combine(self._h, ptrs, lens, len(arrs), _ptr(out), cap, C.byref(n_out)))
+        return out[:n_out.value].copy()
+
+
+class SecretUnmasker(_Handle):
+    """masking/mod.rs:29-31; impl none.rs:28-33, full.rs:54-67, chacha.rs:79-93."""
+    _free = "sda_secret_unmasker_free"
+
+    def __init__(self, scheme: LinearMaskingScheme):
+        super().__init__()
+        self.scheme = scheme
+        cs = scheme._c()
+        check(self._lib.sda_secret_unmasker_new(C.byref(cs), C.byref(self._h)))
+
+    def unmask(self, values: Tuple[Sequence, Sequence]) -> np.ndarray:
+        mask, masked = _vec(values[0]), _vec(values[1])
+        out = np.empty(max(masked.size, 1), dtype=np.int64)
+        _check_mask(self._lib.sda_secret_unmasker_unmask(self._h, _ptr(mask), mask.size, _ptr(masked), masked.size,
+                                                         _ptr(out)))
+        return out[:masked.size].copy()
+
+
+# ---- factory (client/src/crypto/mod.rs:58-66) ---------------------------------------------------------------
+class CryptoModule:
+    """The reference's factory object; the keystore plays no part on this path."""
+
+    def new_share_generator(self, scheme): return ShareGenerator(scheme)
+    def new_share_combiner(self, scheme): return ShareCombiner(scheme)
+    def new_secret_reconstructor(self, scheme, dimension): return SecretReconstructor(scheme, dimension)
+    def new_secret_masker(self, scheme): return SecretMasker(scheme)
+    def new_mask_combiner(self, scheme): return MaskCombiner(scheme)
+    def new_secret_unmasker(self, scheme): return SecretUnmasker(scheme)
+
+
+@dataclass
+class RecipientOutput:
+    """client/src/receive.rs:7-21."""
+    modulus: int
+    values: np.ndarray
+
+    def positive(self) -> "RecipientOutput":
+        v = _vec(self.values)
+        out = np.empty(max(v.size, 1), dtype=np.int64)
+        check(capi.load().sda_positive(_ptr(v), v.size, self.modulus, _ptr(out)))
+        return RecipientOutput(self.modulus, out[:v.size].copy())
+
+
+@dataclass
+class Aggregation:
+    """The compute-relevant fields of protocol/src/resources.rs:44-67."""
+    vector_dimension: int
+    modulus: int
+    masking_scheme: LinearMaskingScheme
+    committee_sharing_scheme: LinearSecretSharingScheme
+
+
+def full_aggregation(aggregation: Aggregation, inputs: Sequence[Sequence[int]], mask_rand=None, share_rand=None,
+                     clerk_subset: Optional[Sequence[int]] = None) -> dict:
+    """The three callers' data flow - participate.rs:52-76, the snapshot transposition
+    (server/src/stores.rs:86-101), clerk.rs:85-86, receive.rs:101-156 - with the HIP core in place of
+    the reference's crypto module.  Returns every intermediate."""
+    crypto = CryptoModule()
+    a = aggregation
+    n = a.committee_sharing_scheme.output_size()
+    masks, maskeds, shares = [], [], []
+    masker = crypto.new_secret_masker(a.masking_scheme)
+    generator = crypto.new_share_generator(a.committee_sharing_scheme)
+    for p, secrets in enumerate(inputs):
+        if len(secrets) != a.vector_dimension:
+            raise ValueError("The input length does not match the aggregation.")      # participate.rs:44-46
+        m, ms = masker.mask(secrets, None if mask_rand is None else mask_rand[p])      # participate.rs:53-54
+        masks.append(m); maskeds.append(ms)
+        shares.append(generator.generate(ms, None if share_rand is None else share_rand[p]))   # :75-76
+    combiner = crypto.new_share_combiner(a.committee_sharing_scheme)
+    clerk_sums = [combiner.combine([shares[p][c] for p in range(len(inputs))]) for c in range(n)]   # clerk.rs:85-86
+    mask = (crypto.new_mask_combiner(a.masking_scheme).combine(masks)
+            if a.masking_scheme.has_mask() else np.empty(0, dtype=np.int64))             # receive.rs:102-118
+    subset = list(range(n)) if clerk_subset is None else list(clerk_subset)
+    rec = crypto.new_secret_reconstructor(a.committee_sharing_scheme, a.vector_dimension)
+    masked_output = rec.reconstruct([(c, clerk_sums[c]) for c in subset])                # receive.rs:140-144
+    output = crypto.new_secret_unmasker(a.masking_scheme).unmask((mask, masked_output))  # receive.rs:149-152
+    return {"masks": masks, "masked": maskeds, "shares": shares, "clerk_sums": clerk_sums,
+            "combined_mask": mask, "masked_output": masked_output, "output": output,
+            "positive": RecipientOutput(a.modulus, output).positive().values}

@@ -1,0 +1,112 @@
+// Launch interface between the C ABI (sda_capi.cpp) and the gfx950 kernels (sda_kernels.hip).
+// Plain structs and device pointers only.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+namespace sda {
+
+struct ModParams {
+    uint64_t m;           // modulus, 2 <= m < 2^62
+    uint64_t mu;          // floor(2^64 / m)          (Barrett)
+    uint64_t lemire_thr;  // 2^64 mod m               (Lemire rejection threshold)
+};
+
+struct MontParams {
+    uint64_t p;     // odd prime modulus
+    uint64_t pinv;  // -p^{-1} mod 2^64
+};
+
+struct DrbgKey {
+    uint32_t w[8];
+};
+
+// Montgomery-form matrix passed BY VALUE in the kernarg segment, so that rows are fetched with
+// scalar loads (s_load) and the multiplier operands live in SGPRs.
+#define SDA_MAT_ARG_MAX 448   // u64 entries (3.5 KiB of the 4 KiB kernarg budget)
+struct MatArg {
+    uint64_t e[SDA_MAT_ARG_MAX];
+};
+
+// strides in elements
+struct GenLayout {
+    const int64_t* secrets;   size_t secrets_stride;
+    const int64_t* rand;      size_t rand_stride;     // rand == nullptr -> DRBG
+    int64_t* out;             size_t out_stride_participant; size_t out_stride_clerk;
+    size_t participants;      size_t len;             // secrets per participant
+    uint64_t first_participant;                       // DRBG stream id of participant 0
+};
+
+// ---- share generation ---------------------------------------------------------------------------
+// additive: k = 1, n shares, n-1 randoms per element (additive.rs:32-51 through batched.rs:18-53)
+hipError_t launch_additive_generate(const GenLayout& L, uint32_t n, const ModParams& mod,
+                                    const DrbgKey& key, int rounds, hipStream_t s);
+
+// packed Shamir, fast path: (k, t) must be one of the compiled pairs and n*(k+t) <= SDA_MAT_ARG_MAX
+bool packed_fast_path_available(uint32_t k, uint32_t t, uint32_t n);
+hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
+                                  const ModParams& mod, const MontParams& mont, const MatArg& Mmont,
+                                  const DrbgKey& key, int rounds, hipStream_t s);
+
+// packed Shamir, any shape: matrix in global memory, randomness must be materialised (L.rand != 0)
+hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
+                                          const ModParams& mod, const MontParams& mont,
+                                          const uint64_t* d_Mmont, hipStream_t s);
+
+// materialise the DRBG draws exactly as the fused kernels would make them:
+// out[p*stride + b*T + i], b < batches, i < T
+hipError_t launch_drbg_fill(int64_t* d_out, size_t stride, size_t participants, size_t batches,
+                            uint32_t T, uint64_t first_participant, const ModParams& mod,
+                            const DrbgKey& key, int rounds, hipStream_t s);
+
+// ---- clerk combine (combiner.rs:15-29) -------------------------------------------------------------
+// acc (lo, hi) += sum over rows; element (job, row, i) at shares + job*job_stride + row*row_stride + i
+hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const int64_t* d_shares,
+                                 size_t jobs, size_t job_stride, size_t n_rows, size_t row_stride,
+                                 size_t dimension, hipStream_t s);
+hipError_t launch_combine_finish(const uint64_t* d_acc_lo, const int64_t* d_acc_hi, size_t count,
+                                 const ModParams& mod, int64_t* d_out, hipStream_t s);
+
+// ---- packed reconstruct (batched.rs:68-97 + tss reconstruct as a k x n' Lagrange matrix) ------------
+hipError_t launch_packed_reconstruct(const int64_t* d_shares, size_t row_stride, uint32_t n_rows,
+                                     uint32_t k, size_t batches, size_t dimension,
+                                     const ModParams& mod, const MontParams& mont,
+                                     const uint64_t* d_Rmont /*[k][n_rows]*/, int64_t* d_out,
+                                     hipStream_t s);
+
+// ---- element-wise masking (full.rs / chacha.rs mask+unmask arithmetic) ----------------------------
+// out = (a + b) mod m   or   (a - b) mod m, any i64 inputs
+hipError_t launch_addsub_mod(const int64_t* d_a, const int64_t* d_b, size_t len, bool subtract,
+                             const ModParams& mod, int64_t* d_out, hipStream_t s);
+// full.rs:21-35 with the on-device CSPRNG: mask[i] uniform, masked[i] = (s[i] + mask[i]) mod m
+hipError_t launch_full_mask_drbg(const int64_t* d_secrets, size_t len, uint64_t stream_id,
+                                 const ModParams& mod, const DrbgKey& key, int rounds,
+                                 int64_t* d_mask, int64_t* d_masked, hipStream_t s);
+
+// ---- rand-0.3 ChaChaRng mask expansion (chacha.rs:36-39, :60-73) ----------------------------------
+// Adds the `dimension` masks of each of the n_seeds seeds into the 128-bit accumulators.
+// d_seeds: n_seeds x 8 u32 key words (seed words beyond the given ones are 0).
+// Fast path: candidate i of every seed is added at position i (correct unless the seed's stream
+// contains a rejected candidate).  d_reject_flags[s] is set to 1 when seed s hit a rejection (zone
+// test); those seeds must then be corrected by launch_chacha_mask_slow(subtract_naive = true).
+hipError_t launch_chacha_mask_accumulate(const uint32_t* d_seeds, size_t n_seeds, size_t dimension,
+                                         const ModParams& mod, uint64_t zone, uint64_t* d_acc_lo,
+                                         int64_t* d_acc_hi, uint32_t* d_reject_flags, hipStream_t s);
+// exact sequential-order expansion (handles rejections) of the seeds named by d_list (n_list indices
+// into d_seeds; d_list == nullptr -> seeds 0..n_list-1), added into the accumulators.  With
+// subtract_naive the fast kernel's contribution for those seeds is taken back first.
+hipError_t launch_chacha_mask_slow(const uint32_t* d_seeds, const uint32_t* d_list, size_t n_list,
+                                   size_t dimension, const ModParams& mod, uint64_t zone,
+                                   uint64_t* d_acc_lo, int64_t* d_acc_hi, bool subtract_naive,
+                                   hipStream_t s);
+
+// ---- misc ---------------------------------------------------------------------------------------
+// out[i] = sum over g < parts of parts[g*part_stride + i]  mod m   (cross-GPU partial sums)
+hipError_t launch_modsum_parts(const int64_t* d_parts, size_t parts, size_t part_stride, size_t len,
+                               const ModParams& mod, int64_t* d_out, hipStream_t s);
+hipError_t launch_fill_synthetic(int64_t* d_out, size_t participants, size_t len, size_t stride,
+                                 uint64_t first_participant, uint64_t seed, const ModParams& mod,
+                                 hipStream_t s);
+
+}  // namespace sda

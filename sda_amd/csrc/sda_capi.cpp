@@ -1,0 +1,1087 @@
+// C ABI of the MI355X secure-aggregation core (include/sda_hip.h).
+//
+// Host logic only: parameter validation mirroring the reference's error behaviour, one-time
+// precomputation (Barrett / Montgomery constants, Lagrange matrices), staging of host buffers, and
+// kernel launches.  All arithmetic on share/mask data happens in sda_kernels.hip on the GPU; there
+// is no CPU fallback - without a usable gfx950 device every compute entry point fails with
+// SDA_ERR_NO_DEVICE.
+#include "../../include/sda_hip.h"
+
+#include <hip/hip_runtime_api.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/random.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "host_math.hpp"
+#include "kernels.hpp"
+#include "modarith.hpp"
+
+using namespace sda;
+
+// -------------------------------------------------------------------------------------------------
+// errors
+// -------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static thread_local int g_device = 0;
+
+static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(SDA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define SDA_TRY(expr)              \
+    do {                           \
+        int _s = (expr);           \
+        if (_s != SDA_OK) return _s; \
+    } while (0)
+
+extern "C" const char* sda_strerror(int status) {
+    switch (status) {
+        case SDA_OK: return "ok";
+        case SDA_ERR_BATCH_INPUT_WRONG_LENGTH: return "Batch input wrong length";
+        case SDA_ERR_SHARING_FAILED: return "Sharing failed for packed secret sharing scheme";
+        case SDA_ERR_INPUTS_MUST_HAVE_SAME_LENGTH: return "Inputs must have same length";
+        case SDA_ERR_NOT_ENOUGH_SHARES: return "Not enough shares to reconstruct";
+        case SDA_ERR_WRONG_DIMENSION: return "Wrong dimension";
+        case SDA_ERR_MISMATCHING_DIMENSION: return "Mismatching dimension";
+        case SDA_ERR_ASSERTION: return "assertion failed";
+        case SDA_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case SDA_ERR_UNSUPPORTED: return "unsupported parameters";
+        case SDA_ERR_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
+        case SDA_ERR_HIP: return "HIP runtime error";
+        case SDA_ERR_ALLOC: return "allocation failed";
+        case SDA_ERR_STATE: return "call out of order";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* sda_last_error(void) { return g_last_error.c_str(); }
+extern "C" int sda_abi_version(void) { return SDA_HIP_ABI_VERSION; }
+extern "C" const char* sda_version(void) { return "sda-hip 0.1.0 (gfx950)"; }
+
+// -------------------------------------------------------------------------------------------------
+// device context
+// -------------------------------------------------------------------------------------------------
+extern "C" int sda_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int sda_set_device(int ordinal) {
+    int n = sda_device_count();
+    if (n == 0) return fail(SDA_ERR_NO_DEVICE, "%s", sda_strerror(SDA_ERR_NO_DEVICE));
+    if (ordinal < 0 || ordinal >= n) return fail(SDA_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (have %d)", ordinal, n);
+    g_device = ordinal;
+    HIP_TRY(hipSetDevice(ordinal));
+    return SDA_OK;
+}
+
+namespace {
+
+struct Ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+
+    int init() {
+        int n = sda_device_count();
+        if (n == 0) return fail(SDA_ERR_NO_DEVICE, "%s", sda_strerror(SDA_ERR_NO_DEVICE));
+        device = g_device < n ? g_device : 0;
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(SDA_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return SDA_OK;
+    }
+    int use() const {
+        HIP_TRY(hipSetDevice(device));
+        return SDA_OK;
+    }
+    hipStream_t pick(void* user) const { return user ? reinterpret_cast<hipStream_t>(user) : stream; }
+    int sync() const {
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SDA_OK;
+    }
+    void destroy() {
+        if (stream) {
+            (void)hipSetDevice(device);
+            (void)hipStreamDestroy(stream);
+            stream = nullptr;
+        }
+    }
+};
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SDA_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(SDA_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        cap = want;
+        return SDA_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+int make_mod(int64_t modulus, ModParams& mod) {
+    if (modulus < 2) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus must be >= 2 (got %lld)", (long long)modulus);
+    if ((uint64_t)modulus >= (1ull << 62))
+        return fail(SDA_ERR_UNSUPPORTED, "modulus must be < 2^62 (got %lld): i64 add/sub of two residues must not overflow", (long long)modulus);
+    mod.m = (uint64_t)modulus;
+    mod.mu = h_barrett_mu(mod.m);
+    mod.lemire_thr = h_lemire_thr(mod.m);
+    return SDA_OK;
+}
+
+int os_entropy(void* buf, size_t len) {
+    uint8_t* b = static_cast<uint8_t*>(buf);
+    size_t got = 0;
+    while (got < len) {
+        ssize_t r = getrandom(b + got, len - got, 0);
+        if (r <= 0) return fail(SDA_ERR_INVALID_ARGUMENT, "getrandom failed");
+        got += (size_t)r;
+    }
+    return SDA_OK;
+}
+
+void key_from_bytes(const uint8_t key[32], DrbgKey& k) {
+    for (int i = 0; i < 8; ++i)
+        k.w[i] = (uint32_t)key[4 * i] | ((uint32_t)key[4 * i + 1] << 8) | ((uint32_t)key[4 * i + 2] << 16) |
+                 ((uint32_t)key[4 * i + 3] << 24);
+}
+
+struct Drbg {
+    DrbgKey key;
+    int rounds = 20;
+    uint64_t next_stream = 0;
+    int init() {
+        uint8_t raw[32];
+        SDA_TRY(os_entropy(raw, sizeof raw));
+        key_from_bytes(raw, key);
+        const char* r = getenv("SDA_DRBG_ROUNDS");     // 20 (default), 12 or 8
+        if (r) {
+            int v = atoi(r);
+            if (v == 20 || v == 12 || v == 8) rounds = v;
+        }
+        return SDA_OK;
+    }
+};
+
+bool sharing_is_additive(const sda_sharing_scheme_t* s) { return s->kind == SDA_SHARING_ADDITIVE; }
+
+int check_scheme_kind(const sda_sharing_scheme_t* s) {
+    if (!s) return fail(SDA_ERR_INVALID_ARGUMENT, "scheme is NULL");
+    if (s->kind != SDA_SHARING_ADDITIVE && s->kind != SDA_SHARING_PACKED_SHAMIR)
+        return fail(SDA_ERR_INVALID_ARGUMENT, "unknown sharing scheme kind %d", s->kind);
+    return SDA_OK;
+}
+
+// 128-bit exact accumulator state living in HBM
+struct AccState {
+    DevBuf lo, hi;
+    size_t count = 0;
+    int reset(size_t n, hipStream_t s) {
+        SDA_TRY(lo.reserve(n * 8));
+        SDA_TRY(hi.reserve(n * 8));
+        count = n;
+        if (n) {
+            HIP_TRY(hipMemsetAsync(lo.p, 0, n * 8, s));
+            HIP_TRY(hipMemsetAsync(hi.p, 0, n * 8, s));
+        }
+        return SDA_OK;
+    }
+    void release() { lo.release(); hi.release(); count = 0; }
+};
+
+// rows given as separate host vectors -> dense device tile uploads + combine_update
+int accumulate_host_rows(const Ctx& ctx, AccState& acc, DevBuf& tile, const int64_t* const* rows, size_t n_rows,
+                         size_t dimension) {
+    if (n_rows == 0 || dimension == 0) return SDA_OK;
+    const size_t tile_bytes_max = (size_t)256 << 20;
+    size_t rows_per_tile = tile_bytes_max / (dimension * 8);
+    if (rows_per_tile < 1) rows_per_tile = 1;
+    if (rows_per_tile > n_rows) rows_per_tile = n_rows;
+    const size_t stride = dimension + (dimension & 1);     // keep rows 16-byte aligned
+    SDA_TRY(tile.reserve(rows_per_tile * stride * 8));
+    for (size_t r0 = 0; r0 < n_rows; r0 += rows_per_tile) {
+        const size_t nr = std::min(rows_per_tile, n_rows - r0);
+        for (size_t r = 0; r < nr; ++r)
+            HIP_TRY(hipMemcpyAsync(tile.as<int64_t>() + r * stride, rows[r0 + r], dimension * 8, hipMemcpyHostToDevice, ctx.stream));
+        HIP_TRY(launch_combine_update(acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), tile.as<int64_t>(), 1, 0, nr, stride,
+                                      dimension, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));          // the tile is reused
+    }
+    return SDA_OK;
+}
+
+int column_sum_host(const Ctx& ctx, AccState& acc, DevBuf& tile, DevBuf& d_out, const ModParams& mod,
+                    const int64_t* const* rows, size_t n_rows, size_t dimension, int64_t* out) {
+    SDA_TRY(ctx.use());
+    SDA_TRY(acc.reset(dimension, ctx.stream));
+    SDA_TRY(accumulate_host_rows(ctx, acc, tile, rows, n_rows, dimension));
+    SDA_TRY(d_out.reserve(dimension * 8));
+    HIP_TRY(launch_combine_finish(acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), dimension, mod, d_out.as<int64_t>(), ctx.stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, dimension * 8, hipMemcpyDeviceToHost, ctx.stream));
+    return ctx.sync();
+}
+
+// rand 0.3 Range<i64>: zone = u64::MAX - u64::MAX % range  
+uint64_t rand03_zone(uint64_t range) { return UINT64_MAX - (UINT64_MAX % range); }
+
+// Adds the masks of `n_seeds` ChaCha seeds (8 key words each, host) into acc.
+int chacha_accumulate(const Ctx& ctx, const std::vector<uint32_t>& seeds8, size_t n_seeds, size_t dimension,
+                      const ModParams& mod, AccState& acc, DevBuf& d_seeds, DevBuf& d_flags, DevBuf& d_list) {
+    if (n_seeds == 0 || dimension == 0) return SDA_OK;
+    const uint64_t zone = rand03_zone(mod.m);
+    // expected rejected candidates per seed; above ~1/4 the naive fast path is wasted work
+    const double p_rej = (double)(UINT64_MAX - zone + 1) / 18446744073709551616.0;
+    const bool all_slow = p_rej * (double)dimension > 0.25;
+    const size_t chunk = (size_t)1 << 20;                  // seeds per launch
+    for (size_t s0 = 0; s0 < n_seeds; s0 += chunk) {
+        const size_t ns = std::min(chunk, n_seeds - s0);
+        SDA_TRY(d_seeds.reserve(ns * 32));
+        HIP_TRY(hipMemcpyAsync(d_seeds.p, seeds8.data() + s0 * 8, ns * 32, hipMemcpyHostToDevice, ctx.stream));
+        if (all_slow) {
+            HIP_TRY(launch_chacha_mask_slow(d_seeds.as<uint32_t>(), nullptr, ns, dimension, mod, zone, acc.lo.as<uint64_t>(),
+                                            acc.hi.as<int64_t>(), false, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            continue;
+        }
+        SDA_TRY(d_flags.reserve(ns * 4));
+        HIP_TRY(hipMemsetAsync(d_flags.p, 0, ns * 4, ctx.stream));
+        HIP_TRY(launch_chacha_mask_accumulate(d_seeds.as<uint32_t>(), ns, dimension, mod, zone, acc.lo.as<uint64_t>(),
+                                              acc.hi.as<int64_t>(), d_flags.as<uint32_t>(), ctx.stream));
+        std::vector<uint32_t> flags(ns);
+        HIP_TRY(hipMemcpyAsync(flags.data(), d_flags.p, ns * 4, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        std::vector<uint32_t> list;
+        for (size_t i = 0; i < ns; ++i)
+            if (flags[i]) list.push_back((uint32_t)i);
+        if (!list.empty()) {
+            SDA_TRY(d_list.reserve(list.size() * 4));
+            HIP_TRY(hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx.stream));
+            HIP_TRY(launch_chacha_mask_slow(d_seeds.as<uint32_t>(), d_list.as<uint32_t>(), list.size(), dimension, mod, zone,
+                                            acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), true, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+        }
+    }
+    return SDA_OK;
+}
+
+// seed words (i64, used `as u32`, chacha.rs:62-64) -> 8 ChaCha key words (rand 0.3 from_seed: at most 8)
+void seed_to_key(const int64_t* words, size_t n_words, uint32_t* key8) {
+    for (int i = 0; i < 8; ++i) key8[i] = (size_t)i < n_words ? (uint32_t)(uint64_t)words[i] : 0u;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+// derived scheme properties - protocol/src/crypto.rs:117-155, :67-74
+// -------------------------------------------------------------------------------------------------
+extern "C" uint64_t sda_scheme_input_size(const sda_sharing_scheme_t* s) {
+    return !s ? 0 : sharing_is_additive(s) ? 1 : s->secret_count;
+}
+extern "C" uint64_t sda_scheme_output_size(const sda_sharing_scheme_t* s) { return s ? s->share_count : 0; }
+extern "C" uint64_t sda_scheme_privacy_threshold(const sda_sharing_scheme_t* s) {
+    return !s ? 0 : sharing_is_additive(s) ? s->share_count - 1 : s->privacy_threshold;
+}
+extern "C" uint64_t sda_scheme_reconstruction_threshold(const sda_sharing_scheme_t* s) {
+    return !s ? 0 : sharing_is_additive(s) ? s->share_count : s->privacy_threshold + s->secret_count;
+}
+extern "C" int sda_masking_has_mask(const sda_masking_scheme_t* s) { return s && s->kind != SDA_MASKING_NONE; }
+
+// -------------------------------------------------------------------------------------------------
+// device memory helpers
+// -------------------------------------------------------------------------------------------------
+extern "C" int sda_dev_malloc(void** d_ptr, size_t bytes) {
+    if (!d_ptr) return fail(SDA_ERR_INVALID_ARGUMENT, "d_ptr is NULL");
+    if (sda_device_count() == 0) return fail(SDA_ERR_NO_DEVICE, "%s", sda_strerror(SDA_ERR_NO_DEVICE));
+    HIP_TRY(hipSetDevice(g_device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(SDA_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return SDA_OK;
+}
+extern "C" int sda_dev_free(void* d_ptr) {
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return SDA_OK;
+}
+extern "C" int sda_dev_upload(void* d_dst, const void* h_src, size_t bytes) {
+    if (bytes) HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return SDA_OK;
+}
+extern "C" int sda_dev_download(void* h_dst, const void* d_src, size_t bytes) {
+    if (bytes) HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return SDA_OK;
+}
+extern "C" int sda_dev_memset(void* d_dst, int value, size_t bytes) {
+    if (bytes) HIP_TRY(hipMemset(d_dst, value, bytes));
+    return SDA_OK;
+}
+extern "C" int sda_dev_synchronize(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return SDA_OK;
+}
+
+// =================================================================================================
+// ShareGenerator
+// =================================================================================================
+struct sda_share_generator {
+    sda_sharing_scheme_t scheme;
+    bool additive = true;
+    uint32_t n = 0, k = 1, t = 0;        // shares, secrets per batch, random draws per batch
+    ModParams mod;
+    MontParams mont{0, 0};
+    std::vector<uint64_t> Mmont;         // n x (k+t), Montgomery form
+    MatArg* matarg = nullptr;            // fast path (kernarg copy)
+    bool fast = false;
+    Drbg drbg;
+    Ctx ctx;
+    DevBuf d_M, d_secrets, d_rand, d_out;
+};
+
+// Builds the n x (k+t) share matrix of tss::packed::PackedSecretSharing::share:
+// the polynomial f with f(w2^0) = 0, f(w2^i) = secret_i (i = 1..k), f(w2^(k+j)) = draw_j (j = 1..t),
+// shares f(w3^j), j = 1..n.
+static int build_packed_share_matrix(const sda_sharing_scheme_t& s, uint64_t p, std::vector<uint64_t>& out) {
+    const uint64_t m = s.secret_count + s.privacy_threshold;
+    const uint64_t w2 = h_canon(s.omega_secrets, p), w3 = h_canon(s.omega_shares, p);
+    std::vector<uint64_t> nodes(m + 1), evals(s.share_count);
+    for (uint64_t e = 0; e <= m; ++e) nodes[e] = h_powmod(w2, e, p);
+    for (uint64_t j = 0; j < s.share_count; ++j) evals[j] = h_powmod(w3, j + 1, p);
+    if (!h_all_distinct(nodes))
+        return fail(SDA_ERR_INVALID_ARGUMENT, "omega_secrets has order <= secret_count + privacy_threshold: interpolation nodes collide");
+    if (!h_lagrange_matrix_mont(nodes, evals, 0, p, out)) return fail(SDA_ERR_INVALID_ARGUMENT, "share matrix is singular");
+    return SDA_OK;
+}
+
+static int validate_packed(const sda_sharing_scheme_t& s) {
+    if (s.secret_count < 1) return fail(SDA_ERR_INVALID_ARGUMENT, "secret_count must be >= 1");
+    if (s.share_count < 1) return fail(SDA_ERR_INVALID_ARGUMENT, "share_count must be >= 1");
+    if (s.secret_count + s.privacy_threshold > 4096 || s.share_count > 65535)
+        return fail(SDA_ERR_UNSUPPORTED, "packed scheme too large");
+    if (s.modulus < 3 || (s.modulus & 1) == 0 || !h_is_prime((uint64_t)s.modulus))
+        return fail(SDA_ERR_INVALID_ARGUMENT, "prime_modulus %lld is not an odd prime", (long long)s.modulus);
+    return SDA_OK;
+}
+
+extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_share_generator_t** out) {
+    if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    SDA_TRY(check_scheme_kind(scheme));
+    sda_share_generator* g = new (std::nothrow) sda_share_generator();
+    if (!g) return fail(SDA_ERR_ALLOC, "out of memory");
+    g->scheme = *scheme;
+    int st = make_mod(scheme->modulus, g->mod);
+    if (st == SDA_OK) st = g->drbg.init();
+    if (st == SDA_OK) {
+        if (sharing_is_additive(scheme)) {
+            if (scheme->share_count < 1 || scheme->share_count > 65535)
+                st = fail(SDA_ERR_INVALID_ARGUMENT, "share_count must be in 1..65535");
+            g->additive = true;
+            g->n = (uint32_t)scheme->share_count; g->k = 1; g->t = g->n - 1;
+        } else {
+            st = validate_packed(*scheme);
+            if (st == SDA_OK) {
+                g->additive = false;
+                g->n = (uint32_t)scheme->share_count; g->k = (uint32_t)scheme->secret_count; g->t = (uint32_t)scheme->privacy_threshold;
+                MontCtx mc = h_mont_ctx(g->mod.m);
+                g->mont.p = mc.p; g->mont.pinv = mc.pinv;
+                st = build_packed_share_matrix(*scheme, g->mod.m, g->Mmont);
+            }
+        }
+    }
+    if (st == SDA_OK) st = g->ctx.init();
+    if (st == SDA_OK && !g->additive) {
+        g->fast = packed_fast_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC");
+        if (g->fast) {
+            g->matarg = new (std::nothrow) MatArg();
+            if (!g->matarg) st = fail(SDA_ERR_ALLOC, "out of memory");
+            else {
+                memset(g->matarg, 0, sizeof(MatArg));
+                memcpy(g->matarg->e, g->Mmont.data(), g->Mmont.size() * 8);
+            }
+        } else {
+            st = g->d_M.reserve(g->Mmont.size() * 8);
+            if (st == SDA_OK && hipMemcpy(g->d_M.p, g->Mmont.data(), g->Mmont.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+                st = fail(SDA_ERR_HIP, "uploading the share matrix failed");
+        }
+    }
+    if (st != SDA_OK) { sda_share_generator_free(g); return st; }
+    *out = g;
+    return SDA_OK;
+}
+
+extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
+    if (!g) return;
+    if (g->ctx.device >= 0) (void)hipSetDevice(g->ctx.device);
+    g->d_M.release(); g->d_secrets.release(); g->d_rand.release(); g->d_out.release();
+    g->ctx.destroy();
+    delete g->matarg;
+    delete g;
+}
+
+extern "C" uint64_t sda_share_generator_share_count(const sda_share_generator_t* g) { return g ? g->n : 0; }
+extern "C" uint64_t sda_share_generator_batch_count(const sda_share_generator_t* g, size_t len) {
+    return g ? (len + g->k - 1) / g->k : 0;                                   // batched.rs:23
+}
+extern "C" uint64_t sda_share_generator_rand_count(const sda_share_generator_t* g, size_t len) {
+    return g ? sda_share_generator_batch_count(g, len) * g->t : 0;
+}
+extern "C" int sda_share_generator_set_drbg_key(sda_share_generator_t* g, const uint8_t key[32]) {
+    if (!g || !key) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    key_from_bytes(key, g->drbg.key);
+    g->drbg.next_stream = 0;
+    return SDA_OK;
+}
+
+extern "C" int sda_share_generator_generate_batch_dev(sda_share_generator_t* g, const int64_t* d_secrets,
+                                                      size_t participants, size_t len, size_t secrets_stride,
+                                                      const int64_t* d_rand, size_t rand_stride,
+                                                      uint64_t first_participant, int64_t* d_out,
+                                                      size_t out_stride_participant, size_t out_stride_clerk,
+                                                      void* stream) {
+    if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "generator is NULL");
+    if (participants == 0 || len == 0) return SDA_OK;
+    if (!d_secrets || !d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    SDA_TRY(g->ctx.use());
+    hipStream_t s = g->ctx.pick(stream);
+    GenLayout L;
+    L.secrets = d_secrets; L.secrets_stride = secrets_stride;
+    L.rand = d_rand; L.rand_stride = rand_stride;
+    L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
+    L.participants = participants; L.len = len; L.first_participant = first_participant;
+    if (g->additive) {
+        HIP_TRY(launch_additive_generate(L, g->n, g->mod, g->drbg.key, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->fast) {
+        HIP_TRY(launch_packed_generate(L, g->n, g->k, g->t, g->mod, g->mont, *g->matarg, g->drbg.key, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    // any-shape path: materialise the CSPRNG draws first (identical values to the fused path)
+    if (!d_rand && g->t > 0) {
+        const size_t batches = (len + g->k - 1) / g->k;
+        const size_t rstride = batches * g->t;
+        SDA_TRY(g->d_rand.reserve(participants * rstride * 8));
+        HIP_TRY(launch_drbg_fill(g->d_rand.as<int64_t>(), rstride, participants, batches, g->t, first_participant, g->mod,
+                                 g->drbg.key, g->drbg.rounds, s));
+        L.rand = g->d_rand.as<int64_t>();
+        L.rand_stride = rstride;
+    }
+    HIP_TRY(launch_packed_generate_generic(L, g->n, g->k, g->t, g->mod, g->mont, g->d_M.as<uint64_t>(), s));
+    return SDA_OK;
+}
+
+extern "C" int sda_share_generator_generate(sda_share_generator_t* g, const int64_t* secrets, size_t len,
+                                            const int64_t* rand, size_t rand_len, int64_t* out, size_t out_len) {
+    if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "generator is NULL");
+    const size_t B = (size_t)sda_share_generator_batch_count(g, len);
+    if (out_len != (size_t)g->n * B) return fail(SDA_ERR_INVALID_ARGUMENT, "out_len must be share_count * batches = %zu (got %zu)", (size_t)g->n * B, out_len);
+    if (len == 0) return SDA_OK;                    // zero batches: n empty vectors (batched.rs:25-28)
+    if (!secrets || !out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    const size_t want_rand = B * g->t;
+    if (rand && rand_len != want_rand)
+        return fail(SDA_ERR_INVALID_ARGUMENT, "rand_len must be %zu (got %zu)", want_rand, rand_len);
+    SDA_TRY(g->ctx.use());
+    SDA_TRY(g->d_secrets.reserve(len * 8));
+    const size_t Bs = B + (B & 1);                  // even clerk stride keeps 16-byte stores legal
+    SDA_TRY(g->d_out.reserve((size_t)g->n * Bs * 8));
+    HIP_TRY(hipMemcpyAsync(g->d_secrets.p, secrets, len * 8, hipMemcpyHostToDevice, g->ctx.stream));
+    const int64_t* d_rand = nullptr;
+    DevBuf staged_rand;
+    if (rand && want_rand) {
+        SDA_TRY(staged_rand.reserve(want_rand * 8));
+        HIP_TRY(hipMemcpyAsync(staged_rand.p, rand, want_rand * 8, hipMemcpyHostToDevice, g->ctx.stream));
+        d_rand = staged_rand.as<int64_t>();
+    }
+    const uint64_t stream_id = g->drbg.next_stream++;
+    int st = sda_share_generator_generate_batch_dev(g, g->d_secrets.as<int64_t>(), 1, len, len, d_rand, want_rand, stream_id,
+                                                    g->d_out.as<int64_t>(), (size_t)g->n * Bs, Bs, nullptr);
+    if (st == SDA_OK) {
+        hipError_t e = hipMemcpy2DAsync(out, B * 8, g->d_out.p, Bs * 8, B * 8, g->n, hipMemcpyDeviceToHost, g->ctx.stream);
+        if (e != hipSuccess) st = fail(SDA_ERR_HIP, "hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
+    }
+    if (st == SDA_OK) st = g->ctx.sync(); else (void)hipStreamSynchronize(g->ctx.stream);
+    staged_rand.release();
+    return st;
+}
+
+// =================================================================================================
+// ShareCombiner
+// =================================================================================================
+struct sda_share_combiner {
+    ModParams mod;
+    Ctx ctx;
+    AccState acc;
+    DevBuf tile, d_out;
+    size_t jobs = 0, dimension = 0;
+    bool begun = false;
+};
+
+extern "C" int sda_share_combiner_new(const sda_sharing_scheme_t* scheme, sda_share_combiner_t** out) {
+    if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    SDA_TRY(check_scheme_kind(scheme));
+    sda_share_combiner* c = new (std::nothrow) sda_share_combiner();
+    if (!c) return fail(SDA_ERR_ALLOC, "out of memory");
+    int st = make_mod(scheme->modulus, c->mod);      // sharing/mod.rs:62-68: both variants use the modulus only
+    if (st == SDA_OK) st = c->ctx.init();
+    if (st != SDA_OK) { sda_share_combiner_free(c); return st; }
+    *out = c;
+    return SDA_OK;
+}
+
+extern "C" void sda_share_combiner_free(sda_share_combiner_t* c) {
+    if (!c) return;
+    if (c->ctx.device >= 0) (void)hipSetDevice(c->ctx.device);
+    c->acc.release(); c->tile.release(); c->d_out.release();
+    c->ctx.destroy();
+    delete c;
+}
+
+extern "C" int sda_share_combiner_combine(sda_share_combiner_t* c, const int64_t* const* rows, const size_t* row_lens,
+                                          size_t n_rows, int64_t* out, size_t out_cap, size_t* out_len) {
+    if (!c || !out_len) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_len = 0;
+    if (n_rows == 0) return SDA_OK;                                        // combiner.rs:17
+    if (!rows || !row_lens) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL rows");
+    const size_t dimension = row_lens[0];
+    for (size_t r = 0; r < n_rows; ++r)
+        if (row_lens[r] != dimension) return fail(SDA_ERR_WRONG_DIMENSION, "Wrong dimension");   // combiner.rs:21
+    if (dimension == 0) return SDA_OK;
+    if (!out || out_cap < dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small");
+    for (size_t r = 0; r < n_rows; ++r)
+        if (!rows[r]) return fail(SDA_ERR_INVALID_ARGUMENT, "rows[%zu] is NULL", r);
+    SDA_TRY(column_sum_host(c->ctx, c->acc, c->tile, c->d_out, c->mod, rows, n_rows, dimension, out));
+    *out_len = dimension;
+    return SDA_OK;
+}
+
+extern "C" int sda_share_combiner_begin_dev(sda_share_combiner_t* c, size_t jobs, size_t dimension, void* stream) {
+    if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
+    if (jobs > 65535) return fail(SDA_ERR_UNSUPPORTED, "at most 65535 jobs");
+    SDA_TRY(c->ctx.use());
+    SDA_TRY(c->acc.reset(jobs * dimension, c->ctx.pick(stream)));
+    c->jobs = jobs; c->dimension = dimension; c->begun = true;
+    return SDA_OK;
+}
+
+extern "C" int sda_share_combiner_update_dev(sda_share_combiner_t* c, const int64_t* d_shares, size_t job_stride,
+                                             size_t n_rows, size_t row_stride, void* stream) {
+    if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
+    if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (n_rows == 0 || c->jobs == 0 || c->dimension == 0) return SDA_OK;
+    if (!d_shares) return fail(SDA_ERR_INVALID_ARGUMENT, "d_shares is NULL");
+    SDA_TRY(c->ctx.use());
+    HIP_TRY(launch_combine_update(c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_shares, c->jobs, job_stride, n_rows,
+                                  row_stride, c->dimension, c->ctx.pick(stream)));
+    return SDA_OK;
+}
+
+extern "C" int sda_share_combiner_finish_dev(sda_share_combiner_t* c, int64_t* d_out, void* stream) {
+    if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
+    if (!c->begun) return fail(SDA_ERR_STATE, "finish before begin");
+    if (c->jobs * c->dimension == 0) return SDA_OK;
+    if (!d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "d_out is NULL");
+    SDA_TRY(c->ctx.use());
+    HIP_TRY(launch_combine_finish(c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), c->jobs * c->dimension, c->mod, d_out,
+                                  c->ctx.pick(stream)));
+    return SDA_OK;
+}
+
+extern "C" int sda_share_combiner_begin(sda_share_combiner_t* c, size_t dimension) {
+    return sda_share_combiner_begin_dev(c, 1, dimension, nullptr);
+}
+
+extern "C" int sda_share_combiner_update(sda_share_combiner_t* c, const int64_t* shares, size_t n_rows, size_t row_stride) {
+    if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
+    if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (n_rows == 0 || c->dimension == 0) return SDA_OK;
+    if (!shares) return fail(SDA_ERR_INVALID_ARGUMENT, "shares is NULL");
+    if (row_stride < c->dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "row_stride < dimension");
+    std::vector<const int64_t*> rows(n_rows);
+    for (size_t r = 0; r < n_rows; ++r) rows[r] = shares + r * row_stride;
+    SDA_TRY(c->ctx.use());
+    return accumulate_host_rows(c->ctx, c->acc, c->tile, rows.data(), n_rows, c->dimension);
+}
+
+extern "C" int sda_share_combiner_finish(sda_share_combiner_t* c, int64_t* out) {
+    if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
+    if (!c->begun) return fail(SDA_ERR_STATE, "finish before begin");
+    if (c->dimension == 0) return SDA_OK;
+    if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
+    SDA_TRY(c->d_out.reserve(c->dimension * 8));
+    SDA_TRY(sda_share_combiner_finish_dev(c, c->d_out.as<int64_t>(), nullptr));
+    HIP_TRY(hipMemcpyAsync(out, c->d_out.p, c->dimension * 8, hipMemcpyDeviceToHost, c->ctx.stream));
+    return c->ctx.sync();
+}
+
+extern "C" int sda_share_combiner_combine_dense(sda_share_combiner_t* c, const int64_t* shares, size_t n_rows,
+                                                size_t dimension, size_t row_stride, int64_t* out) {
+    SDA_TRY(sda_share_combiner_begin(c, dimension));
+    SDA_TRY(sda_share_combiner_update(c, shares, n_rows, row_stride));
+    return sda_share_combiner_finish(c, out);
+}
+
+// =================================================================================================
+// SecretReconstructor
+// =================================================================================================
+struct sda_secret_reconstructor {
+    sda_sharing_scheme_t scheme;
+    bool additive = true;
+    size_t dimension = 0;
+    uint32_t n = 0, k = 1, t = 0;
+    ModParams mod;
+    MontParams mont{0, 0};
+    Ctx ctx;
+    AccState acc;
+    DevBuf tile, d_out, d_R, d_shares;
+    std::vector<size_t> cached_indices;
+    bool have_R = false;
+};
+
+extern "C" int sda_secret_reconstructor_new(const sda_sharing_scheme_t* scheme, size_t dimension,
+                                            sda_secret_reconstructor_t** out) {
+    if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    SDA_TRY(check_scheme_kind(scheme));
+    sda_secret_reconstructor* r = new (std::nothrow) sda_secret_reconstructor();
+    if (!r) return fail(SDA_ERR_ALLOC, "out of memory");
+    r->scheme = *scheme;
+    r->dimension = dimension;
+    int st = make_mod(scheme->modulus, r->mod);
+    if (st == SDA_OK) {
+        if (sharing_is_additive(scheme)) {
+            r->additive = true;
+            r->n = (uint32_t)scheme->share_count;
+        } else {
+            st = validate_packed(*scheme);
+            if (st == SDA_OK) {
+                r->additive = false;
+                r->n = (uint32_t)scheme->share_count; r->k = (uint32_t)scheme->secret_count; r->t = (uint32_t)scheme->privacy_threshold;
+                MontCtx mc = h_mont_ctx(r->mod.m);
+                r->mont.p = mc.p; r->mont.pinv = mc.pinv;
+            }
+        }
+    }
+    if (st == SDA_OK) st = r->ctx.init();
+    if (st != SDA_OK) { sda_secret_reconstructor_free(r); return st; }
+    *out = r;
+    return SDA_OK;
+}
+
+extern "C" void sda_secret_reconstructor_free(sda_secret_reconstructor_t* r) {
+    if (!r) return;
+    if (r->ctx.device >= 0) (void)hipSetDevice(r->ctx.device);
+    r->acc.release(); r->tile.release(); r->d_out.release(); r->d_R.release(); r->d_shares.release();
+    r->ctx.destroy();
+    delete r;
+}
+
+// k x n' Lagrange matrix of tss reconstruct: nodes {1} U {w3^(idx+1)}, evaluated at w2^e, e = 1..k;
+// the column of node 1 (value 0) is dropped.  Identical for every batch, so it is built once per
+// clerk-index set instead of once per batch (reference: Newton interpolation per batch).
+static int prepare_R(sda_secret_reconstructor* r, const size_t* indices, size_t n_rows, hipStream_t s) {
+    if (r->have_R && r->cached_indices.size() == n_rows && std::equal(indices, indices + n_rows, r->cached_indices.begin()))
+        return SDA_OK;
+    const uint64_t p = r->mod.m;
+    const uint64_t w2 = h_canon(r->scheme.omega_secrets, p), w3 = h_canon(r->scheme.omega_shares, p);
+    std::vector<uint64_t> nodes(n_rows + 1), evals(r->k);
+    nodes[0] = 1;
+    for (size_t c = 0; c < n_rows; ++c) nodes[c + 1] = h_powmod(w3, (uint64_t)indices[c] + 1, p);
+    for (uint32_t e = 0; e < r->k; ++e) evals[e] = h_powmod(w2, e + 1, p);
+    if (!h_all_distinct(nodes))
+        return fail(SDA_ERR_INVALID_ARGUMENT, "clerk indices map to colliding evaluation points (duplicate index?)");
+    std::vector<uint64_t> R;
+    if (!h_lagrange_matrix_mont(nodes, evals, 0, p, R)) return fail(SDA_ERR_INVALID_ARGUMENT, "reconstruction matrix is singular");
+    SDA_TRY(r->d_R.reserve(R.size() * 8));
+    HIP_TRY(hipMemcpyAsync(r->d_R.p, R.data(), R.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));               // R is a stack vector
+    r->cached_indices.assign(indices, indices + n_rows);
+    r->have_R = true;
+    return SDA_OK;
+}
+
+extern "C" int sda_secret_reconstructor_reconstruct_dev(sda_secret_reconstructor_t* r, const size_t* indices,
+                                                        size_t n_rows, const int64_t* d_shares, size_t row_len,
+                                                        size_t row_stride, int64_t* d_out, size_t out_cap,
+                                                        size_t* out_len, void* stream) {
+    if (!r || !out_len) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_len = 0;
+    SDA_TRY(r->ctx.use());
+    hipStream_t s = r->ctx.pick(stream);
+    if (r->additive) {                                                       // additive.rs:55-73
+        if (n_rows == 0 || row_len == 0) return SDA_OK;
+        if (!d_shares || !d_out || out_cap < row_len) return fail(SDA_ERR_INVALID_ARGUMENT, "bad device buffers");
+        SDA_TRY(r->acc.reset(row_len, s));
+        HIP_TRY(launch_combine_update(r->acc.lo.as<uint64_t>(), r->acc.hi.as<int64_t>(), d_shares, 1, 0, n_rows, row_stride, row_len, s));
+        HIP_TRY(launch_combine_finish(r->acc.lo.as<uint64_t>(), r->acc.hi.as<int64_t>(), row_len, r->mod, d_out, s));
+        *out_len = row_len;
+        return SDA_OK;
+    }
+    if (n_rows < (size_t)r->t + r->k) return fail(SDA_ERR_NOT_ENOUGH_SHARES, "Not enough shares to reconstruct");   // packed_shamir.rs:75
+    if (!indices) return fail(SDA_ERR_INVALID_ARGUMENT, "indices is NULL");
+    const size_t batches = (r->dimension + r->k - 1) / r->k;                 // batched.rs:77
+    if (batches == 0) return SDA_OK;
+    if (row_len < batches) return fail(SDA_ERR_ASSERTION, "share vector shorter than the number of batches (index out of bounds, batched.rs:84)");
+    if (!d_shares || !d_out || out_cap < r->dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "bad device buffers");
+    if (n_rows > 0xFFFFFFFFull) return fail(SDA_ERR_UNSUPPORTED, "too many rows");
+    SDA_TRY(prepare_R(r, indices, n_rows, s));
+    HIP_TRY(launch_packed_reconstruct(d_shares, row_stride, (uint32_t)n_rows, r->k, batches, r->dimension, r->mod, r->mont,
+                                      r->d_R.as<uint64_t>(), d_out, s));
+    *out_len = r->dimension;
+    return SDA_OK;
+}
+
+extern "C" int sda_secret_reconstructor_reconstruct(sda_secret_reconstructor_t* r, const size_t* indices,
+                                                    const int64_t* const* rows, const size_t* row_lens, size_t n_rows,
+                                                    int64_t* out, size_t out_cap, size_t* out_len) {
+    if (!r || !out_len) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_len = 0;
+    if (n_rows > 0 && (!rows || !row_lens)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL rows");
+    if (r->additive) {
+        if (n_rows == 0) return SDA_OK;                                       // additive.rs:57-60
+        const size_t dimension = row_lens[0];
+        for (size_t i = 0; i < n_rows; ++i)
+            if (row_lens[i] != dimension) return fail(SDA_ERR_MISMATCHING_DIMENSION, "Mismatching dimension");   // additive.rs:64
+        if (dimension == 0) return SDA_OK;
+        if (!out || out_cap < dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small");
+        SDA_TRY(column_sum_host(r->ctx, r->acc, r->tile, r->d_out, r->mod, rows, n_rows, dimension, out));
+        *out_len = dimension;
+        return SDA_OK;
+    }
+    if (n_rows < (size_t)r->t + r->k) return fail(SDA_ERR_NOT_ENOUGH_SHARES, "Not enough shares to reconstruct");
+    const size_t batches = (r->dimension + r->k - 1) / r->k;
+    if (batches == 0) return SDA_OK;
+    for (size_t i = 0; i < n_rows; ++i)
+        if (row_lens[i] < batches) return fail(SDA_ERR_ASSERTION, "share vector %zu shorter than the number of batches (index out of bounds, batched.rs:84)", i);
+    if (!out || out_cap < r->dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small");
+    SDA_TRY(r->ctx.use());
+    const size_t stride = batches + (batches & 1);
+    SDA_TRY(r->d_shares.reserve(n_rows * stride * 8));
+    SDA_TRY(r->d_out.reserve(r->dimension * 8));
+    for (size_t i = 0; i < n_rows; ++i)
+        HIP_TRY(hipMemcpyAsync(r->d_shares.as<int64_t>() + i * stride, rows[i], batches * 8, hipMemcpyHostToDevice, r->ctx.stream));
+    size_t n_out = 0;
+    SDA_TRY(sda_secret_reconstructor_reconstruct_dev(r, indices, n_rows, r->d_shares.as<int64_t>(), batches, stride,
+                                                     r->d_out.as<int64_t>(), r->dimension, &n_out, nullptr));
+    HIP_TRY(hipMemcpyAsync(out, r->d_out.p, n_out * 8, hipMemcpyDeviceToHost, r->ctx.stream));
+    SDA_TRY(r->ctx.sync());
+    *out_len = n_out;
+    return SDA_OK;
+}
+
+// =================================================================================================
+// Masking
+// =================================================================================================
+namespace {
+struct MaskCore {
+    sda_masking_scheme_t scheme;
+    ModParams mod{0, 0, 0};
+    Ctx ctx;
+    AccState acc;
+    DevBuf tile, d_a, d_b, d_out, d_seeds, d_flags, d_list;
+    Drbg drbg;
+
+    int init(const sda_masking_scheme_t* s) {
+        if (!s) return fail(SDA_ERR_INVALID_ARGUMENT, "scheme is NULL");
+        if (s->kind != SDA_MASKING_NONE && s->kind != SDA_MASKING_FULL && s->kind != SDA_MASKING_CHACHA)
+            return fail(SDA_ERR_INVALID_ARGUMENT, "unknown masking scheme kind %d", s->kind);
+        scheme = *s;
+        if (s->kind != SDA_MASKING_NONE) {
+            SDA_TRY(make_mod(s->modulus, mod));
+            SDA_TRY(drbg.init());
+            SDA_TRY(ctx.init());           // `None` is the identity and needs no device
+        }
+        return SDA_OK;
+    }
+    void destroy() {
+        if (ctx.device >= 0) (void)hipSetDevice(ctx.device);
+        acc.release(); tile.release(); d_a.release(); d_b.release(); d_out.release();
+        d_seeds.release(); d_flags.release(); d_list.release();
+        ctx.destroy();
+    }
+    size_t seed_words() const { return (size_t)((scheme.seed_bitsize + 31) / 32); }   // chacha.rs:31
+};
+}  // namespace
+
+struct sda_secret_masker { MaskCore core; };
+struct sda_mask_combiner { MaskCore core; };
+struct sda_secret_unmasker { MaskCore core; };
+
+template <typename H>
+static int mask_handle_new(const sda_masking_scheme_t* scheme, H** out) {
+    if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    H* h = new (std::nothrow) H();
+    if (!h) return fail(SDA_ERR_ALLOC, "out of memory");
+    int st = h->core.init(scheme);
+    if (st != SDA_OK) { h->core.destroy(); delete h; return st; }
+    *out = h;
+    return SDA_OK;
+}
+template <typename H>
+static void mask_handle_free(H* h) {
+    if (!h) return;
+    h->core.destroy();
+    delete h;
+}
+
+extern "C" int sda_secret_masker_new(const sda_masking_scheme_t* s, sda_secret_masker_t** out) { return mask_handle_new(s, out); }
+extern "C" void sda_secret_masker_free(sda_secret_masker_t* m) { mask_handle_free(m); }
+extern "C" int sda_mask_combiner_new(const sda_masking_scheme_t* s, sda_mask_combiner_t** out) { return mask_handle_new(s, out); }
+extern "C" void sda_mask_combiner_free(sda_mask_combiner_t* c) { mask_handle_free(c); }
+extern "C" int sda_secret_unmasker_new(const sda_masking_scheme_t* s, sda_secret_unmasker_t** out) { return mask_handle_new(s, out); }
+extern "C" void sda_secret_unmasker_free(sda_secret_unmasker_t* u) { mask_handle_free(u); }
+
+extern "C" int sda_secret_masker_set_drbg_key(sda_secret_masker_t* m, const uint8_t key[32]) {
+    if (!m || !key) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    key_from_bytes(key, m->core.drbg.key);
+    m->core.drbg.next_stream = 0;
+    return SDA_OK;
+}
+
+extern "C" uint64_t sda_secret_masker_mask_len(const sda_secret_masker_t* m, size_t len) {
+    if (!m) return 0;
+    switch (m->core.scheme.kind) {
+        case SDA_MASKING_FULL: return len;
+        case SDA_MASKING_CHACHA: return m->core.seed_words();
+        default: return 0;
+    }
+}
+
+extern "C" int sda_secret_masker_mask(sda_secret_masker_t* m, const int64_t* secrets, size_t len, const int64_t* rand,
+                                      size_t rand_len, int64_t* mask_out, size_t mask_cap, size_t* mask_len,
+                                      int64_t* masked_out) {
+    if (!m || !mask_len) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    *mask_len = 0;
+    if (len > 0 && (!secrets || !masked_out)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    MaskCore& c = m->core;
+    if (c.scheme.kind == SDA_MASKING_NONE) {                                  // none.rs:13-19
+        if (len) memmove(masked_out, secrets, len * 8);
+        return SDA_OK;
+    }
+    const size_t want_mask = (size_t)sda_secret_masker_mask_len(m, len);
+    if (c.scheme.kind == SDA_MASKING_CHACHA && len != c.scheme.dimension)
+        return fail(SDA_ERR_ASSERTION, "assertion failed: `(left == right)` (dimension %llu, secrets %zu) - chacha.rs:26",
+                    (unsigned long long)c.scheme.dimension, len);
+    if (want_mask > 0 && (!mask_out || mask_cap < want_mask)) return fail(SDA_ERR_INVALID_ARGUMENT, "mask buffer too small (need %zu)", want_mask);
+    if (rand && rand_len != want_mask) return fail(SDA_ERR_INVALID_ARGUMENT, "rand_len must be %zu (got %zu)", want_mask, rand_len);
+    SDA_TRY(c.ctx.use());
+    hipStream_t s = c.ctx.stream;
+
+    if (c.scheme.kind == SDA_MASKING_FULL) {                                  // full.rs:21-35
+        if (len == 0) return SDA_OK;
+        SDA_TRY(c.d_a.reserve(len * 8));
+        SDA_TRY(c.d_b.reserve(len * 8));
+        SDA_TRY(c.d_out.reserve(len * 8));
+        HIP_TRY(hipMemcpyAsync(c.d_a.p, secrets, len * 8, hipMemcpyHostToDevice, s));
+        if (rand) {
+            HIP_TRY(hipMemcpyAsync(c.d_b.p, rand, len * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(launch_addsub_mod(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), len, false, c.mod, c.d_out.as<int64_t>(), s));
+            // canonical mask = (rand + 0) mod q
+            SDA_TRY(c.tile.reserve(len * 8));
+            HIP_TRY(hipMemsetAsync(c.d_a.p, 0, len * 8, s));
+            HIP_TRY(launch_addsub_mod(c.d_b.as<int64_t>(), c.d_a.as<int64_t>(), len, false, c.mod, c.tile.as<int64_t>(), s));
+            HIP_TRY(hipMemcpyAsync(c.d_b.p, c.tile.p, len * 8, hipMemcpyDeviceToDevice, s));
+        } else {
+            HIP_TRY(launch_full_mask_drbg(c.d_a.as<int64_t>(), len, c.drbg.next_stream++, c.mod, c.drbg.key, c.drbg.rounds,
+                                          c.d_b.as<int64_t>(), c.d_out.as<int64_t>(), s));
+        }
+        HIP_TRY(hipMemcpyAsync(mask_out, c.d_b.p, len * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(masked_out, c.d_out.p, len * 8, hipMemcpyDeviceToHost, s));
+        SDA_TRY(c.ctx.sync());
+        *mask_len = len;
+        return SDA_OK;
+    }
+
+    // ChaCha - chacha.rs:24-54
+    const size_t nw = c.seed_words();
+    std::vector<int64_t> seed(nw);
+    if (rand) {
+        for (size_t i = 0; i < nw; ++i) seed[i] = (int64_t)(uint32_t)(uint64_t)rand[i];    // words are u32 (chacha.rs:30-33)
+    } else {
+        std::vector<uint32_t> raw(nw ? nw : 1);
+        SDA_TRY(os_entropy(raw.data(), nw * 4));                              // OsRng seed, chacha.rs:29-33
+        for (size_t i = 0; i < nw; ++i) seed[i] = (int64_t)raw[i];
+    }
+    std::vector<uint32_t> key8(8);
+    seed_to_key(seed.data(), nw, key8.data());
+    if (len) {
+        SDA_TRY(c.acc.reset(len, s));
+        SDA_TRY(chacha_accumulate(c.ctx, key8, 1, len, c.mod, c.acc, c.d_seeds, c.d_flags, c.d_list));
+        SDA_TRY(c.d_a.reserve(len * 8));
+        SDA_TRY(c.d_b.reserve(len * 8));
+        SDA_TRY(c.d_out.reserve(len * 8));
+        HIP_TRY(launch_combine_finish(c.acc.lo.as<uint64_t>(), c.acc.hi.as<int64_t>(), len, c.mod, c.d_b.as<int64_t>(), s));
+        HIP_TRY(hipMemcpyAsync(c.d_a.p, secrets, len * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_addsub_mod(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), len, false, c.mod, c.d_out.as<int64_t>(), s));
+        HIP_TRY(hipMemcpyAsync(masked_out, c.d_out.p, len * 8, hipMemcpyDeviceToHost, s));
+        SDA_TRY(c.ctx.sync());
+    }
+    for (size_t i = 0; i < nw; ++i) mask_out[i] = seed[i];                    // chacha.rs:48-50
+    *mask_len = nw;
+    return SDA_OK;
+}
+
+extern "C" int sda_mask_combiner_combine(sda_mask_combiner_t* mc, const int64_t* const* rows, const size_t* row_lens,
+                                         size_t n_rows, int64_t* out, size_t out_cap, size_t* out_len) {
+    if (!mc || !out_len) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_len = 0;
+    if (n_rows > 0 && (!rows || !row_lens)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL rows");
+    MaskCore& c = mc->core;
+    if (c.scheme.kind == SDA_MASKING_NONE) {                                  // none.rs:21-26
+        for (size_t r = 0; r < n_rows; ++r)
+            if (row_lens[r] != 0) return fail(SDA_ERR_ASSERTION, "assertion failed: masks.iter().all(|mask| mask.len() == 0) - none.rs:23");
+        return SDA_OK;
+    }
+    if (c.scheme.kind == SDA_MASKING_FULL) {                                  // full.rs:37-52
+        if (n_rows == 0) return SDA_OK;
+        const size_t dimension = row_lens[0];
+        for (size_t r = 0; r < n_rows; ++r)
+            if (row_lens[r] != dimension) return fail(SDA_ERR_ASSERTION, "assertion failed: `(left == right)` (mask length) - full.rs:43");
+        if (dimension == 0) return SDA_OK;
+        if (!out || out_cap < dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small");
+        for (size_t r = 0; r < n_rows; ++r)
+            if (!rows[r]) return fail(SDA_ERR_INVALID_ARGUMENT, "rows[%zu] is NULL", r);
+        SDA_TRY(column_sum_host(c.ctx, c.acc, c.tile, c.d_out, c.mod, rows, n_rows, dimension, out));
+        *out_len = dimension;
+        return SDA_OK;
+    }
+    // ChaCha - chacha.rs:56-77: result has the CONFIGURED dimension (:58), also for zero seeds
+    const size_t dimension = (size_t)c.scheme.dimension;
+    if (dimension == 0) return SDA_OK;
+    if (!out || out_cap < dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small");
+    std::vector<uint32_t> key8(n_rows * 8);
+    for (size_t r = 0; r < n_rows; ++r) {
+        if (row_lens[r] > 0 && !rows[r]) return fail(SDA_ERR_INVALID_ARGUMENT, "rows[%zu] is NULL", r);
+        seed_to_key(rows[r], row_lens[r], key8.data() + r * 8);
+    }
+    SDA_TRY(c.ctx.use());
+    SDA_TRY(c.acc.reset(dimension, c.ctx.stream));
+    SDA_TRY(chacha_accumulate(c.ctx, key8, n_rows, dimension, c.mod, c.acc, c.d_seeds, c.d_flags, c.d_list));
+    SDA_TRY(c.d_out.reserve(dimension * 8));
+    HIP_TRY(launch_combine_finish(c.acc.lo.as<uint64_t>(), c.acc.hi.as<int64_t>(), dimension, c.mod, c.d_out.as<int64_t>(), c.ctx.stream));
+    HIP_TRY(hipMemcpyAsync(out, c.d_out.p, dimension * 8, hipMemcpyDeviceToHost, c.ctx.stream));
+    SDA_TRY(c.ctx.sync());
+    *out_len = dimension;
+    return SDA_OK;
+}
+
+extern "C" int sda_secret_unmasker_unmask(sda_secret_unmasker_t* u, const int64_t* mask, size_t mask_len,
+                                          const int64_t* masked, size_t masked_len, int64_t* out) {
+    if (!u) return fail(SDA_ERR_INVALID_ARGUMENT, "unmasker is NULL");
+    MaskCore& c = u->core;
+    if (c.scheme.kind == SDA_MASKING_NONE) {                                  // none.rs:28-33
+        if (mask_len != 0) return fail(SDA_ERR_ASSERTION, "assertion failed: `(left == right)` (mask must be empty) - none.rs:30");
+        if (masked_len && (!masked || !out)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
+        if (masked_len) memmove(out, masked, masked_len * 8);
+        return SDA_OK;
+    }
+    if (mask_len != masked_len)                                               // full.rs:58, chacha.rs:83
+        return fail(SDA_ERR_ASSERTION, "assertion failed: `(left == right)` (mask %zu, masked secrets %zu)", mask_len, masked_len);
+    if (masked_len == 0) return SDA_OK;
+    if (!mask || !masked || !out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    SDA_TRY(c.ctx.use());
+    hipStream_t s = c.ctx.stream;
+    SDA_TRY(c.d_a.reserve(masked_len * 8));
+    SDA_TRY(c.d_b.reserve(masked_len * 8));
+    SDA_TRY(c.d_out.reserve(masked_len * 8));
+    HIP_TRY(hipMemcpyAsync(c.d_a.p, masked, masked_len * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c.d_b.p, mask, masked_len * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_addsub_mod(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), masked_len, true, c.mod, c.d_out.as<int64_t>(), s));   // (ms - m) % q
+    HIP_TRY(hipMemcpyAsync(out, c.d_out.p, masked_len * 8, hipMemcpyDeviceToHost, s));
+    return c.ctx.sync();
+}
+
+extern "C" int sda_positive(const int64_t* values, size_t len, int64_t modulus, int64_t* out) {
+    if (len && (!values || !out)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    for (size_t i = 0; i < len; ++i) out[i] = values[i] < 0 ? values[i] + modulus : values[i];   // receive.rs:15
+    return SDA_OK;
+}
+
+// =================================================================================================
+// multi-GPU helper, synthetic input, timing
+// =================================================================================================
+static int device_ready() {
+    if (sda_device_count() == 0) return fail(SDA_ERR_NO_DEVICE, "%s", sda_strerror(SDA_ERR_NO_DEVICE));
+    return SDA_OK;
+}
+
+extern "C" int sda_modsum_parts_dev(int64_t modulus, const int64_t* d_parts, size_t parts, size_t part_stride,
+                                    size_t len, int64_t* d_out, void* stream) {
+    ModParams mod;
+    SDA_TRY(make_mod(modulus, mod));
+    SDA_TRY(device_ready());
+    if (len == 0) return SDA_OK;
+    if (!d_parts || !d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    HIP_TRY(launch_modsum_parts(d_parts, parts, part_stride, len, mod, d_out, reinterpret_cast<hipStream_t>(stream)));
+    return SDA_OK;
+}
+
+extern "C" int sda_fill_synthetic_dev(int64_t* d_out, size_t participants, size_t len, size_t stride,
+                                      uint64_t first_participant, uint64_t seed, int64_t modulus, void* stream) {
+    ModParams mod;
+    SDA_TRY(make_mod(modulus, mod));
+    SDA_TRY(device_ready());
+    if (!d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    HIP_TRY(launch_fill_synthetic(d_out, participants, len, stride, first_participant, seed, mod, reinterpret_cast<hipStream_t>(stream)));
+    return SDA_OK;
+}
+
+extern "C" int sda_event_create(void** ev) {
+    if (!ev) return fail(SDA_ERR_INVALID_ARGUMENT, "ev is NULL");
+    SDA_TRY(device_ready());
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = e;
+    return SDA_OK;
+}
+extern "C" int sda_event_destroy(void* ev) {
+    if (ev) HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)));
+    return SDA_OK;
+}
+extern "C" int sda_event_record(void* ev, void* stream) {
+    HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), reinterpret_cast<hipStream_t>(stream)));
+    return SDA_OK;
+}
+extern "C" int sda_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!ms) return fail(SDA_ERR_INVALID_ARGUMENT, "ms is NULL");
+    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+    HIP_TRY(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+    return SDA_OK;
+}

@@ -1,0 +1,802 @@
+// gfx950 (MI355X / CDNA4) kernels of the SDA secure-aggregation hot path.
+//
+// All of this is HBM-bound integer work: no MFMA, no GEMM reshaping.  The rules that
+// matter are the streaming ones - 16-byte coalesced loads/stores per lane, >> 256 workgroups,
+// several independent loads in flight per lane, nothing re-read - plus keeping the 64-bit modular
+// arithmetic cheap enough (see modarith.hpp) that the ALU stays under the memory time.
+//
+// Kernel            replaces (reference file:line)                               bound
+// ----------------  -----------------------------------------------------------  -------------------
+// additive_gen      additive.rs:32-51 via batched.rs:18-53                        HBM write (8n B/elem)
+// packed_gen        packed_shamir.rs:40-43 -> tss share, via batched.rs:18-53     HBM write (8n/k B/elem)
+// combine_update    combiner.rs:15-29 (also full.rs:37-52, additive.rs:55-73)     HBM read  (8 B/value)
+// packed_reconstruct packed_shamir.rs:73-77 -> tss reconstruct, batched.rs:68-97  tiny
+// chacha_mask_*     chacha.rs:36-39, :60-73 (rand 0.3 ChaChaRng + gen_range)      VALU (ChaCha20)
+// addsub_mod        full.rs:28-31,60-63; chacha.rs:42-45,86-89                    tiny
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "chacha.hpp"
+#include "kernels.hpp"
+#include "modarith.hpp"
+
+namespace sda {
+
+static constexpr int kThreads = 256;
+
+typedef long long ll2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+
+// =================================================================================================
+// sda-drbg-v1: the on-device CSPRNG used when the caller injects no randomness.
+//
+//   value (stream S, batch b, draw i of T):
+//     main candidate : ChaCha block with words 12,13 = I = (b >> 3) * T + i, word 14 = lo32(S),
+//                      word 15 = (S >> 32) & 0xFFFFFF (attempt 0).  The block is computed by the DPP
+//                      quad that owns batches 8*(b>>3) .. +7; lane c = (b & 7) >> 1, e = b & 1;
+//                      x = (out[8e + c] << 32) | out[8e + 4 + c].
+//     acceptance     : Lemire: accept iff lo64(x * m) >= 2^64 mod m; value = hi64(x * m).
+//     retry (rare)   : attempt a = 1, 2, ...: block with words 12,13 = b * T + i, word 15 |= a << 24;
+//                      candidates x_j = (out[2j] << 32) | out[2j+1], j = 0..7, first accepted wins.
+// =================================================================================================
+template <int ROUNDS>
+__device__ __noinline__ uint64_t drbg_retry(const DrbgKey& key, uint64_t stream, uint64_t b, uint32_t T,
+                                            uint32_t i, const ModParams& mod) {
+    uint64_t I = b * (uint64_t)T + i;
+    uint32_t k[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = key.w[j];
+    uint64_t val = 0;
+    for (uint32_t a = 1; a < 256; ++a) {
+        uint32_t o[16];
+        chacha_block_lane<ROUNDS>(k, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream,
+                                  ((uint32_t)(stream >> 32) & 0xFFFFFFu) | (a << 24), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t x = ((uint64_t)o[2 * j] << 32) | o[2 * j + 1];
+            if (lemire_sample(x, mod.m, mod.lemire_thr, val)) return val;
+        }
+    }
+    return val;
+}
+
+// Two uniform values per lane (for batches b0 = 2*pair and b0+1).  ALL FOUR lanes of a quad must
+// be active when this is called (DPP reads its neighbours).
+template <int ROUNDS>
+__device__ __forceinline__ void drbg_pair(const DrbgKey& key, uint64_t stream, uint64_t pair, uint32_t T,
+                                          uint32_t i, const ModParams& mod, uint64_t& r0, uint64_t& r1) {
+    const uint32_t c = threadIdx.x & 3;
+    const uint64_t g = pair >> 2;                       // batch group of 8 = one quad
+    const uint64_t I = g * (uint64_t)T + i;
+    // this lane's column of the input state
+    const uint32_t cst = c == 0 ? SDA_CHACHA_C0 : c == 1 ? SDA_CHACHA_C1 : c == 2 ? SDA_CHACHA_C2 : SDA_CHACHA_C3;
+    const uint32_t kb = c == 0 ? key.w[0] : c == 1 ? key.w[1] : c == 2 ? key.w[2] : key.w[3];
+    const uint32_t kc = c == 0 ? key.w[4] : c == 1 ? key.w[5] : c == 2 ? key.w[6] : key.w[7];
+    const uint32_t ctr = c == 0 ? (uint32_t)I : c == 1 ? (uint32_t)(I >> 32) : c == 2 ? (uint32_t)stream
+                                                                              : ((uint32_t)(stream >> 32) & 0xFFFFFFu);
+    uint32_t o0, o1, o2, o3;
+    chacha_block_quad<ROUNDS>(cst, kb, kc, ctr, o0, o1, o2, o3);
+    const uint64_t x0 = ((uint64_t)o0 << 32) | o1;
+    const uint64_t x1 = ((uint64_t)o2 << 32) | o3;
+    const bool ok0 = lemire_sample(x0, mod.m, mod.lemire_thr, r0);
+    const bool ok1 = lemire_sample(x1, mod.m, mod.lemire_thr, r1);
+    if (__builtin_expect(!ok0, 0)) r0 = drbg_retry<ROUNDS>(key, stream, 2 * pair, T, i, mod);
+    if (__builtin_expect(!ok1, 0)) r1 = drbg_retry<ROUNDS>(key, stream, 2 * pair + 1, T, i, mod);
+}
+
+// ---- small load/store helpers --------------------------------------------------------------------
+__device__ __forceinline__ ll2 load2(const int64_t* p) { return *reinterpret_cast<const ll2*>(p); }
+__device__ __forceinline__ void store2(int64_t* p, uint64_t a, uint64_t b) {
+    ll2 v; v.x = (long long)a; v.y = (long long)b;
+    *reinterpret_cast<ll2*>(p) = v;
+}
+
+// work item -> (participant, chunk)
+__device__ __forceinline__ void split_item(uint64_t item, uint64_t chunks, uint64_t& p, uint64_t& chunk) {
+    p = item / chunks;
+    chunk = item - p * chunks;
+}
+
+// =================================================================================================
+// K1  additive share generation.  One lane = two adjacent elements (16-byte accesses).
+//     shares 0..n-2 are the uniform draws, share n-1 = secret - sum(draws) mod q  (additive.rs:42-47)
+// =================================================================================================
+template <int ROUNDS, bool VEC>
+__global__ __launch_bounds__(kThreads) void additive_gen_kernel(GenLayout L, uint32_t n, ModParams mod,
+                                                                DrbgKey key, uint64_t chunks) {
+    uint64_t p, chunk;
+    split_item(blockIdx.x, chunks, p, chunk);
+    const uint64_t pair = chunk * kThreads + threadIdx.x;
+    const uint64_t b0 = 2 * pair;
+    const bool in0 = b0 < L.len, in1 = b0 + 1 < L.len;
+
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    uint64_t s0 = 0, s1 = 0;
+    if (VEC && in1) {
+        ll2 v = load2(sp + b0);
+        s0 = canon_i64(v.x, mod.m, mod.mu);
+        s1 = canon_i64(v.y, mod.m, mod.mu);
+    } else {
+        if (in0) s0 = canon_i64(sp[b0], mod.m, mod.mu);
+        if (in1) s1 = canon_i64(sp[b0 + 1], mod.m, mod.mu);
+    }
+
+    int64_t* op = L.out + p * L.out_stride_participant + b0;
+    const uint32_t T = n - 1;
+    const uint64_t stream = L.first_participant + p;
+    const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
+    for (uint32_t i = 0; i < T; ++i) {
+        uint64_t r0 = 0, r1 = 0;
+        if (rp) {
+            if (in0) r0 = canon_i64(rp[b0 * T + i], mod.m, mod.mu);
+            if (in1) r1 = canon_i64(rp[(b0 + 1) * T + i], mod.m, mod.mu);
+        } else {
+            drbg_pair<ROUNDS>(key, stream, pair, T, i, mod, r0, r1);
+        }
+        s0 = submod(s0, r0, mod.m);
+        s1 = submod(s1, r1, mod.m);
+        int64_t* o = op + (size_t)i * L.out_stride_clerk;
+        if (VEC && in1) store2(o, r0, r1);
+        else {
+            if (in0) o[0] = (int64_t)r0;
+            if (in1) o[1] = (int64_t)r1;
+        }
+    }
+    int64_t* o = op + (size_t)T * L.out_stride_clerk;
+    if (VEC && in1) store2(o, s0, s1);
+    else {
+        if (in0) o[0] = (int64_t)s0;
+        if (in1) o[1] = (int64_t)s1;
+    }
+}
+
+// =================================================================================================
+// K2  packed-Shamir share generation:  shares[n] = M[n x (K+T)] * [secrets(K) ; draws(T)]  mod p.
+//     One lane = two adjacent batches.  M is in Montgomery form in the kernarg segment (SGPR
+//     operands); each output is an un-reduced 128-bit dot product + one REDC.
+// =================================================================================================
+template <int KT>
+__device__ __forceinline__ uint64_t mont_dot(const uint64_t* __restrict__ row, const uint64_t (&v)[KT],
+                                             uint64_t p, uint64_t pinv) {
+    U128 acc{0, 0};
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+        mac128(acc, row[i], v[i]);
+        // every product is < p^2 <= p*2^62: four of them keep acc < p*2^64; fold after 8, 12, ...
+        if (((i + 1) & 3) == 0 && (i + 1) >= 8) mont_acc_condsub(acc, p);
+    }
+    if (KT > 4 && (KT & 3) != 0) mont_acc_condsub(acc, p);
+    return mont_redc(acc, p, pinv);
+}
+
+template <int K, int T, int ROUNDS, bool VEC>
+__global__ __launch_bounds__(kThreads) void packed_gen_kernel(GenLayout L, uint32_t n, ModParams mod,
+                                                              MontParams mont, MatArg M, DrbgKey key,
+                                                              uint64_t chunks, uint64_t batches) {
+    constexpr int KT = K + T;
+    uint64_t p, chunk;
+    split_item(blockIdx.x, chunks, p, chunk);
+    const uint64_t pair = chunk * kThreads + threadIdx.x;
+    const uint64_t b0 = 2 * pair;
+    const bool in0 = b0 < batches, in1 = b0 + 1 < batches;
+
+    uint64_t v0[KT], v1[KT];
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    const uint64_t e0 = b0 * K;                       // first secret of this lane
+    if (VEC && e0 + 2 * K <= L.len) {                 // interior: K 16-byte loads
+        uint64_t tmp[2 * K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            ll2 v = load2(sp + e0 + 2 * i);
+            tmp[2 * i] = canon_i64(v.x, mod.m, mod.mu);
+            tmp[2 * i + 1] = canon_i64(v.y, mod.m, mod.mu);
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) { v0[i] = tmp[i]; v1[i] = tmp[K + i]; }
+    } else {                                          // ragged tail: zero padding (batched.rs:37-43)
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const uint64_t a = e0 + i, b = e0 + K + i;
+            v0[i] = a < L.len ? canon_i64(sp[a], mod.m, mod.mu) : 0;
+            v1[i] = b < L.len ? canon_i64(sp[b], mod.m, mod.mu) : 0;
+        }
+    }
+
+    if (L.rand) {
+        const int64_t* rp = L.rand + p * L.rand_stride;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            v0[K + i] = in0 ? canon_i64(rp[b0 * T + i], mod.m, mod.mu) : 0;
+            v1[K + i] = in1 ? canon_i64(rp[(b0 + 1) * T + i], mod.m, mod.mu) : 0;
+        }
+    } else {
+        const uint64_t stream = L.first_participant + p;
+#pragma unroll
+        for (int i = 0; i < T; ++i) drbg_pair<ROUNDS>(key, stream, pair, T, i, mod, v0[K + i], v1[K + i]);
+    }
+
+    int64_t* op = L.out + p * L.out_stride_participant + b0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint64_t* row = &M.e[(size_t)j * KT];
+        const uint64_t a = mont_dot<KT>(row, v0, mont.p, mont.pinv);
+        const uint64_t b = mont_dot<KT>(row, v1, mont.p, mont.pinv);
+        int64_t* o = op + (size_t)j * L.out_stride_clerk;
+        if (VEC && in1) store2(o, a, b);
+        else {
+            if (in0) o[0] = (int64_t)a;
+            if (in1) o[1] = (int64_t)b;
+        }
+    }
+}
+
+// any-shape fallback: one lane = one batch, matrix and randomness read from global memory
+__global__ __launch_bounds__(kThreads) void packed_gen_generic_kernel(GenLayout L, uint32_t n, uint32_t k,
+                                                                      uint32_t t, ModParams mod, MontParams mont,
+                                                                      const uint64_t* __restrict__ Mm,
+                                                                      uint64_t chunks, uint64_t batches) {
+    uint64_t p, chunk;
+    split_item(blockIdx.x, chunks, p, chunk);
+    const uint64_t b = chunk * kThreads + threadIdx.x;
+    if (b >= batches) return;
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    const int64_t* rp = L.rand + p * L.rand_stride;
+    const uint32_t kt = k + t;
+    for (uint32_t j = 0; j < n; ++j) {
+        U128 acc{0, 0};
+        uint32_t since = 0;
+        for (uint32_t i = 0; i < kt; ++i) {
+            uint64_t v;
+            if (i < k) {
+                const uint64_t e = b * k + i;
+                v = e < L.len ? canon_i64(sp[e], mod.m, mod.mu) : 0;
+            } else {
+                v = canon_i64(rp[b * t + (i - k)], mod.m, mod.mu);
+            }
+            mac128(acc, Mm[(size_t)j * kt + i], v);
+            if (++since == 4) { mont_acc_condsub(acc, mont.p); since = 0; }
+        }
+        mont_acc_condsub(acc, mont.p);
+        L.out[p * L.out_stride_participant + (size_t)j * L.out_stride_clerk + b] =
+            (int64_t)mont_redc(acc, mont.p, mont.pinv);
+    }
+}
+
+template <int ROUNDS>
+__global__ __launch_bounds__(kThreads) void drbg_fill_kernel(int64_t* out, size_t stride, size_t batches, uint32_t T,
+                                                             uint64_t first_participant, ModParams mod, DrbgKey key,
+                                                             uint64_t chunks) {
+    uint64_t p, chunk;
+    split_item(blockIdx.x, chunks, p, chunk);
+    const uint64_t pair = chunk * kThreads + threadIdx.x;
+    const uint64_t b0 = 2 * pair;
+    int64_t* o = out + p * stride;
+    for (uint32_t i = 0; i < T; ++i) {
+        uint64_t r0, r1;
+        drbg_pair<ROUNDS>(key, first_participant + p, pair, T, i, mod, r0, r1);
+        if (b0 < batches) o[b0 * T + i] = (int64_t)r0;
+        if (b0 + 1 < batches) o[(b0 + 1) * T + i] = (int64_t)r1;
+    }
+}
+
+// =================================================================================================
+// K3  clerk combine: exact 128-bit column sums over rows, reduced once at finish.
+//     One lane = two adjacent columns; UNROLL independent 16-byte loads in flight.
+// =================================================================================================
+__device__ __forceinline__ void acc_add(uint64_t& lo, int64_t& hi, int64_t v) {
+    const uint64_t nl = lo + (uint64_t)v;
+    hi += (v >> 63) + (nl < lo ? 1 : 0);
+    lo = nl;
+}
+
+__device__ __forceinline__ void acc_atomic_add(uint64_t* lo_p, int64_t* hi_p, uint64_t lo, int64_t hi) {
+    if (lo != 0) {
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(lo_p), (unsigned long long)lo);
+        if (old + lo < old) hi += 1;
+    }
+    if (hi != 0) atomicAdd(reinterpret_cast<unsigned long long*>(hi_p), (unsigned long long)hi);
+}
+
+template <bool VEC, int UNROLL>
+__global__ __launch_bounds__(kThreads) void combine_update_kernel(uint64_t* __restrict__ acc_lo,
+                                                                  int64_t* __restrict__ acc_hi,
+                                                                  const int64_t* __restrict__ shares,
+                                                                  size_t job_stride, size_t n_rows,
+                                                                  size_t row_stride, size_t dimension,
+                                                                  size_t rows_per_split, bool atomic) {
+    const size_t pair = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t c0 = 2 * pair;
+    if (c0 >= dimension) return;
+    const bool two = c0 + 1 < dimension;
+    const size_t job = blockIdx.y;
+    const size_t r_begin = (size_t)blockIdx.z * rows_per_split;
+    size_t r_end = r_begin + rows_per_split;
+    if (r_end > n_rows) r_end = n_rows;
+    const int64_t* base = shares + job * job_stride + c0;
+
+    uint64_t lo0 = 0, lo1 = 0;
+    int64_t hi0 = 0, hi1 = 0;
+    size_t r = r_begin;
+    if (VEC && two) {
+        for (; r + UNROLL <= r_end; r += UNROLL) {
+            ll2 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(base + (r + u) * row_stride));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { acc_add(lo0, hi0, v[u].x); acc_add(lo1, hi1, v[u].y); }
+        }
+        for (; r < r_end; ++r) {
+            ll2 v = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(base + r * row_stride));
+            acc_add(lo0, hi0, v.x); acc_add(lo1, hi1, v.y);
+        }
+    } else {
+        for (; r < r_end; ++r) {
+            acc_add(lo0, hi0, base[r * row_stride]);
+            if (two) acc_add(lo1, hi1, base[r * row_stride + 1]);
+        }
+    }
+
+    const size_t idx = job * dimension + c0;
+    if (atomic) {
+        acc_atomic_add(acc_lo + idx, acc_hi + idx, lo0, hi0);
+        if (two) acc_atomic_add(acc_lo + idx + 1, acc_hi + idx + 1, lo1, hi1);
+    } else {
+        uint64_t l = acc_lo[idx]; int64_t h = acc_hi[idx];
+        uint64_t nl = l + lo0; h += hi0 + (nl < l ? 1 : 0);
+        acc_lo[idx] = nl; acc_hi[idx] = h;
+        if (two) {
+            l = acc_lo[idx + 1]; h = acc_hi[idx + 1];
+            nl = l + lo1; h += hi1 + (nl < l ? 1 : 0);
+            acc_lo[idx + 1] = nl; acc_hi[idx + 1] = h;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void combine_finish_kernel(const uint64_t* __restrict__ acc_lo,
+                                                                  const int64_t* __restrict__ acc_hi, size_t count,
+                                                                  ModParams mod, int64_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= count) return;
+    out[i] = (int64_t)mod_i128(acc_lo[i], acc_hi[i], mod.m, mod.mu);
+}
+
+// =================================================================================================
+// K4  packed reconstruct: secrets[k] = R[k x n'] * sums[n'] per batch (R in Montgomery form).
+// =================================================================================================
+__global__ __launch_bounds__(kThreads) void packed_reconstruct_kernel(const int64_t* __restrict__ shares,
+                                                                      size_t row_stride, uint32_t n_rows, uint32_t k,
+                                                                      size_t batches, size_t dimension, ModParams mod,
+                                                                      MontParams mont,
+                                                                      const uint64_t* __restrict__ Rm,
+                                                                      int64_t* __restrict__ out) {
+    const size_t b = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (b >= batches) return;
+    for (uint32_t e = 0; e < k; ++e) {
+        const size_t o = b * k + e;
+        if (o >= dimension) break;                       // truncate padding (batched.rs:94)
+        U128 acc{0, 0};
+        uint32_t since = 0;
+        for (uint32_t c = 0; c < n_rows; ++c) {
+            const uint64_t v = canon_i64(shares[(size_t)c * row_stride + b], mod.m, mod.mu);
+            mac128(acc, Rm[(size_t)e * n_rows + c], v);
+            if (++since == 4) { mont_acc_condsub(acc, mont.p); since = 0; }
+        }
+        mont_acc_condsub(acc, mont.p);
+        out[o] = (int64_t)mont_redc(acc, mont.p, mont.pinv);
+    }
+}
+
+// =================================================================================================
+// K6  element-wise (a +- b) mod m
+// =================================================================================================
+__global__ __launch_bounds__(kThreads) void addsub_mod_kernel(const int64_t* __restrict__ a,
+                                                              const int64_t* __restrict__ b, size_t len,
+                                                              bool subtract, ModParams mod,
+                                                              int64_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= len) return;
+    const uint64_t x = canon_i64(a[i], mod.m, mod.mu), y = canon_i64(b[i], mod.m, mod.mu);
+    out[i] = (int64_t)(subtract ? submod(x, y, mod.m) : addmod(x, y, mod.m));
+}
+
+template <int ROUNDS>
+__global__ __launch_bounds__(kThreads) void full_mask_drbg_kernel(const int64_t* __restrict__ secrets, size_t len,
+                                                                  uint64_t stream, ModParams mod, DrbgKey key,
+                                                                  int64_t* __restrict__ mask,
+                                                                  int64_t* __restrict__ masked) {
+    const uint64_t pair = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t b0 = 2 * pair;
+    uint64_t r0, r1;
+    drbg_pair<ROUNDS>(key, stream, pair, 1, 0, mod, r0, r1);
+    if (b0 < len) {
+        mask[b0] = (int64_t)r0;
+        masked[b0] = (int64_t)addmod(canon_i64(secrets[b0], mod.m, mod.mu), r0, mod.m);
+    }
+    if (b0 + 1 < len) {
+        mask[b0 + 1] = (int64_t)r1;
+        masked[b0 + 1] = (int64_t)addmod(canon_i64(secrets[b0 + 1], mod.m, mod.mu), r1, mod.m);
+    }
+}
+
+// =================================================================================================
+// K5  rand-0.3 ChaChaRng mask expansion (chacha.rs:36-39, :60-73).
+//     Stream of seed s: block j (128-bit counter = j, key = seed words) -> 8 candidates
+//     v_m = (word[2m] << 32) | word[2m+1]; candidate accepted iff v < zone; mask = v % m; the i-th
+//     mask is the i-th ACCEPTED candidate.  Fast path: assume no rejection (candidate index ==
+//     mask index), one lane owns 8 output positions and loops over seeds; a rejected candidate
+//     flags its seed, and flagged seeds are corrected by the exact sequential-order slow kernel.
+// =================================================================================================
+__global__ __launch_bounds__(kThreads) void chacha_mask_fast_kernel(const uint32_t* __restrict__ seeds,
+                                                                    size_t n_seeds, size_t dimension, ModParams mod,
+                                                                    uint64_t zone, uint64_t* __restrict__ acc_lo,
+                                                                    int64_t* __restrict__ acc_hi,
+                                                                    uint32_t* __restrict__ flags,
+                                                                    size_t seeds_per_split) {
+    const uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x;   // ChaCha block index
+    const size_t pos0 = j * 8;
+    if (pos0 >= dimension) return;
+    const size_t s_begin = (size_t)blockIdx.y * seeds_per_split;
+    size_t s_end = s_begin + seeds_per_split;
+    if (s_end > n_seeds) s_end = n_seeds;
+
+    uint64_t lo[8];
+    uint32_t hi[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { lo[m] = 0; hi[m] = 0; }
+
+    for (size_t s = s_begin; s < s_end; ++s) {
+        uint32_t key[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) key[w] = seeds[s * 8 + w];          // wave-uniform -> SGPRs
+        uint32_t o[16];
+        chacha_block_lane<20>(key, (uint32_t)j, (uint32_t)(j >> 32), 0u, 0u, o);
+        bool rejected = false;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const uint64_t v = ((uint64_t)o[2 * m] << 32) | o[2 * m + 1];
+            if (pos0 + m < dimension && v >= zone) rejected = true;
+            const uint64_t r = barrett_mod64(v, mod.m, mod.mu);
+            const uint64_t nl = lo[m] + r;
+            hi[m] += nl < lo[m] ? 1u : 0u;
+            lo[m] = nl;
+        }
+        if (rejected) flags[s] = 1u;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        if (pos0 + m < dimension) acc_atomic_add(acc_lo + pos0 + m, acc_hi + pos0 + m, lo[m], (int64_t)hi[m]);
+}
+
+// exact expansion for the listed seeds; one workgroup per seed walks the candidate stream in order.
+// With subtract_naive the fast kernel's "candidate i -> position i" contribution is taken back.
+__global__ __launch_bounds__(kThreads) void chacha_mask_slow_kernel(const uint32_t* __restrict__ seeds,
+                                                                    const uint32_t* __restrict__ list, size_t dimension,
+                                                                    ModParams mod, uint64_t zone,
+                                                                    uint64_t* __restrict__ acc_lo,
+                                                                    int64_t* __restrict__ acc_hi, bool subtract_naive) {
+    __shared__ uint32_t wave_tot[kThreads / 64];
+    __shared__ uint32_t chunk_total;
+    const uint32_t s = list ? list[blockIdx.x] : blockIdx.x;
+    uint32_t key[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) key[w] = seeds[(size_t)s * 8 + w];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    uint64_t accepted_base = 0;     // masks emitted before this chunk
+    uint64_t block_base = 0;        // first ChaCha block index of this chunk
+    while (accepted_base < dimension) {
+        const uint64_t j = block_base + threadIdx.x;
+        uint32_t o[16];
+        chacha_block_lane<20>(key, (uint32_t)j, (uint32_t)(j >> 32), 0u, 0u, o);
+        uint64_t r[8];
+        uint32_t okmask = 0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const uint64_t v = ((uint64_t)o[2 * m] << 32) | o[2 * m + 1];
+            if (v < zone) okmask |= 1u << m;
+            r[m] = barrett_mod64(v, mod.m, mod.mu);
+        }
+        // exclusive scan of accepted counts over the workgroup (thread order == stream order)
+        const uint32_t cnt = __builtin_popcount(okmask);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+        if (threadIdx.x == kThreads - 1) chunk_total = wave_off + incl;
+        uint64_t pos = accepted_base + wave_off + (incl - cnt);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (subtract_naive) {
+                const uint64_t ci = j * 8 + m;                           // naive position of candidate
+                if (ci < dimension && r[m] != 0)
+                    acc_atomic_add(acc_lo + ci, acc_hi + ci, (uint64_t)0 - r[m], -1);
+            }
+            if (okmask & (1u << m)) {
+                if (pos < dimension) acc_atomic_add(acc_lo + pos, acc_hi + pos, r[m], 0);
+                ++pos;
+            }
+        }
+        __syncthreads();
+        accepted_base += chunk_total;
+        block_base += kThreads;
+        __syncthreads();
+    }
+}
+
+// =================================================================================================
+// synthetic bench input: splitmix64(seed ^ (participant << 32 | i)) mod m
+// =================================================================================================
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kThreads) void fill_synthetic_kernel(int64_t* out, size_t len, size_t stride,
+                                                                  uint64_t first_participant, uint64_t seed,
+                                                                  ModParams mod, uint64_t chunks) {
+    uint64_t p, chunk;
+    split_item(blockIdx.x, chunks, p, chunk);
+    const uint64_t i = chunk * kThreads + threadIdx.x;
+    if (i >= len) return;
+    const uint64_t x = splitmix64(seed ^ (((first_participant + p) << 32) | i));
+    out[p * stride + i] = (int64_t)barrett_mod64(x, mod.m, mod.mu);
+}
+
+__global__ __launch_bounds__(kThreads) void modsum_parts_kernel(const int64_t* __restrict__ parts, size_t n_parts,
+                                                                size_t part_stride, size_t len, ModParams mod,
+                                                                int64_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= len) return;
+    uint64_t lo = 0;
+    int64_t hi = 0;
+    for (size_t g = 0; g < n_parts; ++g) acc_add(lo, hi, parts[g * part_stride + i]);
+    out[i] = (int64_t)mod_i128(lo, hi, mod.m, mod.mu);
+}
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+static inline hipError_t grid_check(uint64_t blocks) {
+    return blocks > 0x7FFFFFFFull ? hipErrorInvalidConfiguration : hipSuccess;
+}
+
+static bool gen_vec_ok(const GenLayout& L, size_t secrets_per_lane_even) {
+    (void)secrets_per_lane_even;
+    return aligned16(L.secrets) && aligned16(L.out) && (L.secrets_stride % 2 == 0) &&
+           (L.out_stride_participant % 2 == 0) && (L.out_stride_clerk % 2 == 0);
+}
+
+template <int ROUNDS>
+static hipError_t additive_launch_r(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key,
+                                    hipStream_t s) {
+    const uint64_t chunks = ceil_div(ceil_div(L.len, 2), kThreads);
+    const uint64_t blocks = chunks * L.participants;
+    if (blocks == 0) return hipSuccess;
+    if (hipError_t e = grid_check(blocks)) return e;
+    if (gen_vec_ok(L, 0))
+        additive_gen_kernel<ROUNDS, true><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, key, chunks);
+    else
+        additive_gen_kernel<ROUNDS, false><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, key, chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_additive_generate(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key,
+                                    int rounds, hipStream_t s) {
+    switch (rounds) {
+        case 20: return additive_launch_r<20>(L, n, mod, key, s);
+        case 12: return additive_launch_r<12>(L, n, mod, key, s);
+        case 8: return additive_launch_r<8>(L, n, mod, key, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// compiled (k, t) pairs of the fast packed kernel: the BASELINE shapes and their reference-valid
+// (tss FFT) neighbours, plus a few small ones used by tests
+#define SDA_PACKED_SHAPES(X) X(3, 1) X(3, 4) X(8, 2) X(8, 7) X(1, 1) X(2, 1) X(1, 2) X(2, 5) X(4, 3)
+
+bool packed_fast_path_available(uint32_t k, uint32_t t, uint32_t n) {
+    if ((uint64_t)n * (k + t) > SDA_MAT_ARG_MAX) return false;
+#define X(K_, T_) if (k == K_ && t == T_) return true;
+    SDA_PACKED_SHAPES(X)
+#undef X
+    return false;
+}
+
+template <int K, int T, int ROUNDS>
+static hipError_t packed_launch_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const MontParams& mont,
+                                   const MatArg& M, const DrbgKey& key, hipStream_t s) {
+    const uint64_t batches = ceil_div(L.len, K);
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    const uint64_t blocks = chunks * L.participants;
+    if (blocks == 0) return hipSuccess;
+    if (hipError_t e = grid_check(blocks)) return e;
+    if (gen_vec_ok(L, 0))
+        packed_gen_kernel<K, T, ROUNDS, true><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, mont, M, key,
+                                                                                                 chunks, batches);
+    else
+        packed_gen_kernel<K, T, ROUNDS, false><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, mont, M, key,
+                                                                                                  chunks, batches);
+    return hipGetLastError();
+}
+
+template <int ROUNDS>
+static hipError_t packed_launch_r(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                  const MontParams& mont, const MatArg& M, const DrbgKey& key, hipStream_t s) {
+#define X(K_, T_) if (k == K_ && t == T_) return packed_launch_kt<K_, T_, ROUNDS>(L, n, mod, mont, M, key, s);
+    SDA_PACKED_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                  const MontParams& mont, const MatArg& M, const DrbgKey& key, int rounds,
+                                  hipStream_t s) {
+    switch (rounds) {
+        case 20: return packed_launch_r<20>(L, n, k, t, mod, mont, M, key, s);
+        case 12: return packed_launch_r<12>(L, n, k, t, mod, mont, M, key, s);
+        case 8: return packed_launch_r<8>(L, n, k, t, mod, mont, M, key, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
+                                          const ModParams& mod, const MontParams& mont, const uint64_t* d_Mmont,
+                                          hipStream_t s) {
+    if (!L.rand && t > 0) return hipErrorInvalidValue;
+    const uint64_t batches = ceil_div(L.len, k);
+    const uint64_t chunks = ceil_div(batches, kThreads);
+    const uint64_t blocks = chunks * L.participants;
+    if (blocks == 0) return hipSuccess;
+    if (hipError_t e = grid_check(blocks)) return e;
+    packed_gen_generic_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, k, t, mod, mont, d_Mmont, chunks,
+                                                                                batches);
+    return hipGetLastError();
+}
+
+hipError_t launch_drbg_fill(int64_t* d_out, size_t stride, size_t participants, size_t batches, uint32_t T,
+                            uint64_t first_participant, const ModParams& mod, const DrbgKey& key, int rounds,
+                            hipStream_t s) {
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    const uint64_t blocks = chunks * participants;
+    if (blocks == 0 || T == 0) return hipSuccess;
+    if (hipError_t e = grid_check(blocks)) return e;
+    switch (rounds) {
+        case 20: drbg_fill_kernel<20><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_out, stride, batches, T, first_participant, mod, key, chunks); break;
+        case 12: drbg_fill_kernel<12><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_out, stride, batches, T, first_participant, mod, key, chunks); break;
+        case 8: drbg_fill_kernel<8><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_out, stride, batches, T, first_participant, mod, key, chunks); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const int64_t* d_shares, size_t jobs,
+                                 size_t job_stride, size_t n_rows, size_t row_stride, size_t dimension,
+                                 hipStream_t s) {
+    if (jobs == 0 || n_rows == 0 || dimension == 0) return hipSuccess;
+    if (jobs > 65535) return hipErrorInvalidConfiguration;
+    const uint64_t col_blocks = ceil_div(ceil_div(dimension, 2), kThreads);
+    if (hipError_t e = grid_check(col_blocks)) return e;
+    // enough workgroups to fill 256 CUs several times over; split the rows if the columns cannot
+    const uint64_t want_blocks = 256 * 16;
+    uint64_t split = 1;
+    if (col_blocks * jobs < want_blocks) split = ceil_div(want_blocks, col_blocks * jobs);
+    const uint64_t max_split = ceil_div(n_rows, 16);            // at least 16 rows per split
+    if (split > max_split) split = max_split;
+    if (split > 65535) split = 65535;
+    if (split < 1) split = 1;
+    const size_t rows_per_split = ceil_div(n_rows, split);
+    split = ceil_div(n_rows, rows_per_split);
+    const bool atomic = split > 1;
+    const bool vec = aligned16(d_shares) && (job_stride % 2 == 0) && (row_stride % 2 == 0);
+    dim3 grid((unsigned)col_blocks, (unsigned)jobs, (unsigned)split);
+    if (vec)
+        combine_update_kernel<true, 8><<<grid, dim3(kThreads), 0, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows,
+                                                                       row_stride, dimension, rows_per_split, atomic);
+    else
+        combine_update_kernel<false, 1><<<grid, dim3(kThreads), 0, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows,
+                                                                        row_stride, dimension, rows_per_split, atomic);
+    return hipGetLastError();
+}
+
+hipError_t launch_combine_finish(const uint64_t* d_acc_lo, const int64_t* d_acc_hi, size_t count, const ModParams& mod,
+                                 int64_t* d_out, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    const uint64_t blocks = ceil_div(count, kThreads);
+    if (hipError_t e = grid_check(blocks)) return e;
+    combine_finish_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_acc_lo, d_acc_hi, count, mod, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_packed_reconstruct(const int64_t* d_shares, size_t row_stride, uint32_t n_rows, uint32_t k,
+                                     size_t batches, size_t dimension, const ModParams& mod, const MontParams& mont,
+                                     const uint64_t* d_Rmont, int64_t* d_out, hipStream_t s) {
+    if (batches == 0) return hipSuccess;
+    const uint64_t blocks = ceil_div(batches, kThreads);
+    if (hipError_t e = grid_check(blocks)) return e;
+    packed_reconstruct_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_shares, row_stride, n_rows, k, batches,
+                                                                                dimension, mod, mont, d_Rmont, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_addsub_mod(const int64_t* d_a, const int64_t* d_b, size_t len, bool subtract, const ModParams& mod,
+                             int64_t* d_out, hipStream_t s) {
+    if (len == 0) return hipSuccess;
+    const uint64_t blocks = ceil_div(len, kThreads);
+    if (hipError_t e = grid_check(blocks)) return e;
+    addsub_mod_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_a, d_b, len, subtract, mod, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_full_mask_drbg(const int64_t* d_secrets, size_t len, uint64_t stream_id, const ModParams& mod,
+                                 const DrbgKey& key, int rounds, int64_t* d_mask, int64_t* d_masked, hipStream_t s) {
+    if (len == 0) return hipSuccess;
+    const uint64_t blocks = ceil_div(ceil_div(len, 2), kThreads);
+    if (hipError_t e = grid_check(blocks)) return e;
+    switch (rounds) {
+        case 20: full_mask_drbg_kernel<20><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_secrets, len, stream_id, mod, key, d_mask, d_masked); break;
+        case 12: full_mask_drbg_kernel<12><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_secrets, len, stream_id, mod, key, d_mask, d_masked); break;
+        case 8: full_mask_drbg_kernel<8><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_secrets, len, stream_id, mod, key, d_mask, d_masked); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_chacha_mask_accumulate(const uint32_t* d_seeds, size_t n_seeds, size_t dimension,
+                                         const ModParams& mod, uint64_t zone, uint64_t* d_acc_lo, int64_t* d_acc_hi,
+                                         uint32_t* d_reject_flags, hipStream_t s) {
+    if (n_seeds == 0 || dimension == 0) return hipSuccess;
+    const uint64_t pos_blocks = ceil_div(ceil_div(dimension, 8), kThreads);
+    if (hipError_t e = grid_check(pos_blocks)) return e;
+    const uint64_t want_blocks = 256 * 8;
+    uint64_t split = 1;
+    if (pos_blocks < want_blocks) split = ceil_div(want_blocks, pos_blocks);
+    if (split > n_seeds) split = n_seeds;
+    if (split > 65535) split = 65535;
+    const size_t per = ceil_div(n_seeds, split);
+    split = ceil_div(n_seeds, per);
+    chacha_mask_fast_kernel<<<dim3((unsigned)pos_blocks, (unsigned)split), dim3(kThreads), 0, s>>>(
+        d_seeds, n_seeds, dimension, mod, zone, d_acc_lo, d_acc_hi, d_reject_flags, per);
+    return hipGetLastError();
+}
+
+hipError_t launch_chacha_mask_slow(const uint32_t* d_seeds, const uint32_t* d_list, size_t n_list, size_t dimension,
+                                   const ModParams& mod, uint64_t zone, uint64_t* d_acc_lo, int64_t* d_acc_hi,
+                                   bool subtract_naive, hipStream_t s) {
+    if (n_list == 0 || dimension == 0) return hipSuccess;
+    if (hipError_t e = grid_check(n_list)) return e;
+    chacha_mask_slow_kernel<<<dim3((unsigned)n_list), dim3(kThreads), 0, s>>>(d_seeds, d_list, dimension, mod, zone,
+                                                                              d_acc_lo, d_acc_hi, subtract_naive);
+    return hipGetLastError();
+}
+
+hipError_t launch_modsum_parts(const int64_t* d_parts, size_t parts, size_t part_stride, size_t len,
+                               const ModParams& mod, int64_t* d_out, hipStream_t s) {
+    if (len == 0) return hipSuccess;
+    const uint64_t blocks = ceil_div(len, kThreads);
+    if (hipError_t e = grid_check(blocks)) return e;
+    modsum_parts_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_parts, parts, part_stride, len, mod, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_synthetic(int64_t* d_out, size_t participants, size_t len, size_t stride,
+                                 uint64_t first_participant, uint64_t seed, const ModParams& mod, hipStream_t s) {
+    const uint64_t chunks = ceil_div(len, kThreads);
+    const uint64_t blocks = chunks * participants;
+    if (blocks == 0) return hipSuccess;
+    if (hipError_t e = grid_check(blocks)) return e;
+    fill_synthetic_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_out, len, stride, first_participant, seed,
+                                                                            mod, chunks);
+    return hipGetLastError();
+}
+
+}  // namespace sda
