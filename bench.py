@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py - share-gen + clerk-sum elements/sec (mod q) on MI355X, the metric of BASELINE.json.
+
+One "step" = one pass of the hot path over one tile of synthetic participants resident in HBM:
+  share generation (device CSPRNG)  ->  shares materialised in HBM, job-major [n][P_tile][B]
+  per-clerk modular sum             ->  exact 128-bit accumulators [n][B]
+An *element* is one (participant, vector component) pair, so a step processes P_tile * dim elements.
+Default workload = BASELINE config 3 (configs[2]): packed Shamir t=1, k=3, n=8, dim 1,048,576, 62-bit
+prime, 100k participants = 50 steps of a 2000-participant tile (the configuration the north-star
+target is quoted on).  `--workload additive` = config 2 (configs[1]).
+
+N > 1: one process per GPU (torchrun), participants sharded across ranks (weak scaling: the per-GPU
+tile is fixed), no collective on the data path, ONE modular reduce of the partial clerk sums over
+RCCL at the end of the timed region (sda_amd/distributed.py).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte accounting.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P62 = 4611686006577364993
+OMEGA = {8: 631229665360524489, 9: 3451275676410824977, 16: 2589100645267092065, 27: 365137883145458390}
+SEED = 0x5DA5DA5DA5DA5DA5
+KEY = bytes((i * 7 + 1) & 0xFF for i in range(32))
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (scheme kind, n, k, t, omega_secrets order, omega_shares order, total participants, description)
+    "packed": dict(kind="packed", n=8, k=3, t=1, o2=8, o3=9, participants=100_000,
+                   desc="BASELINE config 3: packed Shamir t=1 k=3 n=8, dim 1048576, 62-bit prime, 100k participants"),
+    "packed_ref": dict(kind="packed", n=8, k=3, t=4, o2=8, o3=9, participants=100_000,
+                       desc="reference-valid tss shape t=4 k=3 n=8 (t+k+1 = 8), dim 1048576, 62-bit prime"),
+    "packed26": dict(kind="packed", n=26, k=8, t=2, o2=16, o3=27, participants=1_000_000,
+                     desc="BASELINE config 4 shape: packed Shamir t=2 k=8 n=26, dim 1048576, 62-bit prime"),
+    "additive": dict(kind="additive", n=3, k=1, t=2, o2=8, o3=9, participants=10_000,
+                     desc="BASELINE config 2: additive 3-way, dim 1048576, 62-bit modulus, 10k participants"),
+}
+
+
+def algorithmic_bytes_per_element(n, k):
+    """share-gen reads 8 B (secret) and writes 8n/k B; clerk-sum reads 8n/k B."""
+    gen = 8.0 + 8.0 * n / k
+    comb = 8.0 * n / k
+    return gen, comb
+
+
+def cpu_baseline(w, dim, budget_s=12.0):
+    """The oracle's reference-faithful scalar port (share-gen + clerk-sum), single thread like the
+    reference, on a bounded sample of the same workload.  Reported, never the thing shipped."""
+    from oracle import coracle
+    packed = 1 if w["kind"] == "packed" else 0
+    args = (packed, P62, w["n"], w["k"], w["t"], OMEGA[w["o2"]], OMEGA[w["o3"]])
+    t0 = time.perf_counter()
+    coracle.baseline_pass(*args, 1, dim, 0, SEED, KEY)
+    one = time.perf_counter() - t0
+    parts = max(1, min(64, int(budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    done, _ = coracle.baseline_pass(*args, parts, dim, 0, SEED, KEY)
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "elements/s", "cores": 1, "kind": "port",
+            "sample": f"{parts} participants x dim {dim} (share-gen incl. buffered ChaCha20 draws + clerk-sum), "
+                      f"oracle/sda_oracle.c single thread, {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="packed", choices=sorted(WORKLOADS))
+    ap.add_argument("--dim", type=int, default=1 << 20)
+    ap.add_argument("--tile", type=int, default=2000, help="participants per step and per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sda_amd import capi, crypto
+    from sda_amd.distributed import modular_allreduce
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    lib = capi.load()
+    capi.check(lib.sda_set_device(local_rank))
+
+    w = WORKLOADS[args.workload]
+    n, k, t, dim, P = w["n"], w["k"], w["t"], args.dim, args.tile
+    if w["kind"] == "packed":
+        scheme = crypto.PackedShamir(k, n, t, P62, OMEGA[w["o2"]], OMEGA[w["o3"]])
+    else:
+        scheme = crypto.Additive(n, P62)
+    B = (dim + k - 1) // k
+    Bs = B + (B & 1)
+
+    gen = crypto.ShareGenerator(scheme)
+    gen.set_drbg_key(KEY)
+    comb = crypto.ShareCombiner(scheme)
+
+    # resident tile: secrets [P][dim], shares job-major [n][P][Bs]  (server snapshot layout, stores.rs:86-101)
+    secrets = torch.empty((P, dim), dtype=torch.int64, device=dev)
+    shares = torch.empty((n, P, Bs), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream or None
+    capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, rank * P, SEED, P62, stream))
+    comb.begin_dev(n, B, stream or 0)
+
+    def step(i):
+        first = (i * world + rank) * P                      # participant ids of this tile (CSPRNG stream ids)
+        gen.generate_batch_dev(secrets.data_ptr(), P, dim, dim, shares.data_ptr(), Bs, P * Bs,
+                               first_participant=first, stream=stream or 0)
+        comb.update_dev(shares.data_ptr(), P * Bs, P, Bs, stream=stream or 0)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    comb.begin_dev(n, B, stream or 0)                       # discard the warm-up contributions
+
+    # per-kernel HIP events on the launch stream (3 per step)
+    evs = []
+    for _ in range(3 * args.steps):
+        e = C.c_void_p()
+        capi.check(lib.sda_event_create(C.byref(e)))
+        evs.append(e)
+
+    sums = torch.empty((n, B), dtype=torch.int64, device=dev)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        capi.check(lib.sda_event_record(evs[3 * i], stream))
+        first = (i * world + rank) * P
+        gen.generate_batch_dev(secrets.data_ptr(), P, dim, dim, shares.data_ptr(), Bs, P * Bs,
+                               first_participant=first, stream=stream or 0)
+        capi.check(lib.sda_event_record(evs[3 * i + 1], stream))
+        comb.update_dev(shares.data_ptr(), P * Bs, P, Bs, stream=stream or 0)
+        capi.check(lib.sda_event_record(evs[3 * i + 2], stream))
+    comb.finish_dev(sums.data_ptr(), stream or 0)
+    total = modular_allreduce(sums, P62) if world > 1 else sums     # X1: the only exchange step
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    gen_ms = comb_ms = 0.0
+    ms = C.c_float()
+    for i in range(args.steps):
+        capi.check(lib.sda_event_elapsed_ms(evs[3 * i], evs[3 * i + 1], C.byref(ms))); gen_ms += ms.value
+        capi.check(lib.sda_event_elapsed_ms(evs[3 * i + 1], evs[3 * i + 2], C.byref(ms))); comb_ms += ms.value
+    gen_ms /= args.steps
+    comb_ms /= args.steps
+    for e in evs:
+        lib.sda_event_destroy(e)
+
+    # size-independent check of the full result: reconstruct(clerk sums) == K * world * (sum of the tile's
+    # secrets) mod p -- every step re-shares the same resident tile with fresh randomness
+    verified = None
+    if not args.no_verify:
+        rec = crypto.SecretReconstructor(scheme, dim)
+        out = torch.empty(dim, dtype=torch.int64, device=dev)
+        idx = list(range(scheme.reconstruction_threshold()))
+        rows = total[:len(idx)].contiguous()
+        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim, stream=stream or 0)
+        # expected: sum over ranks and steps of the column sums of each rank's secrets tile
+        cs = crypto.ShareCombiner(crypto.Additive(2, P62))
+        cs.begin_dev(1, dim, stream or 0)
+        for _ in range(args.steps):
+            cs.update_dev(secrets.data_ptr(), 0, P, dim, stream=stream or 0)
+        exp = torch.empty(dim, dtype=torch.int64, device=dev)
+        cs.finish_dev(exp.data_ptr(), stream or 0)
+        exp_total = modular_allreduce(exp, P62) if world > 1 else exp
+        torch.cuda.synchronize(dev)
+        verified = bool(torch.equal(out, exp_total))
+
+    if rank == 0:
+        elements = float(world) * args.steps * P * dim
+        value = elements / dt
+        gen_b, comb_b = algorithmic_bytes_per_element(n, k)
+        per_launch = P * dim
+        gen_gbs = per_launch * gen_b / (gen_ms * 1e-3) / 1e9
+        comb_gbs = per_launch * comb_b / (comb_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.workload}:tile{P}:dim{dim}", {}).get("gen_bytes_per_launch")
+            except Exception:
+                traffic = None
+        dominant_gen = gen_ms >= comb_ms
+        line = {
+            "metric": "share-gen + clerk-sum elements/sec (mod q)", "value": value, "unit": "elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": w["desc"], "name": args.workload, "dim": dim, "tile_participants": P,
+                       "participants_total": world * args.steps * P, "share_count": n, "secret_count": k,
+                       "privacy_threshold": t, "modulus": P62, "randomness": "on-device ChaCha20 (sda-drbg-v1)",
+                       "parallelism": f"participants sharded x{world}, one modular reduce at the end"},
+            "roofline": {"bound": "hbm",
+                         "kernel": "packed_gen_kernel" if w["kind"] == "packed" else "additive_gen_kernel",
+                         "achieved": gen_gbs if dominant_gen else comb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (gen_gbs if dominant_gen else comb_gbs) / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": per_launch * (gen_b if dominant_gen else comb_b),
+                         "avg_launch_ms": gen_ms if dominant_gen else comb_ms},
+            "kernels": {"share_gen": {"avg_ms": gen_ms, "bytes_per_element": gen_b, "GBps": gen_gbs,
+                                      "frac_of_hbm_peak": gen_gbs / HBM_PEAK_GBS},
+                        "clerk_sum": {"avg_ms": comb_ms, "bytes_per_element": comb_b, "GBps": comb_gbs,
+                                      "frac_of_hbm_peak": comb_gbs / HBM_PEAK_GBS}},
+            "path_roofline": {"bytes_per_element": gen_b + comb_b,
+                              "achieved_GBps": value / world * (gen_b + comb_b) / 1e9,
+                              "frac_of_hbm_peak": value / world * (gen_b + comb_b) / 1e9 / HBM_PEAK_GBS},
+            "verified_reconstruct_equals_sum": verified,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(w, dim)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

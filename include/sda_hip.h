@@ -22,7 +22,9 @@
  *    handle (device scratch, stream, precomputed matrices).  No pointer is retained after return.
  *  - Handles are NOT thread-safe (the reference traits carry no Send/Sync bound); use one per thread.
  *  - All host-buffer calls are blocking.  The *_dev calls take device pointers and a hipStream_t
- *    (passed as void*; NULL = the handle's own stream) and are asynchronous on that stream.
+ *    (passed as void*; NULL = the device's default stream, which every handle uses for its own
+ *    work) and are asynchronous on that stream.  Work issued on different streams is NOT ordered
+ *    by the library.
  *  - There is NO CPU fallback: every compute entry point returns SDA_ERR_NO_DEVICE when no gfx950
  *    device is usable.
  *  - Randomness: the reference draws from OsRng inside generate()/mask() (additive.rs:42-44,

@@ -116,7 +116,10 @@ struct Ctx {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(SDA_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // All work is issued on the device's default (null) stream unless the caller passes one:
+        // handles then serialise against each other (generate -> combine -> reconstruct) with no
+        // cross-stream hazards.  Callers wanting overlap pass their own streams to the *_dev calls.
+        stream = nullptr;
         return SDA_OK;
     }
     int use() const {
@@ -128,13 +131,7 @@ struct Ctx {
         HIP_TRY(hipStreamSynchronize(stream));
         return SDA_OK;
     }
-    void destroy() {
-        if (stream) {
-            (void)hipSetDevice(device);
-            (void)hipStreamDestroy(stream);
-            stream = nullptr;
-        }
-    }
+    void destroy() { stream = nullptr; }
 };
 
 // grow-only device buffer

@@ -1,0 +1,114 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every
+symbol include/sda_hip.h declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "sda_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return set(re.findall(r"\b(sda_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_library_exports_every_declared_symbol(built):
+    from sda_amd import capi
+    lib = capi.load()
+    declared = _declared()
+    assert len(declared) >= 50
+    assert declared == set(capi.SIGNATURES), (declared ^ set(capi.SIGNATURES))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (sda_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    assert lib.sda_abi_version() == 1 and b"gfx950" in lib.sda_version()
+
+
+def test_library_is_gfx950_only_and_links_no_oracle(built):
+    from sda_amd import capi
+    out = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", capi.LIB_PATH], text=True)
+    assert "libamdhip64" in out and "oracle" not in out
+    raw = open(capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in raw and b"gfx942" not in raw and b"sm_" not in raw
+
+
+def test_product_does_not_import_oracle():
+    """The product path must not route through the oracle or any CPU fallback."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sda_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("# oracle", "").lower() or f in (), (f, "mentions the oracle")
+
+
+def test_scheme_derived_sizes(built):
+    """protocol/src/crypto.rs:120-153."""
+    from sda_amd import capi
+    lib = capi.load()
+    add = capi.SharingScheme(capi.SHARING_ADDITIVE, 3, 433, 0, 0, 0, 0)
+    pss = capi.SharingScheme(capi.SHARING_PACKED_SHAMIR, 8, 433, 3, 4, 354, 150)
+    assert (lib.sda_scheme_input_size(C.byref(add)), lib.sda_scheme_output_size(C.byref(add)),
+            lib.sda_scheme_privacy_threshold(C.byref(add)), lib.sda_scheme_reconstruction_threshold(C.byref(add))) == (1, 3, 2, 3)
+    assert (lib.sda_scheme_input_size(C.byref(pss)), lib.sda_scheme_output_size(C.byref(pss)),
+            lib.sda_scheme_privacy_threshold(C.byref(pss)), lib.sda_scheme_reconstruction_threshold(C.byref(pss))) == (3, 8, 4, 7)
+    for kind, want in ((capi.MASKING_NONE, 0), (capi.MASKING_FULL, 1), (capi.MASKING_CHACHA, 1)):
+        ms = capi.MaskingScheme(kind, 433, 4, 128)
+        assert lib.sda_masking_has_mask(C.byref(ms)) == want
+
+
+def test_positive_is_receive_rs(built):
+    from sda_amd import crypto
+    out = crypto.RecipientOutput(433, np.array([-1, 0, 432, -432], dtype=np.int64)).positive()
+    assert out.values.tolist() == [432, 0, 432, 1]                           # receive.rs:15
+
+
+def test_error_strings_mirror_the_reference(built):
+    from sda_amd import capi
+    lib = capi.load()
+    want = {capi.ERR_BATCH_INPUT_WRONG_LENGTH: "Batch input wrong length",                      # additive.rs:33
+            capi.ERR_SHARING_FAILED: "Sharing failed for packed secret sharing scheme",        # packed_shamir.rs:41
+            capi.ERR_INPUTS_MUST_HAVE_SAME_LENGTH: "Inputs must have same length",             # packed_shamir.rs:74
+            capi.ERR_NOT_ENOUGH_SHARES: "Not enough shares to reconstruct",                    # packed_shamir.rs:75
+            capi.ERR_WRONG_DIMENSION: "Wrong dimension",                                       # combiner.rs:21
+            capi.ERR_MISMATCHING_DIMENSION: "Mismatching dimension"}                           # additive.rs:64
+    for code, msg in want.items():
+        assert lib.sda_strerror(code).decode() == msg
+
+
+def test_fails_loudly_without_a_gpu(built):
+    """No silent CPU path: on a box without a GPU every handle constructor reports NO_DEVICE."""
+    from sda_amd import capi, crypto
+    lib = capi.load()
+    if lib.sda_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    for make in (lambda: crypto.ShareGenerator(crypto.Additive(3, 433)),
+                 lambda: crypto.ShareCombiner(crypto.Additive(3, 433)),
+                 lambda: crypto.SecretReconstructor(crypto.Additive(3, 433), 4),
+                 lambda: crypto.SecretMasker(crypto.Full(433)),
+                 lambda: crypto.MaskCombiner(crypto.ChaCha(433, 4, 128)),
+                 lambda: crypto.SecretUnmasker(crypto.Full(433))):
+        with pytest.raises(capi.SdaError) as e:
+            make()
+        assert e.value.code == capi.ERR_NO_DEVICE and "no CPU fallback" in e.value.message
+    p = C.c_void_p()
+    assert lib.sda_dev_malloc(C.byref(p), 64) == capi.ERR_NO_DEVICE
+    # parameter validation happens before the device is touched
+    with pytest.raises(capi.SdaError) as e:
+        crypto.ShareGenerator(crypto.Additive(3, 1))
+    assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.SdaError) as e:
+        crypto.ShareGenerator(crypto.PackedShamir(3, 8, 4, 435, 354, 150))
+    assert e.value.code == capi.ERR_INVALID_ARGUMENT and "prime" in e.value.message
+
+
+def test_missing_library_raises(built, monkeypatch):
+    from sda_amd import capi
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", os.path.join(ROOT, "sda_amd", "lib", "nope.so"))
+    with pytest.raises(OSError, match="no fallback"):
+        capi.load()

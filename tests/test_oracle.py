@@ -1,0 +1,239 @@
+"""CPU tests of the ORACLE itself: pin it against every golden vector / KAT available for this path
+ and cross-check its two implementations (Python big-int vs C) and its two
+formulations (tss FFT/Newton vs Lagrange matrix)."""
+import itertools
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import coracle, pyoracle as po
+
+P62 = po.P62
+
+
+# ---- golden vectors held by the reference's own tests ----------------------------------------------------
+def test_reference_end_to_end_vectors():
+    """F0-F4 (full_loop.rs:29-67 -> [2,4,6,8]; README.md:157 -> 0 2 2 4 4 6 6 8 8 10): recompute every
+    committed scenario from its recorded randomness in both value modes."""
+    for sc in load_golden("full_loop.json")["scenarios"]:
+        for mode in ("rust_signed", "canonical"):
+            r = po.full_aggregation(sc["aggregation"], sc["inputs"], sc["mask_rand"], sc["share_rand"],
+                                    sc["clerk_subset"], mode)
+            assert r["positive"] == sc["expected_positive"], sc["name"]
+            assert r == sc["stages"][mode], sc["name"]
+    names = [s["name"] for s in load_golden("full_loop.json")["scenarios"]]
+    assert names[:5] == ["F0_readme_walkthrough", "F1_simple", "F2_with_fullmask", "F3_with_chachamask",
+                         "F4_with_packedshamir"]
+
+
+def test_full_loop_any_randomness():
+    """The reference uses OsRng: the revealed output must not depend on the draws (F1-F4)."""
+    rnd = random.Random(7)
+    add = dict(kind="Additive", share_count=3, modulus=433)
+    for msk, shr in itertools.product(
+            [dict(kind="None"), dict(kind="Full", modulus=433), dict(kind="ChaCha", modulus=433, dimension=4, seed_bitsize=128)],
+            [add, dict(po.PSS_433)]):
+        a = dict(vector_dimension=4, modulus=433, masking_scheme=msk, committee_sharing_scheme=shr)
+        gen = po.new_share_generator(shr)
+        nb = (4 + gen.batch_input_size() - 1) // gen.batch_input_size()
+        for _ in range(5):
+            mr = [[rnd.randrange(433) for _ in range(4)] if msk["kind"] == "Full" else [rnd.getrandbits(32) for _ in range(4)]
+                  for _ in range(2)]
+            sr = [[rnd.randrange(432) for _ in range(nb * gen.rand_per_batch())] for _ in range(2)]
+            for mode in ("rust_signed", "canonical"):
+                assert po.full_aggregation(a, [[1, 2, 3, 4]] * 2, mr, sr, None, mode)["positive"] == [2, 4, 6, 8]
+
+
+# ---- third-party KATs (tss 0.2, rand 0.3 / RFC 7539) -----------------------------------------------------------
+def test_tss_kats():
+    k = load_golden("kats.json")["kats"]
+    pss = po.PackedSecretSharing(4, 8, 3, 433, 354, 150)
+    b1 = k["B1_recover_polynomial"]
+    coeffs = pss.recover_polynomial([1, 2, 3], [8, 8, 8, 8])
+    assert coeffs == b1["recalled_signed"] == b1["signed"]          # tss test_recover_polynomial, exact signs
+    assert [c % 433 for c in coeffs] == b1["recalled_canonical"]
+    pss26 = po.PackedSecretSharing(4, 26, 3, 433, 354, 17)
+    ev = pss26.evaluate_polynomial(coeffs + [0] * 19)
+    assert [e % 433 for e in ev] == k["B2_evaluate_polynomial"]["recalled_canonical"]   # tss test_evaluate_polynomial
+    # independent re-derivation: direct DFT
+    assert [e % 433 for e in ev] == [sum(c * pow(17, i * j, 433) for j, c in enumerate(coeffs)) % 433 for i in range(27)]
+    assert [s % 433 for s in pss.share_fft([1, 2, 3], [8, 8, 8, 8])] == k["B3_share"]["expected"]
+    assert pss.share_lagrange([1, 2, 3], [8, 8, 8, 8]) == k["B3_share"]["expected"]
+    assert pss.share_matrix()[0] == k["B4_share_matrix_row0"]["expected"]
+    for idx in k["B5_reconstruct"]["index_sets"]:
+        sh = [k["B5_reconstruct"]["shares"][i] for i in idx]
+        assert [v % 433 for v in pss.reconstruct_newton(idx, sh)] == [1, 2, 3]
+        assert pss.reconstruct_lagrange(idx, sh) == [1, 2, 3]
+
+
+def test_chacha_kats():
+    k = load_golden("kats.json")["kats"]
+    blk = po.chacha_block(list(po.CHACHA_CONST) + [0] * 12)
+    assert [hex(w) for w in blk[:4]] == k["C1_chacha20_zero_key_block0"]["expected_first4"]   # RFC 7539 keystream
+    # RFC 7539 section 2.3.2 block function test vector (key 00..1f, counter 1, nonce 00 00 00 09 00 00 00 4a 00 00 00 00)
+    key = [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)]
+    st = list(po.CHACHA_CONST) + key + [1, 0x09000000, 0x4a000000, 0]
+    out = po.chacha_block(st)
+    assert out[:4] == [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3]
+    assert out[12:] == [0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    assert list(coracle.chacha_block(st)) == out
+    assert po.ChaChaMasker(433, 8, 128).expand([0, 0, 0, 0]) == k["C2_masks_seed0"]["expected"]
+    assert po.ChaChaMasker(433, 8, 128).expand([1, 2, 3, 4]) == k["C3_masks_seed1234"]["expected"]
+    assert hex(po.ChaChaRng([1, 2, 3, 4]).next_u64()) == k["C3_masks_seed1234"]["expected_first_u64"]
+    assert list(coracle.chacha_expand([1, 2, 3, 4], 433, 8)) == k["C3_masks_seed1234"]["expected"]
+
+
+def test_chacha_counter_carry_and_rejection():
+    rng = po.ChaChaRng([5])
+    rng.state[12] = 0xFFFFFFFF
+    rng._update()
+    assert rng.state[12] == 0 and rng.state[13] == 1          # 128-bit counter carries
+    q = (1 << 61) + 1                                         # ~12% of candidates are rejected
+    n = 2000
+    want = po.ChaChaMasker(q, n, 128).expand([7, 7, 7, 7])
+    r2 = po.ChaChaRng([7, 7, 7, 7])
+    zone = po.MASK64 - (po.MASK64 % q)
+    vals, rejected = [], 0
+    while len(vals) < n:
+        v = r2.next_u64()
+        if v < zone:
+            vals.append(v % q)
+        else:
+            rejected += 1
+    assert rejected > 100 and vals == want
+    assert list(coracle.chacha_expand([7, 7, 7, 7], q, n)) == want
+
+
+# ---- FFT / Newton (tss) == Lagrange matrix (what the HIP path implements) -------------------------------------
+@pytest.mark.parametrize("prime,w2,w3,t,k,n", [(433, 354, 150, 4, 3, 8), (433, 354, 17, 4, 3, 26),
+                                               (746497, 95660, 610121, 155, 100, 728)])
+def test_tss_fft_equals_matrix_form(prime, w2, w3, t, k, n):
+    pss = po.PackedSecretSharing(t, n, k, prime, w2, w3)
+    assert pss.is_fft_shape()
+    rnd = random.Random(prime)
+    reps = 1 if n > 100 else 20
+    M = pss.share_matrix()
+    for _ in range(reps):
+        s = [rnd.randrange(prime) for _ in range(k)]
+        r = [rnd.randrange(prime - 1) for _ in range(t)]
+        fft = pss.share_fft(s, r, "rust_signed")
+        assert [v % prime for v in fft] == [sum(a * b for a, b in zip(row, s + r)) % prime for row in M]
+        idx = sorted(rnd.sample(range(n), t + k if n > 100 else rnd.randrange(t + k, n + 1)))
+        sh = [fft[i] for i in idx]
+        if n <= 100:
+            assert [v % prime for v in pss.reconstruct_newton(idx, sh)] == s
+        assert pss.reconstruct_lagrange(idx, sh) == s
+
+
+def test_p62_parameters():
+    """the 62-bit prime and its roots of unity."""
+    assert P62.bit_length() == 62 and 4 * P62 < 2 ** 64 <= 8 * P62
+    for order, w in po.P62_OMEGA.items():
+        assert pow(w, order, P62) == 1
+        for d in range(1, order):
+            if order % d == 0:
+                assert pow(w, d, P62) != 1
+    for sc in load_golden("p62.json")["scenarios"]:
+        modes = ["canonical"] + (["rust_signed"] if "rust_signed" in sc["stages"] else [])
+        for mode in modes:
+            r = po.full_aggregation(sc["aggregation"], sc["inputs"], sc.get("mask_rand", [[]] * len(sc["inputs"])),
+                                    sc["share_rand"], sc["clerk_subset"], mode)
+            assert r == sc["stages"][mode]
+            assert r["positive"] == [sum(col) % P62 for col in zip(*sc["inputs"])]
+
+
+# ---- C oracle == Python oracle -------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode_name,mode", [("canonical", 0), ("rust_signed", 1)])
+def test_c_oracle_additive_and_combine(mode_name, mode):
+    rnd = random.Random(3)
+    for q, n, dim in [(433, 3, 10), (P62, 3, 17), (P62, 5, 4), (97, 1, 6), (2, 3, 9)]:
+        secrets = [rnd.randrange(q) for _ in range(dim)]
+        rand = [rnd.randrange(q) for _ in range(dim * (n - 1))]
+        gen = po.AdditiveSecretSharing(n, q, mode_name)
+        want = po.generate(gen, secrets, rand)
+        got = coracle.additive_generate(q, n, secrets, rand, mode)
+        assert got.tolist() == want
+        rows = [[rnd.randrange(-(q - 1), q) for _ in range(dim)] for _ in range(6)]
+        assert coracle.combine(q, rows, mode).tolist() == po.combine(rows, q, mode_name)
+        a = [rnd.randrange(-(q - 1), q) for _ in range(dim)]
+        b = [rnd.randrange(q) for _ in range(dim)]
+        rem = po._rem(mode_name)
+        assert coracle.addsub(a, b, q, False, mode).tolist() == [rem(x + y, q) for x, y in zip(a, b)] or mode == 0
+        assert coracle.addsub(a, b, q, True, mode).tolist() == [rem(x - y, q) for x, y in zip(a, b)] or mode == 0
+        assert coracle.addsub(a, b, q, True, 0).tolist() == [(x - y) % q for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("k,t,n,o2,o3", [(3, 1, 8, 8, 9), (3, 4, 8, 8, 9), (8, 2, 26, 16, 27), (8, 7, 26, 16, 27),
+                                         (5, 3, 26, 16, 27)])
+def test_c_oracle_packed(k, t, n, o2, o3):
+    rnd = random.Random(k * 10 + t)
+    w2, w3 = po.P62_OMEGA[o2], po.P62_OMEGA[o3]
+    dim = 4 * k + 1
+    secrets = [rnd.randrange(-(1 << 63), 1 << 63) for _ in range(dim)]
+    B = (dim + k - 1) // k
+    rand = [rnd.randrange(-(1 << 63), 1 << 63) for _ in range(B * t)]
+    gen = po.PackedShamirGenerator(t, n, k, P62, w2, w3, "canonical")
+    want = po.generate(gen, secrets, rand)
+    got = coracle.packed_generate(P62, k, t, n, w2, w3, secrets, rand)
+    assert got.tolist() == want
+    assert coracle.packed_share_matrix(P62, k, t, n, w2, w3).tolist() == gen.pss.share_matrix()
+    idx = sorted(rnd.sample(range(n), t + k + (1 if t + k < n else 0)))
+    rec = po.PackedShamirReconstructor(dim, t, n, k, P62, w2, w3, "canonical")
+    want_s = rec.reconstruct([(i, want[i]) for i in idx])
+    assert want_s == [s % P62 for s in secrets]
+    assert coracle.packed_reconstruct(P62, k, t, w2, w3, dim, idx, got[idx]).tolist() == want_s
+    with pytest.raises(ValueError):
+        coracle.packed_reconstruct(P62, k, t, w2, w3, dim, idx[:t + k - 1], got[idx[:t + k - 1]])
+
+
+def test_c_oracle_chacha_combine():
+    rnd = random.Random(9)
+    for q in (433, P62, (1 << 61) + 1):
+        seeds = [[rnd.getrandbits(32) for _ in range(4)] for _ in range(3)]
+        m = po.ChaChaMasker(q, 50, 128, "canonical")
+        assert coracle.chacha_combine(seeds, q, 50).tolist() == m.combine(seeds)
+    assert coracle.chacha_combine([], 433, 4).tolist() == [0, 0, 0, 0]
+
+
+def test_drbg_spec_c_equals_python_and_golden():
+    g = load_golden("drbg.json")
+    key = bytes.fromhex(g["key_hex"])
+    for c in g["cases"]:
+        want = po.drbg_fill(key, c["stream"], c["batches"], c["T"], c["modulus"], c["rounds"])
+        assert want == c["values"]
+        assert coracle.drbg_fill(key, c["stream"], c["batches"], c["T"], c["modulus"], c["rounds"]).tolist() == want
+        assert all(0 <= v < c["modulus"] for v in want)
+    # retry stream exercised: heavy-rejection modulus
+    m = (1 << 61) + 1
+    assert coracle.drbg_fill(key, 3, 300, 2, m).tolist() == po.drbg_fill(key, 3, 300, 2, m)
+
+
+def test_synthetic_input_and_baseline_pass():
+    a = coracle.fill_synthetic(2, 5, 10, 0x5DA5DA5DA5DA5DA5, P62)
+    assert a.tolist() == [[po.synthetic_secret(0x5DA5DA5DA5DA5DA5, 10 + p, i, P62) for i in range(5)] for p in range(2)]
+    key = bytes(range(32))
+    for packed, n, k, t, o2, o3 in [(1, 8, 3, 1, 8, 9), (0, 3, 1, 2, 8, 9)]:
+        done, sums = coracle.baseline_pass(packed, P62, n, k, t, po.P62_OMEGA[o2], po.P62_OMEGA[o3], 4, 50, 0, 1, key)
+        assert done == 200
+        sec = coracle.fill_synthetic(4, 50, 0, 1, P62)
+        if packed:
+            rec = coracle.packed_reconstruct(P62, k, t, po.P62_OMEGA[o2], po.P62_OMEGA[o3], 50, [1, 3, 5, 7], sums[[1, 3, 5, 7]])
+        else:
+            rec = coracle.combine(P62, sums)
+        assert rec.tolist() == coracle.combine(P62, sec).tolist()
+
+
+def test_positive_and_errors():
+    assert po.positive([-1, 0, 5], 433) == [432, 0, 5] == coracle.positive([-1, 0, 5], 433).tolist()
+    with pytest.raises(ValueError, match="Wrong dimension"):
+        po.combine([[1, 2], [1]], 433)
+    with pytest.raises(ValueError, match="Mismatching dimension"):
+        po.AdditiveSecretSharing(3, 433).reconstruct([(0, [1, 2]), (1, [1])])
+    with pytest.raises(ValueError, match="Not enough shares"):
+        po.PackedShamirReconstructor(3, 4, 8, 3, 433, 354, 150).reconstruct([(i, [1]) for i in range(6)])
+    with pytest.raises(ValueError, match="Batch input wrong length"):
+        po.AdditiveSecretSharing(3, 433).generate_for_batch([1, 2], [0, 0])
+    assert po.combine([], 433) == [] and po.AdditiveSecretSharing(3, 433).reconstruct([]) == []
+    assert po.trunc_rem(-394, 433) == -394 and po.trunc_rem(1 - 400, 433) == -399 and po.trunc_rem(-866, 433) == 0

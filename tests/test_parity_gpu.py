@@ -1,0 +1,454 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle on the same
+inputs.  Bit-exact (integer work).  Run on the GPU box with  pytest -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+P62 = 4611686006577364993
+W = {8: 631229665360524489, 9: 3451275676410824977, 16: 2589100645267092065, 27: 365137883145458390}
+KEY = bytes(range(32))
+
+
+def _scheme(d):
+    from sda_amd import crypto
+    if d["kind"] == "Additive":
+        return crypto.Additive(d["share_count"], d["modulus"])
+    return crypto.PackedShamir(d["secret_count"], d["share_count"], d["privacy_threshold"], d["prime_modulus"],
+                               d["omega_secrets"], d["omega_shares"])
+
+
+def _mask_scheme(d):
+    from sda_amd import crypto
+    if d["kind"] == "None":
+        return crypto.NoMask()
+    if d["kind"] == "Full":
+        return crypto.Full(d["modulus"])
+    return crypto.ChaCha(d["modulus"], d["dimension"], d["seed_bitsize"])
+
+
+def _run_scenario(sc):
+    from sda_amd import crypto
+    a = sc["aggregation"]
+    agg = crypto.Aggregation(a["vector_dimension"], a["modulus"], _mask_scheme(a["masking_scheme"]),
+                             _scheme(a["committee_sharing_scheme"]))
+    mask_rand = sc.get("mask_rand")
+    if a["masking_scheme"]["kind"] == "None":
+        mask_rand = None
+    got = crypto.full_aggregation(agg, sc["inputs"], mask_rand, sc["share_rand"], sc["clerk_subset"])
+    want = sc["stages"]["canonical"]
+    q = a["committee_sharing_scheme"].get("modulus", a["committee_sharing_scheme"].get("prime_modulus"))
+    for p in range(len(sc["inputs"])):
+        assert [list(map(int, row)) for row in got["shares"][p]] == want["shares"][p], f"shares of participant {p}"
+        assert list(map(int, got["masked"][p])) == want["masked"][p]
+        if a["masking_scheme"]["kind"] != "None":
+            assert list(map(int, got["masks"][p])) == want["masks"][p]
+    assert [list(map(int, s)) for s in got["clerk_sums"]] == want["clerk_sums"]
+    assert list(map(int, got["combined_mask"])) == want["combined_mask"]
+    assert list(map(int, got["masked_output"])) == want["masked_output"]
+    assert list(map(int, got["output"])) == want["output"]
+    assert list(map(int, got["positive"])) == want["positive"]
+    if "expected_positive" in sc:
+        assert list(map(int, got["positive"])) == sc["expected_positive"]
+    # rust_signed stage values agree modulo q with what the GPU emits
+    if "rust_signed" in sc["stages"]:
+        rs = sc["stages"]["rust_signed"]
+        assert [[v % q for v in s] for s in rs["clerk_sums"]] == [list(map(int, s)) for s in got["clerk_sums"]]
+        assert rs["positive"] == list(map(int, got["positive"]))
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_reference_full_loop_vectors(gpu, idx):
+    """F0-F4: the reference's own end-to-end vectors (full_loop.rs:29-67,148; README.md:157)."""
+    _run_scenario(load_golden("full_loop.json")["scenarios"][idx])
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_p62_vectors(gpu, idx):
+    """62-bit prime configurations (BASELINE configs 2-4 shapes) incl. un-range-checked i64 inputs."""
+    _run_scenario(load_golden("p62.json")["scenarios"][idx])
+
+
+def test_kats_share_and_reconstruct(gpu):
+    from sda_amd import crypto
+    k = load_golden("kats.json")["kats"]
+    sch = _scheme(k["B3_share"]["scheme"])
+    g = crypto.ShareGenerator(sch)
+    shares = g.generate(k["B3_share"]["secrets"], k["B3_share"]["randomness"])
+    assert [int(s[0]) for s in shares] == k["B3_share"]["expected"]
+    r = crypto.SecretReconstructor(sch, 3)
+    for idx in k["B5_reconstruct"]["index_sets"]:
+        out = r.reconstruct([(i, [k["B5_reconstruct"]["shares"][i]]) for i in idx])
+        assert list(map(int, out)) == k["B5_reconstruct"]["expected"]
+
+
+# ---- share generation vs the C oracle ---------------------------------------------------------------
+@pytest.mark.parametrize("n,q,dim", [(3, 433, 10), (3, P62, 1), (2, P62, 2), (5, P62, 1001), (1, 97, 33),
+                                     (3, (1 << 61) + 20, 4096), (3, 2, 17)])
+def test_additive_generate_injected(gpu, n, q, dim):
+    from sda_amd import crypto
+    from oracle import coracle
+    rng = np.random.default_rng(n * 1000 + dim)
+    secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
+    rand = rng.integers(-(1 << 62), 1 << 62, size=dim * (n - 1), dtype=np.int64)
+    got = crypto.ShareGenerator(crypto.Additive(n, q)).generate(secrets, rand)
+    want = coracle.additive_generate(q, n, secrets, rand, mode=0)
+    assert np.array_equal(got, want)
+    # and mod q against the reference's signed arithmetic on in-range inputs
+    s2 = np.mod(secrets, q)
+    r2 = np.mod(rand, q)
+    signed = coracle.additive_generate(q, n, s2, r2, mode=1)
+    assert np.array_equal(np.mod(signed, q), crypto.ShareGenerator(crypto.Additive(n, q)).generate(s2, r2))
+
+
+PACKED_SHAPES = [(3, 1, 8, 8, 9), (3, 4, 8, 8, 9), (8, 2, 26, 16, 27), (8, 7, 26, 16, 27), (1, 1, 8, 8, 9),
+                 (2, 1, 8, 8, 9), (1, 2, 8, 8, 9), (2, 5, 8, 8, 9), (4, 3, 26, 8, 27),
+                 (5, 3, 26, 16, 27), (3, 0, 8, 8, 9)]   # the last two have no compiled fast path
+
+
+@pytest.mark.parametrize("k,t,n,o2,o3", PACKED_SHAPES)
+@pytest.mark.parametrize("dim", [1, 7, 1000, 6151])
+def test_packed_generate_injected(gpu, k, t, n, o2, o3, dim):
+    from sda_amd import crypto
+    from oracle import coracle
+    rng = np.random.default_rng(k * 100 + t * 10 + dim)
+    secrets = rng.integers(0, P62, size=dim, dtype=np.int64)
+    secrets[::5] = rng.integers(-(1 << 63), (1 << 63) - 1, size=secrets[::5].size, dtype=np.int64)
+    B = (dim + k - 1) // k
+    rand = rng.integers(-(1 << 63), (1 << 63) - 1, size=B * t, dtype=np.int64)
+    sch = crypto.PackedShamir(k, n, t, P62, W[o2], W[o3])
+    got = crypto.ShareGenerator(sch).generate(secrets, rand)
+    want = coracle.packed_generate(P62, k, t, n, W[o2], W[o3], secrets, rand)
+    assert got.shape == (n, B)
+    assert np.array_equal(got, want)
+
+
+def test_packed_generic_path_equals_fast_path(gpu, monkeypatch):
+    from sda_amd import crypto
+    sch = crypto.PackedShamir(3, 8, 1, P62, W[8], W[9])
+    rng = np.random.default_rng(5)
+    secrets = rng.integers(0, P62, size=5000, dtype=np.int64)
+    fast = crypto.ShareGenerator(sch)
+    fast.set_drbg_key(KEY)
+    a = fast.generate(secrets)
+    monkeypatch.setenv("SDA_FORCE_GENERIC", "1")
+    slow = crypto.ShareGenerator(sch)
+    slow.set_drbg_key(KEY)
+    b = slow.generate(secrets)
+    assert np.array_equal(a, b)
+
+
+def test_small_prime_packed_matches_tss_fft_path(gpu):
+    """p = 433 (full_loop.rs:57-64): the matrix form on the GPU equals the recalled tss FFT path."""
+    from sda_amd import crypto
+    from oracle import pyoracle as po
+    pss = po.PackedSecretSharing(4, 8, 3, 433, 354, 150)
+    rng = np.random.default_rng(1)
+    secrets = rng.integers(0, 433, size=30).tolist()
+    rand = rng.integers(0, 432, size=40).tolist()
+    got = crypto.ShareGenerator(crypto.PackedShamir(3, 8, 4, 433, 354, 150)).generate(secrets, rand)
+    for b in range(10):
+        fft = pss.share_fft(secrets[3 * b:3 * b + 3], rand[4 * b:4 * b + 4], "rust_signed")
+        assert [int(got[j][b]) for j in range(8)] == [v % 433 for v in fft]
+
+
+# ---- device CSPRNG (sda-drbg-v1) ----------------------------------------------------------------------
+@pytest.mark.parametrize("case", range(6))
+def test_drbg_matches_spec(gpu, case, monkeypatch):
+    """Additive shares 0..n-2 ARE the raw draws, so generate(rand=NULL) exposes the CSPRNG stream."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    g = load_golden("drbg.json")
+    c = g["cases"][case]
+    monkeypatch.setenv("SDA_DRBG_ROUNDS", str(c["rounds"]))
+    T, B, m = c["T"], c["batches"], c["modulus"]
+    gen = crypto.ShareGenerator(crypto.Additive(T + 1, m))
+    gen.set_drbg_key(bytes.fromhex(g["key_hex"]))
+    secrets = DeviceBuffer.from_numpy(np.zeros(B + (B & 1), dtype=np.int64))
+    Bs = B + (B & 1)
+    out = DeviceBuffer((T + 1) * Bs)
+    gen.generate_batch_dev(secrets.ptr, 1, B, Bs, out.ptr, (T + 1) * Bs, Bs, first_participant=c["stream"])
+    got = out.to_numpy().reshape(T + 1, Bs)[:, :B]
+    want = np.array(c["values"], dtype=np.int64).reshape(B, T).T
+    assert np.array_equal(got[:T], want)
+    assert np.array_equal(got[T], np.mod(-want.astype(object).sum(axis=0), m).astype(np.int64))
+
+
+def test_drbg_rejection_path(gpu):
+    """A modulus with a large Lemire rejection zone forces the retry stream; C oracle has the same spec."""
+    from sda_amd import crypto
+    from oracle import coracle
+    m = (1 << 61) + 1                       # 2^64 mod m is ~2^61-ish: heavy rejection
+    gen = crypto.ShareGenerator(crypto.Additive(3, m))
+    gen.set_drbg_key(KEY)
+    dim = 4001
+    got = gen.generate(np.zeros(dim, dtype=np.int64))        # stream 0
+    want = coracle.drbg_fill(KEY, 0, dim, 2, m).reshape(dim, 2).T
+    assert np.array_equal(got[:2], want)
+    got2 = gen.generate(np.zeros(dim, dtype=np.int64))       # stream 1: fresh randomness per call
+    assert np.array_equal(got2[:2], coracle.drbg_fill(KEY, 1, dim, 2, m).reshape(dim, 2).T)
+    assert not np.array_equal(got, got2)
+
+
+def test_packed_generate_drbg_vs_oracle(gpu):
+    from sda_amd import crypto
+    from oracle import coracle
+    for (k, t, n, o2, o3) in [(3, 1, 8, 8, 9), (3, 4, 8, 8, 9), (8, 2, 26, 16, 27), (5, 3, 26, 16, 27)]:
+        sch = crypto.PackedShamir(k, n, t, P62, W[o2], W[o3])
+        gen = crypto.ShareGenerator(sch)
+        gen.set_drbg_key(KEY)
+        dim = 3001
+        secrets = coracle.fill_synthetic(1, dim, 0, 1, P62)[0]
+        B = gen.batch_count(dim)
+        got = gen.generate(secrets)
+        rnd = coracle.drbg_fill(KEY, 0, B, t, P62)
+        assert np.array_equal(got, coracle.packed_generate(P62, k, t, n, W[o2], W[o3], secrets, rnd)), (k, t)
+
+
+# ---- combiner -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P,L,q", [(2, 4, 433), (1, 1, P62), (7, 1001, P62), (300, 64, P62), (5000, 6, P62),
+                                   (33, 4097, (1 << 62) - 57), (3, 2, 2)])
+def test_combine_vs_oracle(gpu, P, L, q):
+    from sda_amd import crypto
+    from oracle import coracle
+    rng = np.random.default_rng(P * 7 + L)
+    rows = rng.integers(-(q - 1), q, size=(P, L), dtype=np.int64)          # the reference's (-q, q) domain
+    comb = crypto.ShareCombiner(crypto.Additive(3, q))
+    got = comb.combine(list(rows))
+    assert np.array_equal(got, coracle.combine(q, rows, mode=0))
+    assert np.array_equal(got, np.mod(coracle.combine(q, rows, mode=1), q))   # == reference mod q
+    wild = rng.integers(-(1 << 63), (1 << 63) - 1, size=(P, L), dtype=np.int64)   # any i64 is accepted
+    assert np.array_equal(comb.combine(list(wild)), coracle.combine(q, wild, mode=0))
+
+
+def test_combine_edge_cases(gpu):
+    from sda_amd import capi, crypto
+    comb = crypto.ShareCombiner(crypto.PackedShamir(3, 8, 1, P62, W[8], W[9]))
+    assert comb.combine([]).size == 0                                       # combiner.rs:17
+    assert comb.combine([[], []]).size == 0
+    with pytest.raises(capi.SdaError) as e:
+        comb.combine([[1, 2, 3], [1, 2]])
+    assert e.value.code == capi.ERR_WRONG_DIMENSION and "Wrong dimension" in e.value.message   # combiner.rs:21
+    assert list(comb.combine([[5, -1, P62]])) == [5, P62 - 1, 0]
+
+
+def test_streaming_combiner_equals_one_shot(gpu):
+    from sda_amd import crypto
+    from oracle import coracle
+    rng = np.random.default_rng(3)
+    P, L = 257, 3001
+    rows = rng.integers(0, P62, size=(P, L), dtype=np.int64)
+    comb = crypto.ShareCombiner(crypto.Additive(3, P62))
+    comb.begin(L)
+    for lo in range(0, P, 50):
+        comb.update(rows[lo:lo + 50])
+    assert np.array_equal(comb.finish(L), coracle.combine(P62, rows))
+
+
+def test_combiner_dev_jobs_layout(gpu):
+    """[jobs][rows][L] resident in HBM, the layout the snapshot transposition yields (stores.rs:86-101)."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(4)
+    jobs, P, L = 8, 40, 1234
+    data = rng.integers(0, P62, size=(jobs, P, L), dtype=np.int64)
+    d = DeviceBuffer.from_numpy(data)
+    out = DeviceBuffer(jobs * L)
+    comb = crypto.ShareCombiner(crypto.Additive(3, P62))
+    comb.begin_dev(jobs, L)
+    comb.update_dev(d.ptr, P * L, P // 2, L)
+    comb.update_dev(d.at((P // 2) * L), P * L, P - P // 2, L)
+    comb.finish_dev(out.ptr)
+    got = out.to_numpy().reshape(jobs, L)
+    for j in range(jobs):
+        assert np.array_equal(got[j], coracle.combine(P62, data[j]))
+
+
+# ---- reconstruct ----------------------------------------------------------------------------------------
+def test_packed_reconstruct_vs_oracle_and_errors(gpu):
+    from sda_amd import capi, crypto
+    from oracle import coracle
+    k, t, n = 3, 4, 8
+    sch = crypto.PackedShamir(k, n, t, P62, W[8], W[9])
+    dim = 1000
+    rng = np.random.default_rng(11)
+    secrets = rng.integers(0, P62, size=dim, dtype=np.int64)
+    B = (dim + k - 1) // k
+    rand = rng.integers(0, P62, size=B * t, dtype=np.int64)
+    shares = coracle.packed_generate(P62, k, t, n, W[8], W[9], secrets, rand)
+    rec = crypto.SecretReconstructor(sch, dim)
+    for subset in ([0, 1, 2, 3, 4, 5, 6, 7], [7, 5, 3, 1, 0, 2, 6], [1, 2, 3, 4, 5, 6, 7]):
+        got = rec.reconstruct([(c, shares[c]) for c in subset])
+        assert np.array_equal(got, secrets)
+        assert np.array_equal(got, coracle.packed_reconstruct(P62, k, t, W[8], W[9], dim, subset, shares[subset]))
+    with pytest.raises(capi.SdaError) as e:
+        rec.reconstruct([(c, shares[c]) for c in range(6)])
+    assert e.value.code == capi.ERR_NOT_ENOUGH_SHARES and "Not enough shares to reconstruct" in e.value.message
+    with pytest.raises(capi.SdaError) as e:                                  # duplicate clerk index
+        rec.reconstruct([(c, shares[c]) for c in [0, 1, 2, 3, 4, 5, 5]])
+    assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.SdaError) as e:                                  # a short row: index OOB in batched.rs:84
+        rec.reconstruct([(c, shares[c][:-1]) for c in range(7)])
+    assert e.value.code == capi.ERR_ASSERTION
+
+
+def test_additive_reconstruct(gpu):
+    from sda_amd import capi, crypto
+    rec = crypto.SecretReconstructor(crypto.Additive(3, 433), 99)            # configured dimension is ignored
+    assert list(rec.reconstruct([(0, [400, 1]), (1, [30, 2]), (2, [4, -3])])) == [1, 0]
+    assert rec.reconstruct([]).size == 0                                     # additive.rs:57-60
+    with pytest.raises(capi.SdaError) as e:
+        rec.reconstruct([(0, [1, 2]), (1, [1])])
+    assert e.value.code == capi.ERR_MISMATCHING_DIMENSION and "Mismatching dimension" in e.value.message
+
+
+# ---- masking ----------------------------------------------------------------------------------------------
+def test_chacha_masks_kats(gpu):
+    from sda_amd import crypto
+    k = load_golden("kats.json")["kats"]
+    for name in ("C2_masks_seed0", "C3_masks_seed1234"):
+        c = k[name]
+        comb = crypto.MaskCombiner(crypto.ChaCha(c["modulus"], 8, 128))
+        assert list(map(int, comb.combine([c["seed"]]))) == c["expected"]
+
+
+@pytest.mark.parametrize("q,dim,seeds", [(433, 1000, 5), (P62, 4099, 9), (P62, 8, 1), (97, 3, 300),
+                                         ((1 << 61) + 1, 3000, 6),            # ~12% rejection: exact-order path for all
+                                         ((1 << 62) - (1 << 49), 2000, 60)])  # 2^-13 rejection: fast path + fix-ups
+def test_chacha_combine_vs_oracle(gpu, q, dim, seeds):
+    from sda_amd import crypto
+    from oracle import coracle
+    rng = np.random.default_rng(dim + seeds)
+    S = rng.integers(0, 1 << 32, size=(seeds, 4), dtype=np.int64)
+    got = crypto.MaskCombiner(crypto.ChaCha(q, dim, 128)).combine(list(S))
+    assert np.array_equal(got, coracle.chacha_combine(S, q, dim))
+
+
+def test_chacha_mask_roundtrip_and_seed_forms(gpu):
+    from sda_amd import crypto
+    from oracle import coracle
+    q, dim = P62, 1237
+    sch = crypto.ChaCha(q, dim, 128)
+    secrets = np.arange(dim, dtype=np.int64) * 3 - 50
+    m = crypto.SecretMasker(sch)
+    seed, masked = m.mask(secrets, [1, 2, 3, 4])
+    assert list(seed) == [1, 2, 3, 4]                                        # chacha.rs:48-50
+    mask = coracle.chacha_expand([1, 2, 3, 4], q, dim)
+    assert np.array_equal(masked, coracle.addsub(secrets, mask, q))
+    seed2, masked2 = m.mask(secrets)                                         # OS-entropy seed
+    assert seed2.size == 4 and all(0 <= int(w) < (1 << 32) for w in seed2)
+    mask2 = crypto.MaskCombiner(sch).combine([seed2])
+    assert np.array_equal(crypto.SecretUnmasker(sch).unmask((mask2, masked2)), np.mod(secrets, q))
+    # 256-bit and 64-bit seeds; words beyond 8 are ignored by rand 0.3
+    for words in ([9, 8, 7, 6, 5, 4, 3, 2], [1, 2], [1, 2, 3, 4, 5, 6, 7, 8, 9, 10]):
+        got = crypto.MaskCombiner(crypto.ChaCha(q, 64, 32 * len(words))).combine([words])
+        assert np.array_equal(got, coracle.chacha_expand(words, q, 64))
+    with pytest.raises(AssertionError):                                      # assert_eq!, chacha.rs:26
+        m.mask(secrets[:-1], [1, 2, 3, 4])
+    assert list(crypto.MaskCombiner(crypto.ChaCha(q, 5, 128)).combine([])) == [0] * 5   # chacha.rs:58
+
+
+def test_full_and_none_masking(gpu):
+    from sda_amd import crypto
+    from oracle import coracle
+    q, dim = P62, 1001
+    rng = np.random.default_rng(8)
+    secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
+    draws = rng.integers(0, q, size=dim, dtype=np.int64)
+    full = crypto.Full(q)
+    mask, masked = crypto.SecretMasker(full).mask(secrets, draws)
+    assert np.array_equal(mask, draws) and np.array_equal(masked, coracle.addsub(secrets, draws, q))
+    m = crypto.SecretMasker(full)
+    m.set_drbg_key(KEY)
+    mask2, masked2 = m.mask(secrets)                                         # device CSPRNG
+    assert np.array_equal(mask2, coracle.drbg_fill(KEY, 0, dim, 1, q))
+    assert np.array_equal(crypto.SecretUnmasker(full).unmask((mask2, masked2)), np.mod(secrets, q))
+    masks = rng.integers(0, q, size=(12, dim), dtype=np.int64)
+    assert np.array_equal(crypto.MaskCombiner(full).combine(list(masks)), coracle.combine(q, masks))
+    with pytest.raises(AssertionError):                                      # full.rs:43
+        crypto.MaskCombiner(full).combine([[1, 2], [1]])
+    with pytest.raises(AssertionError):                                      # full.rs:58
+        crypto.SecretUnmasker(full).unmask(([1], [1, 2]))
+    none = crypto.NoMask()
+    mk, ms = crypto.SecretMasker(none).mask([5, -7, 9])
+    assert mk.size == 0 and list(ms) == [5, -7, 9]                            # none.rs:13-19: untouched
+    assert crypto.MaskCombiner(none).combine([[], []]).size == 0
+    with pytest.raises(AssertionError):                                      # none.rs:23
+        crypto.MaskCombiner(none).combine([[1]])
+    with pytest.raises(AssertionError):                                      # none.rs:30
+        crypto.SecretUnmasker(none).unmask(([1], [1]))
+    assert list(crypto.SecretUnmasker(none).unmask(([], [3, -4]))) == [3, -4]
+
+
+def test_scheme_validation(gpu):
+    from sda_amd import capi, crypto
+    for bad in (crypto.Additive(3, 1), crypto.Additive(0, 433), crypto.Additive(3, 1 << 62),
+                crypto.PackedShamir(3, 8, 4, 435, 354, 150),           # composite modulus
+                crypto.PackedShamir(3, 8, 4, 433, 1, 150),             # omega_secrets of order 1: nodes collide
+                crypto.PackedShamir(0, 8, 4, 433, 354, 150)):
+        with pytest.raises(capi.SdaError):
+            crypto.ShareGenerator(bad)
+
+
+# ---- BASELINE-size property tests (size-independent invariants; data stays in HBM) ------------------------
+@pytest.mark.parametrize("shape", ["additive_n3", "packed_k3_t1_n8", "packed_k8_t2_n26"])
+def test_full_dimension_roundtrip(gpu, shape):
+    """dim = 1,048,576 (BASELINE configs 2-4), P participants on the device CSPRNG:
+    reconstruct(combine(generate(x_p))) == sum_p x_p mod q, for a strict subset of clerks where the
+    scheme allows it; plus bit-exact share spot-checks against the oracle on sampled batches."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    dim, P = 1 << 20, 24
+    if shape == "additive_n3":
+        sch, k, t, n = crypto.Additive(3, P62), 1, 2, 3
+        subset = [0, 1, 2]
+    elif shape == "packed_k3_t1_n8":
+        k, t, n = 3, 1, 8
+        sch = crypto.PackedShamir(k, n, t, P62, W[8], W[9])
+        subset = [6, 1, 4, 3]
+    else:
+        k, t, n = 8, 2, 26
+        sch = crypto.PackedShamir(k, n, t, P62, W[16], W[27])
+        subset = list(range(25, 15, -1))
+    B = (dim + k - 1) // k
+    Bs = B + (B & 1)
+    lib = gpu
+    secrets = DeviceBuffer(P * dim)
+    from sda_amd.capi import check
+    check(lib.sda_fill_synthetic_dev(secrets.ptr, P, dim, dim, 100, 0x5DA5DA5DA5DA5DA5, P62, None))
+    shares = DeviceBuffer(n * P * Bs)                                        # job-major [n][P][Bs]
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    gen.generate_batch_dev(secrets.ptr, P, dim, dim, shares.ptr, Bs, P * Bs, first_participant=100)
+    comb = crypto.ShareCombiner(sch)
+    sums = DeviceBuffer(n * B)
+    comb.begin_dev(n, B)
+    comb.update_dev(shares.ptr, P * Bs, P, Bs)
+    comb.finish_dev(sums.ptr)
+    rec = crypto.SecretReconstructor(sch, dim)
+    S = sums.to_numpy().reshape(n, B)
+    got = rec.reconstruct([(c, S[c]) for c in subset])
+    host_secrets = secrets.to_numpy().reshape(P, dim)
+    assert np.array_equal(host_secrets[:2], coracle.fill_synthetic(2, dim, 100, 0x5DA5DA5DA5DA5DA5, P62))
+    assert np.array_equal(got, coracle.combine(P62, host_secrets))           # == sum of secrets mod q
+    # device-resident reconstruct from the first rows (contiguous [n'][B] in HBM)
+    first = list(range(sch.reconstruction_threshold()))
+    out = DeviceBuffer(dim)
+    assert rec.reconstruct_dev(first, sums.ptr, B, B, out.ptr, dim) == dim
+    assert np.array_equal(out.to_numpy(), got)
+    # spot-check one participant's shares bit-exactly against the oracle
+    p = 7
+    rnd = coracle.drbg_fill(KEY, 100 + p, B, t, P62)
+    if shape == "additive_n3":
+        want = coracle.additive_generate(P62, n, host_secrets[p], rnd)
+    else:
+        want = coracle.packed_generate(P62, k, t, n, sch.omega_secrets, sch.omega_shares, host_secrets[p], rnd)
+    all_shares = shares.to_numpy().reshape(n, P, Bs)
+    assert np.array_equal(all_shares[:, p, :B], want)
+    assert np.array_equal(S, np.stack([coracle.combine(P62, all_shares[c, :, :B]) for c in range(n)]))
