@@ -29,6 +29,19 @@ struct MatArg {
     uint64_t e[SDA_MAT_ARG_MAX];
 };
 
+// Constants of the balanced-31-bit-limb Montgomery path (R = 2^62, radix B = 2^31); see
+// packed_gen_l31_kernel.  MatArg entries are then (uint32)m0 | (uint64)(uint32)m1 << 32 with
+// m1 * B + m0 = centred representative of (M_ji * 2^62 mod p), m0 in [-2^30, 2^30).
+struct L31Params {
+    uint64_t p;       // modulus
+    uint64_t p2;      // 2p
+    uint64_t h;       // (p + 1) / 2 : v >= h is centred to v - p
+    int32_t  p0;      // p mod 2^31
+    int32_t  p1;      // p >> 31
+    uint32_t pinvB;   // -p^{-1} mod 2^31
+    uint32_t pad;
+};
+
 // strides in elements
 struct GenLayout {
     const int64_t* secrets;   size_t secrets_stride;
@@ -48,6 +61,12 @@ bool packed_fast_path_available(uint32_t k, uint32_t t, uint32_t n);
 hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
                                   const ModParams& mod, const MontParams& mont, const MatArg& Mmont,
                                   const DrbgKey& key, int rounds, hipStream_t s);
+
+// packed Shamir, k + t <= 4 (BASELINE config 3): balanced 31-bit limbs, carry-free v_mad_i64_i32 dot
+bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n);
+hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
+                                      const ModParams& mod, const L31Params& lp, const MatArg& Ml31,
+                                      const DrbgKey& key, int rounds, hipStream_t s);
 
 // packed Shamir, any shape: matrix in global memory, randomness must be materialised (L.rand != 0)
 hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,

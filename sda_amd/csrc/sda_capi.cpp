@@ -365,6 +365,8 @@ struct sda_share_generator {
     std::vector<uint64_t> Mmont;         // n x (k+t), Montgomery form
     MatArg* matarg = nullptr;            // fast path (kernarg copy)
     bool fast = false;
+    bool l31 = false;                    // k + t <= 4: balanced-31-bit-limb kernel
+    L31Params lp{};
     Drbg drbg;
     Ctx ctx;
     DevBuf d_M, d_secrets, d_rand, d_out;
@@ -392,6 +394,32 @@ static int validate_packed(const sda_sharing_scheme_t& s) {
         return fail(SDA_ERR_UNSUPPORTED, "packed scheme too large");
     if (s.modulus < 3 || (s.modulus & 1) == 0 || !h_is_prime((uint64_t)s.modulus))
         return fail(SDA_ERR_INVALID_ARGUMENT, "prime_modulus %lld is not an odd prime", (long long)s.modulus);
+    return SDA_OK;
+}
+
+// Constants of the balanced-limb kernel: matrix entries in Montgomery form with R = 2^62, centred to
+// (-p/2, p/2] and split into balanced limbs m1 * 2^31 + m0, m0 in [-2^30, 2^30).
+static int build_l31(sda_share_generator* g) {
+    const uint64_t p = g->mod.m;
+    const uint64_t B = 1ull << 31;
+    uint64_t inv;
+    if (!h_invmod(p % B, B, inv)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not invertible mod 2^31");
+    g->lp.p = p; g->lp.p2 = 2 * p; g->lp.h = (p + 1) / 2;
+    g->lp.p0 = (int32_t)(p % B); g->lp.p1 = (int32_t)(p >> 31);
+    g->lp.pinvB = (uint32_t)((B - inv) % B); g->lp.pad = 0;
+    g->matarg = new (std::nothrow) MatArg();
+    if (!g->matarg) return fail(SDA_ERR_ALLOC, "out of memory");
+    memset(g->matarg, 0, sizeof(MatArg));
+    const uint64_t r64_inv_to_r62 = h_powmod(4 % p, p - 2, p);          // Mmont holds M * 2^64: divide by 4
+    for (size_t i = 0; i < g->Mmont.size(); ++i) {
+        const uint64_t mr = h_mulmod(g->Mmont[i], r64_inv_to_r62, p);   // M * 2^62 mod p
+        __int128 c = mr > (p - 1) / 2 ? (__int128)mr - (__int128)p : (__int128)mr;
+        int64_t c64 = (int64_t)c;
+        int64_t m0 = (int64_t)(((uint64_t)c64 & (B - 1)));
+        if (m0 >= (int64_t)(B >> 1)) m0 -= (int64_t)B;
+        const int64_t m1 = (c64 - m0) / (int64_t)B;
+        g->matarg->e[i] = (uint64_t)(uint32_t)(int32_t)m0 | ((uint64_t)(uint32_t)(int32_t)m1 << 32);
+    }
     return SDA_OK;
 }
 
@@ -423,8 +451,11 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
     }
     if (st == SDA_OK) st = g->ctx.init();
     if (st == SDA_OK && !g->additive) {
-        g->fast = packed_fast_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC");
-        if (g->fast) {
+        g->l31 = packed_l31_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64");
+        g->fast = !g->l31 && packed_fast_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC");
+        if (g->l31) {
+            st = build_l31(g);
+        } else if (g->fast) {
             g->matarg = new (std::nothrow) MatArg();
             if (!g->matarg) st = fail(SDA_ERR_ALLOC, "out of memory");
             else {
@@ -483,6 +514,10 @@ extern "C" int sda_share_generator_generate_batch_dev(sda_share_generator_t* g, 
     L.participants = participants; L.len = len; L.first_participant = first_participant;
     if (g->additive) {
         HIP_TRY(launch_additive_generate(L, g->n, g->mod, g->drbg.key, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->l31) {
+        HIP_TRY(launch_packed_generate_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, g->drbg.key, g->drbg.rounds, s));
         return SDA_OK;
     }
     if (g->fast) {

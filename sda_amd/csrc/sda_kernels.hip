@@ -229,6 +229,144 @@ __global__ __launch_bounds__(kThreads) void packed_gen_kernel(GenLayout L, uint3
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// K2'  packed-Shamir share generation for k + t <= 4 (BASELINE config 3), the VALU-lean form.
+//
+// gfx950 cost model (tools/microbench_valu.hip): only v_add/sub/xor/and/mov issue at ~2.5 cycles per
+// wave64; EVERYTHING else - multiplies, v_mad_*64*, 64-bit adds, shifts, compares, carry ops - costs
+// ~4.5.  So the work is organised to minimise instruction count, not multiplier width:
+//   * every residue is centred to (-p/2, p/2) and split into balanced signed limbs x = x1*B + x0,
+//     B = 2^31, |x0|,|x1| <= 2^30; the matrix constants (Montgomery form, R = B^2 = 2^62) likewise;
+//   * a 4-term dot product is then three signed 64-bit column sums C0, C1, C2 built by 16
+//     v_mad_i64_i32 with NO carry handling: |C0|,|C2| <= 2^62, |C1| < 2^63;
+//   * Montgomery reduction runs directly on the columns, one radix-B digit at a time
+//     (q = C * (-p^-1) mod B, balanced), again carry-free; the result lies in (-1.5p, 1.5p),
+//     +2p and two conditional subtractions make it canonical.
+// Bounds and exactness were checked exhaustively in big-int arithmetic (tests/test_limb31_model.py).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t sext31(uint32_t x) { return ((int32_t)(x << 1)) >> 1; }
+
+__device__ __forceinline__ void centre_limbs(uint64_t v, const L31Params& P, int32_t& l0, int32_t& l1) {
+    const int64_t c = (int64_t)(v >= P.h ? v - P.p : v);            // |c| <= (p-1)/2 < 2^61
+    l0 = sext31((uint32_t)c);
+    l1 = (int32_t)(c >> 31) + (int32_t)(((uint32_t)c >> 30) & 1u);     // (c - l0) / B
+}
+
+// One-instruction wrappers: hipcc expands an SGPR-resident i32 (sign-extended in the SALU) times a VGPR
+// i32 into a 64x32 schoolbook product (v_mul_lo_u32 + v_mad_u64_u32 + ...) instead of the single
+// v_mad_i64_i32 it is.  The wrappers pin the instruction; scheduling and allocation stay with hipcc.
+__device__ __forceinline__ int64_t mad_sv(int32_t s_a, int32_t v_b, int64_t c) {      // SGPR * VGPR + acc
+    int64_t d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "s"(s_a), "v"(v_b), "v"(c) : "vcc");
+    return d;
+}
+__device__ __forceinline__ int64_t mul_sv(int32_t s_a, int32_t v_b) {                 // SGPR * VGPR
+    int64_t d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(d) : "s"(s_a), "v"(v_b) : "vcc");
+    return d;
+}
+
+template <int KT>
+__device__ __forceinline__ uint64_t l31_dot(const uint64_t* __restrict__ row, const int32_t (&v0)[KT],
+                                            const int32_t (&v1)[KT], const L31Params& P) {
+    int64_t C0, C1, C2;
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+        const int32_t m0 = (int32_t)(uint32_t)row[i];
+        const int32_t m1 = (int32_t)(uint32_t)(row[i] >> 32);
+        if (i == 0) {
+            C0 = mul_sv(m0, v0[i]);
+            C1 = mul_sv(m0, v1[i]);
+            C2 = mul_sv(m1, v1[i]);
+        } else {
+            C0 = mad_sv(m0, v0[i], C0);
+            C1 = mad_sv(m0, v1[i], C1);
+            C2 = mad_sv(m1, v1[i], C2);
+        }
+        C1 = mad_sv(m1, v0[i], C1);
+    }
+    // radix-B Montgomery reduction on the columns
+    const int32_t q0 = sext31((uint32_t)C0 * P.pinvB);
+    C0 = mad_sv(P.p0, q0, C0);                                  // == 0 mod B
+    int64_t E = mad_sv(P.p1, q0, C0 >> 31);
+    const int32_t q1 = sext31(((uint32_t)C1 + (uint32_t)E) * P.pinvB);
+    E = mad_sv(P.p0, q1, E);                                    // C1 + E == 0 mod B
+    // (C1 + E) / B without a 65-bit sum: the low limbs add up to 0 or B
+    const int64_t top = mad_sv(P.p1, q1, C2) + (C1 >> 31) + ((E + 0x7FFFFFFF) >> 31);
+    uint64_t r = (uint64_t)top + P.p2;                          // in [0, 4p)
+    if (r >= P.p2) r -= P.p2;
+    if (r >= P.p) r -= P.p;
+    return r;
+}
+
+template <int K, int T, int ROUNDS, bool VEC>
+__global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, uint32_t n, ModParams mod,
+                                                                  L31Params lp, MatArg M, DrbgKey key,
+                                                                  uint64_t chunks, uint64_t batches) {
+    constexpr int KT = K + T;
+    static_assert(KT <= 4, "the carry-free column bounds hold for at most 4 terms");
+    uint64_t p, chunk;
+    split_item(blockIdx.x, chunks, p, chunk);
+    const uint64_t pair = chunk * kThreads + threadIdx.x;
+    const uint64_t b0 = 2 * pair;
+    const bool in0 = b0 < batches, in1 = b0 + 1 < batches;
+
+    uint64_t s0[KT], s1[KT];
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    const uint64_t e0 = b0 * K;
+    if (VEC && e0 + 2 * K <= L.len) {
+        uint64_t tmp[2 * K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            ll2 v = load2(sp + e0 + 2 * i);
+            tmp[2 * i] = canon_i64(v.x, mod.m, mod.mu);
+            tmp[2 * i + 1] = canon_i64(v.y, mod.m, mod.mu);
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) { s0[i] = tmp[i]; s1[i] = tmp[K + i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const uint64_t a = e0 + i, b = e0 + K + i;
+            s0[i] = a < L.len ? canon_i64(sp[a], mod.m, mod.mu) : 0;
+            s1[i] = b < L.len ? canon_i64(sp[b], mod.m, mod.mu) : 0;
+        }
+    }
+    if (L.rand) {
+        const int64_t* rp = L.rand + p * L.rand_stride;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            s0[K + i] = in0 ? canon_i64(rp[b0 * T + i], mod.m, mod.mu) : 0;
+            s1[K + i] = in1 ? canon_i64(rp[(b0 + 1) * T + i], mod.m, mod.mu) : 0;
+        }
+    } else {
+        const uint64_t stream = L.first_participant + p;
+#pragma unroll
+        for (int i = 0; i < T; ++i) drbg_pair<ROUNDS>(key, stream, pair, T, i, mod, s0[K + i], s1[K + i]);
+    }
+
+    int32_t a0[KT], a1[KT], c0[KT], c1[KT];
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+        centre_limbs(s0[i], lp, a0[i], a1[i]);
+        centre_limbs(s1[i], lp, c0[i], c1[i]);
+    }
+
+    int64_t* op = L.out + p * L.out_stride_participant + b0;
+#pragma unroll 2
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint64_t* row = &M.e[(size_t)j * KT];
+        const uint64_t a = l31_dot<KT>(row, a0, a1, lp);
+        const uint64_t b = l31_dot<KT>(row, c0, c1, lp);
+        int64_t* o = op + (size_t)j * L.out_stride_clerk;
+        if (VEC && in1) store2(o, a, b);
+        else {
+            if (in0) o[0] = (int64_t)a;
+            if (in1) o[1] = (int64_t)b;
+        }
+    }
+}
+
 // any-shape fallback: one lane = one batch, matrix and randomness read from global memory
 __global__ __launch_bounds__(kThreads) void packed_gen_generic_kernel(GenLayout L, uint32_t n, uint32_t k,
                                                                       uint32_t t, ModParams mod, MontParams mont,
@@ -645,6 +783,53 @@ hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, ui
         case 20: return packed_launch_r<20>(L, n, k, t, mod, mont, M, key, s);
         case 12: return packed_launch_r<12>(L, n, k, t, mod, mont, M, key, s);
         case 8: return packed_launch_r<8>(L, n, k, t, mod, mont, M, key, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+#define SDA_PACKED_L31_SHAPES(X) X(3, 1) X(1, 1) X(2, 1) X(1, 2) X(2, 2) X(1, 3) X(3, 0) X(4, 0) X(2, 0) X(1, 0)
+
+bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n) {
+    if ((uint64_t)n * (k + t) > SDA_MAT_ARG_MAX) return false;
+#define X(K_, T_) if (k == K_ && t == T_) return true;
+    SDA_PACKED_L31_SHAPES(X)
+#undef X
+    return false;
+}
+
+template <int K, int T, int ROUNDS>
+static hipError_t packed_l31_launch_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const L31Params& lp,
+                                       const MatArg& M, const DrbgKey& key, hipStream_t s) {
+    const uint64_t batches = ceil_div(L.len, K);
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    const uint64_t blocks = chunks * L.participants;
+    if (blocks == 0) return hipSuccess;
+    if (hipError_t e = grid_check(blocks)) return e;
+    if (gen_vec_ok(L, 0))
+        packed_gen_l31_kernel<K, T, ROUNDS, true><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, lp, M, key,
+                                                                                                     chunks, batches);
+    else
+        packed_gen_l31_kernel<K, T, ROUNDS, false><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, lp, M, key,
+                                                                                                      chunks, batches);
+    return hipGetLastError();
+}
+
+template <int ROUNDS>
+static hipError_t packed_l31_launch_r(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                      const L31Params& lp, const MatArg& M, const DrbgKey& key, hipStream_t s) {
+#define X(K_, T_) if (k == K_ && t == T_) return packed_l31_launch_kt<K_, T_, ROUNDS>(L, n, mod, lp, M, key, s);
+    SDA_PACKED_L31_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                      const L31Params& lp, const MatArg& M, const DrbgKey& key, int rounds,
+                                      hipStream_t s) {
+    switch (rounds) {
+        case 20: return packed_l31_launch_r<20>(L, n, k, t, mod, lp, M, key, s);
+        case 12: return packed_l31_launch_r<12>(L, n, k, t, mod, lp, M, key, s);
+        case 8: return packed_l31_launch_r<8>(L, n, k, t, mod, lp, M, key, s);
         default: return hipErrorInvalidValue;
     }
 }
