@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--workload", default="packed", choices=sorted(WORKLOADS))
     ap.add_argument("--dim", type=int, default=1 << 20)
     ap.add_argument("--tile", type=int, default=2000, help="participants per step and per GPU")
+    ap.add_argument("--row-align", type=int, default=16, help="pad share rows to a multiple of this many elements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -110,7 +111,7 @@ def main():
     else:
         scheme = crypto.Additive(n, P62)
     B = (dim + k - 1) // k
-    Bs = B + (B & 1)
+    Bs = (B + args.row_align - 1) // args.row_align * args.row_align
 
     gen = crypto.ShareGenerator(scheme)
     gen.set_drbg_key(KEY)

@@ -88,7 +88,7 @@ __device__ __forceinline__ void drbg_pair(const DrbgKey& key, uint64_t stream, u
 __device__ __forceinline__ ll2 load2(const int64_t* p) { return *reinterpret_cast<const ll2*>(p); }
 __device__ __forceinline__ void store2(int64_t* p, uint64_t a, uint64_t b) {
     ll2 v; v.x = (long long)a; v.y = (long long)b;
-    *reinterpret_cast<ll2*>(p) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<ll2*>(p));   // shares are written once, read much later
 }
 
 // work item -> (participant, chunk)

@@ -1,0 +1,83 @@
+// C++ rendition of the reference's integration-tests/tests/full_loop.rs (:29-67, :113, :148) and of
+// the README walkthrough (README.md:86,105-107,157), driving the HIP core through the C++ host mirror
+// with OS randomness exactly like the reference tests do (no injection): participants -> snapshot
+// transposition -> clerks -> reveal, asserting the revealed output.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "sda_crypto.hpp"
+
+using namespace sda_client;
+
+struct Aggregation {                       // protocol/src/resources.rs:44-67 (compute-relevant fields)
+    size_t vector_dimension;
+    int64_t modulus;
+    LinearMaskingScheme masking_scheme;
+    LinearSecretSharingScheme committee_sharing_scheme;
+};
+
+static int failures = 0;
+#define EXPECT(cond, what) do { if (!(cond)) { printf("FAIL %s: %s\n", what, #cond); ++failures; } } while (0)
+
+static std::vector<int64_t> run(const Aggregation& a, const std::vector<std::vector<int64_t>>& inputs,
+                                const std::vector<size_t>* clerk_subset = nullptr) {
+    CryptoModule crypto;
+    const size_t n = a.committee_sharing_scheme.output_size();
+    std::vector<std::vector<Mask>> masks;
+    std::vector<std::vector<std::vector<Share>>> per_participant;           // [p][clerk][batch]
+    for (const auto& secrets : inputs) {                                    // participate.rs:52-76
+        auto masker = crypto.new_secret_masker(a.masking_scheme);
+        auto mm = masker->mask(secrets);
+        if (a.masking_scheme.has_mask()) masks.push_back(mm.first);
+        auto generator = crypto.new_share_generator(a.committee_sharing_scheme);
+        per_participant.push_back(generator->generate(mm.second));
+    }
+    std::vector<std::vector<Share>> clerk_sums(n);
+    for (size_t c = 0; c < n; ++c) {                                        // stores.rs:86-101 + clerk.rs:85-86
+        std::vector<std::vector<Share>> job;
+        for (auto& pp : per_participant) job.push_back(pp[c]);
+        clerk_sums[c] = crypto.new_share_combiner(a.committee_sharing_scheme)->combine(job);
+    }
+    std::vector<Mask> mask;                                                 // receive.rs:102-118
+    if (a.masking_scheme.has_mask()) mask = crypto.new_mask_combiner(a.masking_scheme)->combine(masks);
+    std::vector<std::pair<size_t, std::vector<Share>>> indexed;             // receive.rs:127-138
+    if (clerk_subset) for (size_t c : *clerk_subset) indexed.push_back({c, clerk_sums[c]});
+    else for (size_t c = 0; c < n; ++c) indexed.push_back({c, clerk_sums[c]});
+    auto masked_output = crypto.new_secret_reconstructor(a.committee_sharing_scheme, a.vector_dimension)->reconstruct(indexed);
+    auto output = crypto.new_secret_unmasker(a.masking_scheme)->unmask({mask, masked_output});   // receive.rs:149-152
+    return RecipientOutput{a.modulus, output}.positive().values;
+}
+
+int main() {
+    if (sda_device_count() < 1) { printf("no GPU: %s\n", sda_strerror(SDA_ERR_NO_DEVICE)); return 2; }
+    const auto add = LinearSecretSharingScheme::Additive(3, 433);
+    const auto pss = LinearSecretSharingScheme::PackedShamir(3, 8, 4, 433, 354, 150);
+    const std::vector<std::vector<int64_t>> two = {{1, 2, 3, 4}, {1, 2, 3, 4}};
+    const std::vector<int64_t> want = {2, 4, 6, 8};
+    EXPECT(run({4, 433, LinearMaskingScheme::None(), add}, two) == want, "simple (full_loop.rs:29-32)");
+    EXPECT(run({4, 433, LinearMaskingScheme::Full(433), add}, two) == want, "with_fullmask (:34-40)");
+    EXPECT(run({4, 433, LinearMaskingScheme::ChaCha(433, 4, 128), add}, two) == want, "with_chachamask (:42-52)");
+    EXPECT(run({4, 433, LinearMaskingScheme::None(), pss}, two) == want, "with_packedshamir (:54-67)");
+    const std::vector<size_t> subset = {7, 5, 4, 3, 2, 1, 0};
+    EXPECT(run({4, 433, LinearMaskingScheme::Full(433), pss}, two, &subset) == want, "packed shamir, one clerk missing");
+    // README walkthrough: dim 10, q 433, 3 shares, 3 participants
+    const std::vector<std::vector<int64_t>> readme = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}};
+    EXPECT(run({10, 433, LinearMaskingScheme::None(), add}, readme) == (std::vector<int64_t>{0, 2, 2, 4, 4, 6, 6, 8, 8, 10}),
+           "README walkthrough (README.md:157)");
+    // error behaviour mirrors the reference's strings
+    try {
+        ShareCombiner(add).combine({{1, 2, 3}, {1, 2}});
+        EXPECT(false, "ragged combine must fail");
+    } catch (const SdaClientError& e) { EXPECT(std::string(e.what()) == "Wrong dimension", "combiner.rs:21"); }
+    try {
+        SecretReconstructor(pss, 4).reconstruct({{0, {1, 2}}, {1, {1, 2}}});
+        EXPECT(false, "too few shares must fail");
+    } catch (const SdaClientError& e) { EXPECT(std::string(e.what()) == "Not enough shares to reconstruct", "packed_shamir.rs:75"); }
+    try {
+        SecretMasker(LinearMaskingScheme::ChaCha(433, 4, 128)).mask({1, 2, 3});
+        EXPECT(false, "dimension mismatch must panic");
+    } catch (const Panic&) {}
+    if (failures == 0) printf("full_loop.cpp: all scenarios OK\n");
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,109 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the participant sharding and the modular
+all-reduce choreography (all_to_all of slices -> local modular sum -> all_gather) of
+sda_amd/distributed.py.  The local modular sum on a GPU is a HIP kernel; here a checker reducer is
+injected (there is no CPU fallback in the product), so what is tested is the exchange itself:
+slicing, padding, ordering and the no-overflow property that a plain int64 SUM would violate."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P62 = 4611686006577364993
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _checker_modsum(parts: torch.Tensor, modulus: int) -> torch.Tensor:
+    """exact column sum mod q with Python ints (checker only)"""
+    a = parts.numpy().astype(object)
+    return torch.from_numpy(np.array([int(x) % modulus for x in a.sum(axis=0)], dtype=np.int64))
+
+
+def _worker(rank, world, port, length, q_out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sda_amd.distributed import modular_allreduce, shard_participants
+    from oracle import coracle
+
+    # every rank owns a shard of participants and computes its partial clerk sums with the ORACLE
+    # (this test is about the exchange; the GPU tests cover the kernels)
+    total_participants, n, k, t, dim = 11, 8, 3, 1, length
+    first, count = shard_participants(total_participants, world, rank)
+    w2, w3 = 631229665360524489, 3451275676410824977
+    key = bytes(range(32))
+    B = (dim + k - 1) // k
+    partial = np.zeros((n, B), dtype=np.int64)
+    for p in range(first, first + count):
+        secrets = coracle.fill_synthetic(1, dim, p, 7, P62)[0]
+        rnd = coracle.drbg_fill(key, p, B, t, P62)
+        shares = coracle.packed_generate(P62, k, t, n, w2, w3, secrets, rnd)
+        partial = np.stack([coracle.combine(P62, np.stack([partial[c], shares[c]])) for c in range(n)])
+    got = modular_allreduce(torch.from_numpy(partial), P62, local_modsum=_checker_modsum)
+    # a worst-case vector too: every rank contributes q-1 everywhere (plain int64 SUM wraps for 8 ranks)
+    worst = modular_allreduce(torch.full((5, 7), P62 - 1, dtype=torch.int64), P62, local_modsum=_checker_modsum)
+    if rank == 0:
+        q_out.put((got.numpy(), worst.numpy(), first, count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,length", [(2, 50), (2, 7), (3, 20)])
+def test_modular_allreduce_and_sharding_gloo(world, length):
+    from oracle import coracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, length, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, worst, first, count = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process truth over all 11 participants
+    n, k, t, dim = 8, 3, 1, length
+    w2, w3 = 631229665360524489, 3451275676410824977
+    key = bytes(range(32))
+    B = (dim + k - 1) // k
+    allshares = []
+    for p in range(11):
+        secrets = coracle.fill_synthetic(1, dim, p, 7, P62)[0]
+        allshares.append(coracle.packed_generate(P62, k, t, n, w2, w3, secrets, coracle.drbg_fill(key, p, B, t, P62)))
+    want = np.stack([coracle.combine(P62, np.stack([s[c] for s in allshares])) for c in range(n)])
+    assert np.array_equal(got, want)
+    assert np.array_equal(worst, np.full((5, 7), (world * (P62 - 1)) % P62, dtype=np.int64))
+    # reconstruct from the reduced sums == sum of all secrets
+    rec = coracle.packed_reconstruct(P62, k, t, w2, w3, dim, [0, 2, 5, 7], got[[0, 2, 5, 7]])
+    assert np.array_equal(rec, coracle.combine(P62, coracle.fill_synthetic(11, dim, 0, 7, P62)))
+
+
+def test_shard_participants_partition():
+    from sda_amd.distributed import shard_participants
+    for total in (0, 1, 7, 100_000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_participants(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_single_rank_requires_gpu_reducer():
+    """Without an injected reducer the local sum is the HIP kernel: CPU tensors are refused, loudly."""
+    from sda_amd.distributed import modular_allreduce
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        modular_allreduce(torch.zeros(4, dtype=torch.int64), P62)

@@ -452,3 +452,51 @@ def test_full_dimension_roundtrip(gpu, shape):
     all_shares = shares.to_numpy().reshape(n, P, Bs)
     assert np.array_equal(all_shares[:, p, :B], want)
     assert np.array_equal(S, np.stack([coracle.combine(P62, all_shares[c, :, :B]) for c in range(n)]))
+
+
+# ---- host mirror in C++ (the reference's host language is compiled) and multi-GPU helper ---------------------
+def test_cpp_host_mirror_full_loop(gpu):
+    """tests/cpp/full_loop.cpp: the reference's full_loop.rs scenarios through sda_amd/host/sda_crypto.hpp,
+    with OS randomness like the reference's own tests."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "full_loop")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all scenarios OK" in out.stdout
+
+
+def test_modsum_parts_dev(gpu):
+    """cross-GPU partial-sum reducer: 8 parts of (q-1) must not wrap (a plain u64 SUM would)."""
+    from sda_amd.capi import check
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(2)
+    parts = rng.integers(0, P62, size=(8, 1001), dtype=np.int64)
+    parts[:, 0] = P62 - 1
+    d = DeviceBuffer.from_numpy(parts)
+    out = DeviceBuffer(1001)
+    check(gpu.sda_modsum_parts_dev(P62, d.ptr, 8, 1001, 1001, out.ptr, None))
+    assert np.array_equal(out.to_numpy(), coracle.combine(P62, parts))
+    assert out.to_numpy()[0] == (8 * (P62 - 1)) % P62
+
+
+def test_any_i64_canonicalisation_property(gpu):
+    """the boundary accepts ANY i64 (SURVEY.md 8b 'Value domain'): outputs equal python's x % q."""
+    from sda_amd import crypto
+    edge = np.array([0, 1, -1, P62 - 1, P62, P62 + 1, -P62, 2 ** 63 - 1, -2 ** 63, -2 ** 63 + 1, 2 ** 62, -(2 ** 62)],
+                    dtype=np.int64)
+    for q in (433, P62, 2, (1 << 62) - 57):
+        got = crypto.ShareCombiner(crypto.Additive(3, q)).combine([edge])
+        assert got.tolist() == [int(x) % q for x in edge.tolist()]
+        un = crypto.SecretUnmasker(crypto.Full(q)).unmask((edge, edge[::-1].copy()))
+        assert un.tolist() == [(int(b) - int(a)) % q for a, b in zip(edge.tolist(), edge[::-1].tolist())]
+    sch = crypto.PackedShamir(3, 8, 1, (1 << 62) - 57, pow(3, ((1 << 62) - 58) // 8, (1 << 62) - 57), 1)
+    # omega_shares = 1 makes the share points collide with node 1: generation still defined, checked vs oracle
+    from oracle import coracle
+    p = (1 << 62) - 57
+    w2 = sch.omega_secrets
+    if len({pow(w2, e, p) for e in range(5)}) == 5:
+        g = crypto.ShareGenerator(crypto.PackedShamir(3, 8, 1, p, w2, 3))
+        rnd = np.array([5, -7], dtype=np.int64)
+        got = g.generate(edge[:6], rnd)
+        assert np.array_equal(got, coracle.packed_generate(p, 3, 1, 8, w2, 3, edge[:6], rnd))
