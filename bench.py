@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--dim", type=int, default=1 << 20)
     ap.add_argument("--tile", type=int, default=2000, help="participants per step and per GPU")
     ap.add_argument("--row-align", type=int, default=16, help="pad share rows to a multiple of this many elements")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="1: share-gen of tile i+1 runs concurrently with clerk-sum of tile i (two streams, "
+                         "double-buffered shares); 0: one stream, strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -118,17 +121,39 @@ def main():
     comb = crypto.ShareCombiner(scheme)
 
     # resident tile: secrets [P][dim], shares job-major [n][P][Bs]  (server snapshot layout, stores.rs:86-101)
+    nbuf = 2 if args.overlap else 1
     secrets = torch.empty((P, dim), dtype=torch.int64, device=dev)
-    shares = torch.empty((n, P, Bs), dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream or None
-    capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, rank * P, SEED, P62, stream))
-    comb.begin_dev(n, B, stream or 0)
+    shares = [torch.empty((n, P, Bs), dtype=torch.int64, device=dev) for _ in range(nbuf)]
+    if args.overlap:
+        s_gen, s_comb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    else:
+        s_gen = s_comb = torch.cuda.current_stream(dev)
+    h_gen, h_comb = s_gen.cuda_stream or None, s_comb.cuda_stream or None
+    capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, rank * P, SEED, P62, None))
+    torch.cuda.synchronize(dev)
+    comb.begin_dev(n, B, h_comb or 0)
+    gen_done = [torch.cuda.Event() for _ in range(nbuf)]
+    comb_done = [torch.cuda.Event() for _ in range(nbuf)]
 
-    def step(i):
+    def step(i, slot, evs=None):
+        """share-gen of tile i into shares[slot] on s_gen; clerk-sum of it on s_comb"""
         first = (i * world + rank) * P                      # participant ids of this tile (CSPRNG stream ids)
-        gen.generate_batch_dev(secrets.data_ptr(), P, dim, dim, shares.data_ptr(), Bs, P * Bs,
-                               first_participant=first, stream=stream or 0)
-        comb.update_dev(shares.data_ptr(), P * Bs, P, Bs, stream=stream or 0)
+        buf = shares[slot]
+        s_gen.wait_event(comb_done[slot])                   # the previous reader of this buffer is done
+        if evs:
+            capi.check(lib.sda_event_record(evs[0], h_gen))
+        gen.generate_batch_dev(secrets.data_ptr(), P, dim, dim, buf.data_ptr(), Bs, P * Bs,
+                               first_participant=first, stream=h_gen or 0)
+        if evs:
+            capi.check(lib.sda_event_record(evs[1], h_gen))
+        gen_done[slot].record(s_gen)
+        s_comb.wait_event(gen_done[slot])
+        if evs:
+            capi.check(lib.sda_event_record(evs[2], h_comb))
+        comb.update_dev(buf.data_ptr(), P * Bs, P, Bs, stream=h_comb or 0)
+        if evs:
+            capi.check(lib.sda_event_record(evs[3], h_comb))
+        comb_done[slot].record(s_comb)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -136,13 +161,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    for e in comb_done:
+        e.record(s_comb)
     for i in range(args.warmup):
-        step(-1 - i)
-    comb.begin_dev(n, B, stream or 0)                       # discard the warm-up contributions
+        step(-1 - i, i % nbuf)
+    torch.cuda.synchronize(dev)
+    comb.begin_dev(n, B, h_comb or 0)                       # discard the warm-up contributions
+    for e in comb_done:
+        e.record(s_comb)
 
-    # per-kernel HIP events on the launch stream (3 per step)
+    # per-kernel HIP events on the streams the kernels are launched on (4 per step)
     evs = []
-    for _ in range(3 * args.steps):
+    for _ in range(4 * args.steps):
         e = C.c_void_p()
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
@@ -151,27 +181,23 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        capi.check(lib.sda_event_record(evs[3 * i], stream))
-        first = (i * world + rank) * P
-        gen.generate_batch_dev(secrets.data_ptr(), P, dim, dim, shares.data_ptr(), Bs, P * Bs,
-                               first_participant=first, stream=stream or 0)
-        capi.check(lib.sda_event_record(evs[3 * i + 1], stream))
-        comb.update_dev(shares.data_ptr(), P * Bs, P, Bs, stream=stream or 0)
-        capi.check(lib.sda_event_record(evs[3 * i + 2], stream))
-    comb.finish_dev(sums.data_ptr(), stream or 0)
-    total = modular_allreduce(sums, P62) if world > 1 else sums     # X1: the only exchange step
+        step(i, i % nbuf, evs[4 * i:4 * i + 4])
+    comb.finish_dev(sums.data_ptr(), h_comb or 0)
+    with torch.cuda.stream(s_comb):
+        total = modular_allreduce(sums, P62) if world > 1 else sums     # X1: the only exchange step
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    stream = None
 
     gen_ms = comb_ms = 0.0
     ms = C.c_float()
     for i in range(args.steps):
-        capi.check(lib.sda_event_elapsed_ms(evs[3 * i], evs[3 * i + 1], C.byref(ms))); gen_ms += ms.value
-        capi.check(lib.sda_event_elapsed_ms(evs[3 * i + 1], evs[3 * i + 2], C.byref(ms))); comb_ms += ms.value
+        capi.check(lib.sda_event_elapsed_ms(evs[4 * i], evs[4 * i + 1], C.byref(ms))); gen_ms += ms.value
+        capi.check(lib.sda_event_elapsed_ms(evs[4 * i + 2], evs[4 * i + 3], C.byref(ms))); comb_ms += ms.value
     gen_ms /= args.steps
     comb_ms /= args.steps
     for e in evs:
@@ -219,6 +245,9 @@ def main():
             "config": {"workload": w["desc"], "name": args.workload, "dim": dim, "tile_participants": P,
                        "participants_total": world * args.steps * P, "share_count": n, "secret_count": k,
                        "privacy_threshold": t, "modulus": P62, "randomness": "on-device ChaCha20 (sda-drbg-v1)",
+                       "row_stride_elements": Bs,
+                       "schedule": ("share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares"
+                                    if args.overlap else "one stream, serial"),
                        "parallelism": f"participants sharded x{world}, one modular reduce at the end"},
             "roofline": {"bound": "hbm",
                          "kernel": "packed_gen_kernel" if w["kind"] == "packed" else "additive_gen_kernel",

@@ -62,7 +62,7 @@ hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, ui
                                   const ModParams& mod, const MontParams& mont, const MatArg& Mmont,
                                   const DrbgKey& key, int rounds, hipStream_t s);
 
-// packed Shamir, k + t <= 4 (BASELINE config 3): balanced 31-bit limbs, carry-free v_mad_i64_i32 dot
+// packed Shamir, compiled (k, t) shapes: balanced 31-bit limbs, carry-free v_mad_i64_i32 dot products
 bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n);
 hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
                                       const ModParams& mod, const L31Params& lp, const MatArg& Ml31,

@@ -230,15 +230,16 @@ __global__ __launch_bounds__(kThreads) void packed_gen_kernel(GenLayout L, uint3
 }
 
 // -------------------------------------------------------------------------------------------------
-// K2'  packed-Shamir share generation for k + t <= 4 (BASELINE config 3), the VALU-lean form.
+// K2'  packed-Shamir share generation, the VALU-lean form (all compiled (k, t) shapes).
 //
 // gfx950 cost model (tools/microbench_valu.hip): only v_add/sub/xor/and/mov issue at ~2.5 cycles per
 // wave64; EVERYTHING else - multiplies, v_mad_*64*, 64-bit adds, shifts, compares, carry ops - costs
 // ~4.5.  So the work is organised to minimise instruction count, not multiplier width:
 //   * every residue is centred to (-p/2, p/2) and split into balanced signed limbs x = x1*B + x0,
 //     B = 2^31, |x0|,|x1| <= 2^30; the matrix constants (Montgomery form, R = B^2 = 2^62) likewise;
-//   * a 4-term dot product is then three signed 64-bit column sums C0, C1, C2 built by 16
-//     v_mad_i64_i32 with NO carry handling: |C0|,|C2| <= 2^62, |C1| < 2^63;
+//   * a dot product of up to 4 terms is then three signed 64-bit column sums C0, C1, C2 built by 16
+//     v_mad_i64_i32 with NO carry handling: |C0|,|C2| <= 2^62, |C1| < 2^63 (longer dot products are
+//     cut into groups of 4 terms whose reduced results are added lazily in [0, 2p));
 //   * Montgomery reduction runs directly on the columns, one radix-B digit at a time
 //     (q = C * (-p^-1) mod B, balanced), again carry-free; the result lies in (-1.5p, 1.5p),
 //     +2p and two conditional subtractions make it canonical.
@@ -266,12 +267,15 @@ __device__ __forceinline__ int64_t mul_sv(int32_t s_a, int32_t v_b) {           
     return d;
 }
 
-template <int KT>
-__device__ __forceinline__ uint64_t l31_dot(const uint64_t* __restrict__ row, const int32_t (&v0)[KT],
-                                            const int32_t (&v1)[KT], const L31Params& P) {
+// One group of N <= 4 terms: carry-free columns + radix-B Montgomery reduction -> value in (-1.5p, 1.5p)
+// congruent to  sum_i M_i * v_i  (mod p).
+template <int N>
+__device__ __forceinline__ int64_t l31_group(const uint64_t* __restrict__ row, const int32_t* v0, const int32_t* v1,
+                                             const L31Params& P) {
+    static_assert(N >= 1 && N <= 4, "column bounds hold for at most 4 terms");
     int64_t C0, C1, C2;
 #pragma unroll
-    for (int i = 0; i < KT; ++i) {
+    for (int i = 0; i < N; ++i) {
         const int32_t m0 = (int32_t)(uint32_t)row[i];
         const int32_t m1 = (int32_t)(uint32_t)(row[i] >> 32);
         if (i == 0) {
@@ -285,18 +289,36 @@ __device__ __forceinline__ uint64_t l31_dot(const uint64_t* __restrict__ row, co
         }
         C1 = mad_sv(m1, v0[i], C1);
     }
-    // radix-B Montgomery reduction on the columns
     const int32_t q0 = sext31((uint32_t)C0 * P.pinvB);
     C0 = mad_sv(P.p0, q0, C0);                                  // == 0 mod B
     int64_t E = mad_sv(P.p1, q0, C0 >> 31);
     const int32_t q1 = sext31(((uint32_t)C1 + (uint32_t)E) * P.pinvB);
     E = mad_sv(P.p0, q1, E);                                    // C1 + E == 0 mod B
     // (C1 + E) / B without a 65-bit sum: the low limbs add up to 0 or B
-    const int64_t top = mad_sv(P.p1, q1, C2) + (C1 >> 31) + ((E + 0x7FFFFFFF) >> 31);
-    uint64_t r = (uint64_t)top + P.p2;                          // in [0, 4p)
-    if (r >= P.p2) r -= P.p2;
-    if (r >= P.p) r -= P.p;
-    return r;
+    return mad_sv(P.p1, q1, C2) + (C1 >> 31) + ((E + 0x7FFFFFFF) >> 31);
+}
+
+// x in [0, 4p) -> [0, 2p)
+__device__ __forceinline__ uint64_t condsub(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
+
+// sum_i M_i * v_i mod p for any KT: groups of <= 4 terms, partial results kept lazily in [0, 2p)
+template <int KT>
+__device__ __forceinline__ uint64_t l31_dot(const uint64_t* __restrict__ row, const int32_t (&v0)[KT],
+                                            const int32_t (&v1)[KT], const L31Params& P) {
+    uint64_t r = 0;
+#pragma unroll
+    for (int g = 0; g < KT; g += 4) {
+        constexpr int dummy = 0; (void)dummy;
+        int64_t top;
+        const int left = KT - g;
+        if (left >= 4) top = l31_group<4>(row + g, v0 + g, v1 + g, P);
+        else if (left == 3) top = l31_group<3>(row + g, v0 + g, v1 + g, P);
+        else if (left == 2) top = l31_group<2>(row + g, v0 + g, v1 + g, P);
+        else top = l31_group<1>(row + g, v0 + g, v1 + g, P);
+        const uint64_t u = condsub((uint64_t)top + P.p2, P.p2);           // [0, 2p)
+        r = g == 0 ? u : condsub(r + u, P.p2);                            // [0, 2p)
+    }
+    return condsub(r, P.p);
 }
 
 template <int K, int T, int ROUNDS, bool VEC>
@@ -304,7 +326,6 @@ __global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, u
                                                                   L31Params lp, MatArg M, DrbgKey key,
                                                                   uint64_t chunks, uint64_t batches) {
     constexpr int KT = K + T;
-    static_assert(KT <= 4, "the carry-free column bounds hold for at most 4 terms");
     uint64_t p, chunk;
     split_item(blockIdx.x, chunks, p, chunk);
     const uint64_t pair = chunk * kThreads + threadIdx.x;
@@ -787,7 +808,8 @@ hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, ui
     }
 }
 
-#define SDA_PACKED_L31_SHAPES(X) X(3, 1) X(1, 1) X(2, 1) X(1, 2) X(2, 2) X(1, 3) X(3, 0) X(4, 0) X(2, 0) X(1, 0)
+#define SDA_PACKED_L31_SHAPES(X) X(3, 1) X(3, 4) X(8, 2) X(8, 7) X(1, 1) X(2, 1) X(1, 2) X(2, 2) X(1, 3) X(3, 0) \
+    X(4, 0) X(2, 0) X(1, 0) X(2, 5) X(4, 3) X(4, 4) X(5, 3)
 
 bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n) {
     if ((uint64_t)n * (k + t) > SDA_MAT_ARG_MAX) return false;

@@ -48,7 +48,30 @@ def prep(p, rows):
 
 
 def share(ctx, row, v):
-    """device side: centre_limbs() + l31_dot()"""
+    """device side: l31_dot(): groups of <= 4 terms, partial results kept lazily in [0, 2p)"""
+    p = ctx["p"]
+    r = None
+    for g in range(0, len(v), 4):
+        top = group(ctx, row[g:g + 4], v[g:g + 4])
+        u = top + 2 * p
+        assert 0 <= u < 4 * p and u < (1 << 64)
+        if u >= 2 * p:
+            u -= 2 * p
+        if r is None:
+            r = u
+        else:
+            r += u
+            assert r < 4 * p and r < (1 << 64)
+            if r >= 2 * p:
+                r -= 2 * p
+    if r >= p:
+        r -= p
+    assert 0 <= r < p
+    return r
+
+
+def group(ctx, row, v):
+    """device side: centre_limbs() + l31_group()"""
     p = ctx["p"]
     C0 = C1 = C2 = 0
     assert len(v) <= 4
@@ -68,14 +91,7 @@ def share(ctx, row, v):
     assert (C1 + E) % B == 0
     carry1 = (C1 >> 31) + (i64(E + MB) >> 31)
     assert carry1 == (C1 + E) // B
-    top = i64(i64(C2 + q1 * ctx["p1"]) + carry1)
-    r = top + 2 * p
-    assert 0 <= r < 4 * p and r < (1 << 64)
-    if r >= 2 * p:
-        r -= 2 * p
-    if r >= p:
-        r -= p
-    return r
+    return i64(i64(C2 + q1 * ctx["p1"]) + carry1)
 
 
 def _roots(p, o2, o3):
@@ -84,7 +100,7 @@ def _roots(p, o2, o3):
 
 
 @pytest.mark.parametrize("p,k,t", [(po.P62, 3, 1), (433, 3, 1), (po.P62, 1, 1), (po.P62, 2, 2), (746497, 2, 1),
-                                   (po.P62, 1, 3), (po.P62, 4, 0), (5038849, 3, 1)])
+                                   (po.P62, 1, 3), (po.P62, 4, 0), (5038849, 3, 1), (po.P62, 3, 4), (433, 3, 4)])
 def test_limb31_dot_is_exact_and_fits(p, k, t):
     rnd = random.Random(p % 1000 + k)
     if p == po.P62:
@@ -104,9 +120,9 @@ def test_limb31_dot_is_exact_and_fits(p, k, t):
     # adversarial matrix entries at the edge of the centred range, all terms aligned
     rinv = pow(1 << 62, -1, p)
     for mr in {(p - 1) // 2, -((p - 1) // 2), 1, -1, 0, min((1 << 61) - 1, (p - 1) // 2), -min((1 << 61) - 1, (p - 1) // 2)}:
-        row = [bal(mr)] * 4
+        row = [bal(mr)] * 7
         for x in special:
-            v = [x] * 4
+            v = [x] * 7
             assert share(ctx, row, v) == sum((mr * rinv) % p * y for y in v) % p
 
 
@@ -117,6 +133,11 @@ def test_largest_modulus():
     rnd = random.Random(0)
     ctx = prep(p, [[rnd.randrange(p) for _ in range(4)] for _ in range(4)])
     rinv = pow(1 << 62, -1, p)
+    ctx15 = prep(p, [[rnd.randrange(p) for _ in range(15)] for _ in range(2)])
+    for _ in range(300):
+        v = [rnd.choice([0, p - 1, (p - 1) // 2, (p + 1) // 2, rnd.randrange(p)]) for _ in range(15)]
+        for row in ctx15["M"]:
+            assert share(ctx15, row, v) == sum(((m1 * B + m0) * rinv) % p * x for (m0, m1), x in zip(row, v)) % p
     for _ in range(2000):
         v = [rnd.choice([0, p - 1, (p - 1) // 2, (p + 1) // 2, rnd.randrange(p)]) for _ in range(4)]
         for row in ctx["M"]:
