@@ -53,7 +53,7 @@ def algorithmic_bytes_per_element(n, k):
     return gen, comb
 
 
-def cpu_baseline(w, dim, budget_s=12.0):
+def cpu_baseline(w, dim, budget_s=15.0):
     """The oracle's reference-faithful scalar port (share-gen + clerk-sum), single thread like the
     reference, on a bounded sample of the same workload.  Reported, never the thing shipped."""
     from oracle import coracle
@@ -62,7 +62,7 @@ def cpu_baseline(w, dim, budget_s=12.0):
     t0 = time.perf_counter()
     coracle.baseline_pass(*args, 1, dim, 0, SEED, KEY)
     one = time.perf_counter() - t0
-    parts = max(1, min(64, int(budget_s / max(one, 1e-3))))
+    parts = max(1, min(1024, int(budget_s / max(one, 1e-3))))
     t0 = time.perf_counter()
     done, _ = coracle.baseline_pass(*args, parts, dim, 0, SEED, KEY)
     dt = time.perf_counter() - t0

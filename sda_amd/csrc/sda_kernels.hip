@@ -39,13 +39,13 @@ typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 //     retry (rare)   : attempt a = 1, 2, ...: block with words 12,13 = b * T + i, word 15 |= a << 24;
 //                      candidates x_j = (out[2j] << 32) | out[2j+1], j = 0..7, first accepted wins.
 // =================================================================================================
+// Everything by value: a by-reference key would force a scratch copy of it at kernel entry
+// (measured: +11 GB of HBM writes per 2000-participant launch).
 template <int ROUNDS>
-__device__ __noinline__ uint64_t drbg_retry(const DrbgKey& key, uint64_t stream, uint64_t b, uint32_t T,
-                                            uint32_t i, const ModParams& mod) {
-    uint64_t I = b * (uint64_t)T + i;
-    uint32_t k[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) k[j] = key.w[j];
+__device__ __noinline__ uint64_t drbg_retry(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t k4, uint32_t k5,
+                                            uint32_t k6, uint32_t k7, uint64_t stream, uint64_t I, uint64_t m,
+                                            uint64_t lemire_thr) {
+    const uint32_t k[8] = {k0, k1, k2, k3, k4, k5, k6, k7};
     uint64_t val = 0;
     for (uint32_t a = 1; a < 256; ++a) {
         uint32_t o[16];
@@ -54,34 +54,49 @@ __device__ __noinline__ uint64_t drbg_retry(const DrbgKey& key, uint64_t stream,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint64_t x = ((uint64_t)o[2 * j] << 32) | o[2 * j + 1];
-            if (lemire_sample(x, mod.m, mod.lemire_thr, val)) return val;
+            if (lemire_sample(x, m, lemire_thr, val)) return val;
         }
     }
     return val;
 }
 
+// this lane's column of the ChaCha input state (lane c = lane id & 3 of a DPP quad): constant, key
+// word c, key word 4 + c.  Computed once per lane with selects - a dynamically indexed key would be
+// placed in scratch.
+struct QuadCol {
+    uint32_t cst, kb, kc;
+};
+__device__ __forceinline__ QuadCol quad_col(const DrbgKey& key) {
+    const uint32_t c = threadIdx.x & 3;
+    QuadCol q;
+    q.cst = c == 0 ? SDA_CHACHA_C0 : c == 1 ? SDA_CHACHA_C1 : c == 2 ? SDA_CHACHA_C2 : SDA_CHACHA_C3;
+    q.kb = c == 0 ? key.w[0] : c == 1 ? key.w[1] : c == 2 ? key.w[2] : key.w[3];
+    q.kc = c == 0 ? key.w[4] : c == 1 ? key.w[5] : c == 2 ? key.w[6] : key.w[7];
+    return q;
+}
+
 // Two uniform values per lane (for batches b0 = 2*pair and b0+1).  ALL FOUR lanes of a quad must
 // be active when this is called (DPP reads its neighbours).
 template <int ROUNDS>
-__device__ __forceinline__ void drbg_pair(const DrbgKey& key, uint64_t stream, uint64_t pair, uint32_t T,
-                                          uint32_t i, const ModParams& mod, uint64_t& r0, uint64_t& r1) {
+__device__ __forceinline__ void drbg_pair(const DrbgKey& key, const QuadCol& qc, uint64_t stream, uint64_t pair,
+                                          uint32_t T, uint32_t i, const ModParams& mod, uint64_t& r0, uint64_t& r1) {
     const uint32_t c = threadIdx.x & 3;
     const uint64_t g = pair >> 2;                       // batch group of 8 = one quad
     const uint64_t I = g * (uint64_t)T + i;
-    // this lane's column of the input state
-    const uint32_t cst = c == 0 ? SDA_CHACHA_C0 : c == 1 ? SDA_CHACHA_C1 : c == 2 ? SDA_CHACHA_C2 : SDA_CHACHA_C3;
-    const uint32_t kb = c == 0 ? key.w[0] : c == 1 ? key.w[1] : c == 2 ? key.w[2] : key.w[3];
-    const uint32_t kc = c == 0 ? key.w[4] : c == 1 ? key.w[5] : c == 2 ? key.w[6] : key.w[7];
     const uint32_t ctr = c == 0 ? (uint32_t)I : c == 1 ? (uint32_t)(I >> 32) : c == 2 ? (uint32_t)stream
                                                                               : ((uint32_t)(stream >> 32) & 0xFFFFFFu);
     uint32_t o0, o1, o2, o3;
-    chacha_block_quad<ROUNDS>(cst, kb, kc, ctr, o0, o1, o2, o3);
+    chacha_block_quad<ROUNDS>(qc.cst, qc.kb, qc.kc, ctr, o0, o1, o2, o3);
     const uint64_t x0 = ((uint64_t)o0 << 32) | o1;
     const uint64_t x1 = ((uint64_t)o2 << 32) | o3;
     const bool ok0 = lemire_sample(x0, mod.m, mod.lemire_thr, r0);
     const bool ok1 = lemire_sample(x1, mod.m, mod.lemire_thr, r1);
-    if (__builtin_expect(!ok0, 0)) r0 = drbg_retry<ROUNDS>(key, stream, 2 * pair, T, i, mod);
-    if (__builtin_expect(!ok1, 0)) r1 = drbg_retry<ROUNDS>(key, stream, 2 * pair + 1, T, i, mod);
+    if (__builtin_expect(!ok0, 0))
+        r0 = drbg_retry<ROUNDS>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
+                                (2 * pair) * (uint64_t)T + i, mod.m, mod.lemire_thr);
+    if (__builtin_expect(!ok1, 0))
+        r1 = drbg_retry<ROUNDS>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
+                                (2 * pair + 1) * (uint64_t)T + i, mod.m, mod.lemire_thr);
 }
 
 // ---- small load/store helpers --------------------------------------------------------------------
@@ -125,13 +140,14 @@ __global__ __launch_bounds__(kThreads) void additive_gen_kernel(GenLayout L, uin
     const uint32_t T = n - 1;
     const uint64_t stream = L.first_participant + p;
     const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
+    const QuadCol qc = quad_col(key);
     for (uint32_t i = 0; i < T; ++i) {
         uint64_t r0 = 0, r1 = 0;
         if (rp) {
             if (in0) r0 = canon_i64(rp[b0 * T + i], mod.m, mod.mu);
             if (in1) r1 = canon_i64(rp[(b0 + 1) * T + i], mod.m, mod.mu);
         } else {
-            drbg_pair<ROUNDS>(key, stream, pair, T, i, mod, r0, r1);
+            drbg_pair<ROUNDS>(key, qc, stream, pair, T, i, mod, r0, r1);
         }
         s0 = submod(s0, r0, mod.m);
         s1 = submod(s1, r1, mod.m);
@@ -211,8 +227,9 @@ __global__ __launch_bounds__(kThreads) void packed_gen_kernel(GenLayout L, uint3
         }
     } else {
         const uint64_t stream = L.first_participant + p;
+        const QuadCol qc = quad_col(key);
 #pragma unroll
-        for (int i = 0; i < T; ++i) drbg_pair<ROUNDS>(key, stream, pair, T, i, mod, v0[K + i], v1[K + i]);
+        for (int i = 0; i < T; ++i) drbg_pair<ROUNDS>(key, qc, stream, pair, T, i, mod, v0[K + i], v1[K + i]);
     }
 
     int64_t* op = L.out + p * L.out_stride_participant + b0;
@@ -362,8 +379,9 @@ __global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, u
         }
     } else {
         const uint64_t stream = L.first_participant + p;
+        const QuadCol qc = quad_col(key);
 #pragma unroll
-        for (int i = 0; i < T; ++i) drbg_pair<ROUNDS>(key, stream, pair, T, i, mod, s0[K + i], s1[K + i]);
+        for (int i = 0; i < T; ++i) drbg_pair<ROUNDS>(key, qc, stream, pair, T, i, mod, s0[K + i], s1[K + i]);
     }
 
     int32_t a0[KT], a1[KT], c0[KT], c1[KT];
@@ -429,9 +447,10 @@ __global__ __launch_bounds__(kThreads) void drbg_fill_kernel(int64_t* out, size_
     const uint64_t pair = chunk * kThreads + threadIdx.x;
     const uint64_t b0 = 2 * pair;
     int64_t* o = out + p * stride;
+    const QuadCol qc = quad_col(key);
     for (uint32_t i = 0; i < T; ++i) {
         uint64_t r0, r1;
-        drbg_pair<ROUNDS>(key, first_participant + p, pair, T, i, mod, r0, r1);
+        drbg_pair<ROUNDS>(key, qc, first_participant + p, pair, T, i, mod, r0, r1);
         if (b0 < batches) o[b0 * T + i] = (int64_t)r0;
         if (b0 + 1 < batches) o[(b0 + 1) * T + i] = (int64_t)r1;
     }
@@ -566,7 +585,7 @@ __global__ __launch_bounds__(kThreads) void full_mask_drbg_kernel(const int64_t*
     const uint64_t pair = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
     const uint64_t b0 = 2 * pair;
     uint64_t r0, r1;
-    drbg_pair<ROUNDS>(key, stream, pair, 1, 0, mod, r0, r1);
+    drbg_pair<ROUNDS>(key, quad_col(key), stream, pair, 1, 0, mod, r0, r1);
     if (b0 < len) {
         mask[b0] = (int64_t)r0;
         masked[b0] = (int64_t)addmod(canon_i64(secrets[b0], mod.m, mod.mu), r0, mod.m);
