@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsda_hip.so")
+# SDA_HIP_LIBRARY lets a developer A/B two builds of the same library; it is never a fallback
+LIB_PATH = os.environ.get("SDA_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libsda_hip.so")
 
 c_i64p = C.POINTER(C.c_int64)
 c_u8p = C.POINTER(C.c_uint8)
