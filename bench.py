@@ -101,8 +101,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     lib = capi.load()
     capi.check(lib.sda_set_device(local_rank))
@@ -157,7 +159,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -184,10 +186,10 @@ def main():
         step(i, i % nbuf, evs[4 * i:4 * i + 4])
     comb.finish_dev(sums.data_ptr(), h_comb or 0)
     with torch.cuda.stream(s_comb):
-        total = modular_allreduce(sums, P62) if world > 1 else sums     # X1: the only exchange step
+        total = modular_allreduce(sums, P62) if use_dist else sums     # X1: the only exchange step
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -219,7 +221,7 @@ def main():
             cs.update_dev(secrets.data_ptr(), 0, P, dim, stream=stream or 0)
         exp = torch.empty(dim, dtype=torch.int64, device=dev)
         cs.finish_dev(exp.data_ptr(), stream or 0)
-        exp_total = modular_allreduce(exp, P62) if world > 1 else exp
+        exp_total = modular_allreduce(exp, P62) if use_dist else exp
         torch.cuda.synchronize(dev)
         verified = bool(torch.equal(out, exp_total))
 
@@ -269,7 +271,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -14,6 +14,7 @@ torch.distributed is plumbing here (RCCL over xGMI with backend "nccl"; gloo on 
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -48,7 +49,8 @@ def modular_allreduce(partial: torch.Tensor, modulus: int, group=None,
     reduce_fn = local_modsum or _hip_modsum_parts
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     flat = partial.reshape(-1).contiguous()
-    if world == 1:
+    force = dist.is_initialized() and os.environ.get("SDA_FORCE_COLLECTIVES") == "1"   # exercise RCCL with 1 rank
+    if world == 1 and not force:
         return reduce_fn(flat.unsqueeze(0), modulus).reshape(partial.shape)
     n = flat.numel()
     seg = (n + world - 1) // world                      # slice owned by each rank

@@ -500,3 +500,23 @@ def test_any_i64_canonicalisation_property(gpu):
         rnd = np.array([5, -7], dtype=np.int64)
         got = g.generate(edge[:6], rnd)
         assert np.array_equal(got, coracle.packed_generate(p, 3, 1, 8, w2, 3, edge[:6], rnd))
+
+
+def test_bench_under_torchrun_single_rank_rccl(gpu):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, backend nccl = RCCL),
+    with one rank and the collective path forced, so init / all_to_all / all_gather / all_reduce run on
+    real RCCL.  The result must verify (reconstruct == sum of secrets)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDA_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--tile", "64", "--dim", "65536", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["verified_reconstruct_equals_sum"] is True
+    assert d["roofline"]["bound"] == "hbm" and d["value"] > 0
