@@ -304,6 +304,37 @@ int sda_secret_unmasker_unmask(sda_secret_unmasker_t* u,
 int sda_positive(const int64_t* values, size_t len, int64_t modulus, int64_t* out);
 
 /* =============================================================================================
+ * Share-vector wire codec (first "next" row): zig-zag LEB128 varints, the format either
+ * side of the path - ShareEncryptor::encrypt encodes every share with `encode_var` before sealing
+ * (client/src/crypto/encryption/sodium.rs:36-41) and ShareDecryptor::decrypt decodes until the reader
+ * is empty (:83-89); integer-encoding 1.0 `VarInt for i64`.  The sealed box itself stays out of scope.
+ * ============================================================================================= */
+typedef struct sda_varint_codec sda_varint_codec_t;
+int  sda_varint_codec_new(sda_varint_codec_t** out);
+void sda_varint_codec_free(sda_varint_codec_t* c);
+size_t sda_varint_max_encoded_size(size_t count);            /* 10 bytes per value */
+
+/* encode `len` values -> out[*out_len] (sodium.rs:36-41) */
+int sda_varint_encode(sda_varint_codec_t* c, const int64_t* values, size_t len,
+                      uint8_t* out, size_t out_cap, size_t* out_len);
+/* decode the whole byte string -> out[*out_len] values (sodium.rs:83-89).  A stream that ends inside a
+ * value, or holds more than 10 bytes without a terminator, is refused with SDA_ERR_INVALID_ARGUMENT
+ * (the reference would return garbage for it). */
+int sda_varint_decode(sda_varint_codec_t* c, const uint8_t* bytes, size_t n_bytes,
+                      int64_t* out, size_t out_cap, size_t* out_len);
+
+/* device forms: `rows` vectors of `len` values (row r at d_values + r*row_stride) <-> one concatenated
+ * byte stream; d_row_offsets[rows + 1] (device, u64) holds the byte offset of every row's encoding, so
+ * each clerk's / participant's vector can be sealed or opened separately.
+ *   encode: *total_bytes (host) is valid on return (the call synchronises once to size the output).
+ *   decode: d_status (device u32) is OR-ed with 1 = malformed, 2 = a row does not hold `len` values,
+ *           4 = a row ends inside a value; zero it beforehand.  d_row_offsets may be NULL for rows == 1. */
+int sda_varint_encode_dev(sda_varint_codec_t* c, const int64_t* d_values, size_t rows, size_t len, size_t row_stride,
+                          uint8_t* d_out, size_t out_cap, uint64_t* d_row_offsets, uint64_t* total_bytes, void* stream);
+int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_row_offsets,
+                          size_t rows, size_t len, int64_t* d_values, size_t row_stride, uint32_t* d_status, void* stream);
+
+/* =============================================================================================
  * Cross-GPU modular reduction helper (new; no reference counterpart - SURVEY.md 8e).
  * d_parts holds `parts` vectors of `len` canonical residues (part g at d_parts + g*part_stride);
  * d_out[len] = sum over parts mod modulus.  Used after an all-to-all of per-GPU partial clerk sums

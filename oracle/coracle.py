@@ -157,3 +157,21 @@ def baseline_pass(packed, modulus, n, k, t, w2, w3, participants, length, first_
                                     C.c_size_t(participants), C.c_size_t(length), C.c_uint64(first_participant),
                                     C.c_uint64(seed), kb, sums.ctypes.data_as(I64P))
     return done, sums
+
+
+def varint_encode(values) -> bytes:
+    v, vp = _i64(values)
+    out = np.empty(v.size * 10 + 1, dtype=np.uint8)
+    lib().sdao_varint_encode.restype = C.c_size_t
+    n = lib().sdao_varint_encode(vp, C.c_size_t(v.size), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out[:n].tobytes()
+
+
+def varint_decode(raw: bytes, cap=None):
+    b = np.frombuffer(raw, dtype=np.uint8)
+    cap = len(raw) if cap is None else cap
+    out = np.empty(max(cap, 1), dtype=np.int64)
+    lib().sdao_varint_decode.restype = C.c_size_t
+    n = lib().sdao_varint_decode(b.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(b.size), out.ctypes.data_as(I64P),
+                                 C.c_size_t(cap))
+    return out[:n].copy()

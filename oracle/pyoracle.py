@@ -724,3 +724,49 @@ def splitmix64(x: int) -> int:
 def synthetic_secret(seed: int, participant: int, i: int, modulus: int) -> int:
     """SURVEY.md 8d synthetic input."""
     return splitmix64(seed ^ (((participant << 32) | i) & MASK64)) % modulus
+
+
+# --------------------------------------------------------------------------------------
+# Share-vector wire codec (SURVEY.md 8f rank 1): integer-encoding 1.0 `VarInt for i64`
+# [recalled] as used by client/src/crypto/encryption/sodium.rs:36-41 (encode) and :83-89
+# (decode): zig-zag, then LEB128 (7-bit groups, least significant first, MSB = continuation).
+# --------------------------------------------------------------------------------------
+def varint_encode_i64(v: int) -> bytes:
+    """`share.encode_var(&mut buf)` - sodium.rs:39"""
+    assert -(1 << 63) <= v < (1 << 63)
+    n = ((v << 1) ^ (v >> 63)) & MASK64                 # zig-zag
+    out = bytearray()
+    while n >= 0x80:
+        out.append(0x80 | (n & 0x7F))
+        n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def varint_encode(values: Sequence[int]) -> bytes:
+    """sodium.rs:36-41: the encodings concatenated."""
+    return b"".join(varint_encode_i64(v) for v in values)
+
+
+def varint_decode_one(src: bytes) -> Tuple[int, int]:
+    """`Share::decode_var(reader)` - sodium.rs:86; u64::decode_var + zig-zag decode."""
+    result, shift = 0, 0
+    for b in src:
+        result |= ((b & 0x7F) << shift) & MASK64
+        shift += 7
+        if b & 0x80 == 0 or shift > 10 * 7:
+            break
+    v = (result >> 1) ^ (-(result & 1) & MASK64)
+    if v >= 1 << 63:
+        v -= 1 << 64
+    return v, shift // 7
+
+
+def varint_decode(raw: bytes) -> List[int]:
+    """sodium.rs:83-89: decode until the reader is empty."""
+    out, pos = [], 0
+    while pos < len(raw):
+        v, size = varint_decode_one(raw[pos:])
+        out.append(v)
+        pos += size
+    return out

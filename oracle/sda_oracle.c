@@ -421,3 +421,34 @@ size_t sdao_baseline_pass(int packed, int64_t modulus, int n, int k, int t, int6
     free(secrets); free(rnd); free(shares); free(tmp);
     return participants * len;
 }
+
+/* ================================================================================================
+ * Share-vector wire codec: integer-encoding 1.0 `VarInt for i64` [recalled],
+ * call sites client/src/crypto/encryption/sodium.rs:36-41 (encode) and :83-89 (decode).
+ * ============================================================================================== */
+size_t sdao_varint_encode(const int64_t* values, size_t len, uint8_t* out) {
+    size_t pos = 0;
+    for (size_t i = 0; i < len; ++i) {
+        uint64_t n = ((uint64_t)values[i] << 1) ^ (uint64_t)(values[i] >> 63);   /* zig-zag */
+        while (n >= 0x80) { out[pos++] = (uint8_t)(0x80 | (n & 0x7F)); n >>= 7; }
+        out[pos++] = (uint8_t)n;
+    }
+    return pos;
+}
+
+/* decodes until the input is exhausted or `cap` values were produced; returns the value count */
+size_t sdao_varint_decode(const uint8_t* src, size_t n_bytes, int64_t* out, size_t cap) {
+    size_t pos = 0, count = 0;
+    while (pos < n_bytes && count < cap) {
+        uint64_t result = 0;
+        unsigned shift = 0;
+        while (pos < n_bytes) {
+            uint8_t b = src[pos++];
+            result |= (uint64_t)(b & 0x7F) << (shift & 63);
+            shift += 7;
+            if ((b & 0x80) == 0 || shift > 70) break;
+        }
+        out[count++] = (int64_t)((result >> 1) ^ (uint64_t)(-(int64_t)(result & 1)));
+    }
+    return count;
+}

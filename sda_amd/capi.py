@@ -110,6 +110,15 @@ SIGNATURES = {
     "sda_secret_unmasker_free": (None, [_H]),
     "sda_secret_unmasker_unmask": (C.c_int, [_H, c_i64p, C.c_size_t, c_i64p, C.c_size_t, c_i64p]),
     "sda_positive": (C.c_int, [c_i64p, C.c_size_t, C.c_int64, c_i64p]),
+    "sda_varint_codec_new": (C.c_int, [_HP]),
+    "sda_varint_codec_free": (None, [_H]),
+    "sda_varint_max_encoded_size": (C.c_size_t, [C.c_size_t]),
+    "sda_varint_encode": (C.c_int, [_H, c_i64p, C.c_size_t, c_u8p, C.c_size_t, c_sizep]),
+    "sda_varint_decode": (C.c_int, [_H, c_u8p, C.c_size_t, c_i64p, C.c_size_t, c_sizep]),
+    "sda_varint_encode_dev": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
+    "sda_varint_decode_dev": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_void_p]),
     "sda_modsum_parts_dev": (C.c_int, [C.c_int64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                        C.c_void_p]),
     "sda_fill_synthetic_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64,

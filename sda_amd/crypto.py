@@ -383,3 +383,40 @@ def full_aggregation(aggregation: Aggregation, inputs: Sequence[Sequence[int]], 
     return {"masks": masks, "masked": maskeds, "shares": shares, "clerk_sums": clerk_sums,
             "combined_mask": mask, "masked_output": masked_output, "output": output,
             "positive": RecipientOutput(a.modulus, output).positive().values}
+
+
+# ---- share-vector wire codec -------------------------------------------------------------
+class VarintCodec(_Handle):
+    """zig-zag LEB128 codec of share vectors: what `ShareEncryptor::encrypt` does before sealing
+    (encryption/sodium.rs:36-41) and `ShareDecryptor::decrypt` after opening (:83-89)."""
+    _free = "sda_varint_codec_free"
+
+    def __init__(self):
+        super().__init__()
+        check(self._lib.sda_varint_codec_new(C.byref(self._h)))
+
+    def encode(self, shares) -> bytes:
+        v = _vec(shares)
+        out = np.empty(max(v.size * 10, 1), dtype=np.uint8)
+        n = C.c_size_t()
+        check(self._lib.sda_varint_encode(self._h, _ptr(v), v.size, out.ctypes.data_as(capi.c_u8p), v.size * 10, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def decode(self, raw: bytes) -> np.ndarray:
+        b = np.frombuffer(raw, dtype=np.uint8)
+        out = np.empty(max(b.size, 1), dtype=np.int64)
+        n = C.c_size_t()
+        check(self._lib.sda_varint_decode(self._h, b.ctypes.data_as(capi.c_u8p), b.size, _ptr(out), b.size, C.byref(n)))
+        return out[:n.value].copy()
+
+    def encode_dev(self, d_values: int, rows: int, length: int, row_stride: int, d_out: int, out_cap: int,
+                   d_row_offsets: int = 0, stream: int = 0) -> int:
+        total = C.c_uint64()
+        check(self._lib.sda_varint_encode_dev(self._h, d_values, rows, length, row_stride, d_out, out_cap,
+                                              d_row_offsets or None, C.byref(total), stream or None))
+        return total.value
+
+    def decode_dev(self, d_bytes: int, n_bytes: int, d_row_offsets: int, rows: int, length: int, d_values: int,
+                   row_stride: int, d_status: int, stream: int = 0) -> None:
+        check(self._lib.sda_varint_decode_dev(self._h, d_bytes, n_bytes, d_row_offsets or None, rows, length, d_values,
+                                              row_stride, d_status, stream or None))

@@ -120,6 +120,24 @@ hipError_t launch_chacha_mask_slow(const uint32_t* d_seeds, const uint32_t* d_li
                                    uint64_t* d_acc_lo, int64_t* d_acc_hi, bool subtract_naive,
                                    hipStream_t s);
 
+// ---- zig-zag LEB128 codec of share vectors (sodium.rs:36-41, :83-89) - varint_kernels.hip -------------
+struct VarintRows {
+    const int64_t* values;    // row r at values + r*row_stride
+    size_t rows, len, row_stride;
+};
+size_t varint_encode_blocks(size_t rows, size_t len);     // workgroups (= entries of the block-sum arrays)
+size_t varint_decode_blocks(size_t n_bytes);
+hipError_t launch_varint_lengths(const VarintRows& R, uint32_t* d_block_bytes, hipStream_t s);
+hipError_t launch_scan_u32(const uint32_t* d_in, uint64_t* d_out, size_t n, uint64_t* d_total, hipStream_t s);
+hipError_t launch_varint_write(const VarintRows& R, const uint64_t* d_block_off, uint8_t* d_out,
+                               uint64_t* d_row_offsets, hipStream_t s);
+hipError_t launch_varint_count(const uint8_t* d_bytes, size_t n_bytes, uint32_t* d_block_counts, hipStream_t s);
+hipError_t launch_varint_decode(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_block_val_off,
+                                size_t rows, size_t len, size_t row_stride, int64_t* d_out, uint32_t* d_status,
+                                hipStream_t s);
+hipError_t launch_varint_rowcheck(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t rows,
+                                  size_t len, const uint64_t* d_block_val_off, uint32_t* d_status, hipStream_t s);
+
 // ---- misc ---------------------------------------------------------------------------------------
 // out[i] = sum over g < parts of parts[g*part_stride + i]  mod m   (cross-GPU partial sums)
 hipError_t launch_modsum_parts(const int64_t* d_parts, size_t parts, size_t part_stride, size_t len,

@@ -1067,6 +1067,140 @@ extern "C" int sda_positive(const int64_t* values, size_t len, int64_t modulus, 
 }
 
 // =================================================================================================
+// Share-vector wire codec (zig-zag LEB128) - sodium.rs:36-41, :83-89
+// =================================================================================================
+struct sda_varint_codec {
+    Ctx ctx;
+    DevBuf d_blocks, d_offs, d_total, d_status, d_in, d_out, d_rowoff;
+};
+
+extern "C" int sda_varint_codec_new(sda_varint_codec_t** out) {
+    if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    sda_varint_codec* c = new (std::nothrow) sda_varint_codec();
+    if (!c) return fail(SDA_ERR_ALLOC, "out of memory");
+    int st = c->ctx.init();
+    if (st == SDA_OK) st = c->d_total.reserve(8);
+    if (st == SDA_OK) st = c->d_status.reserve(4);
+    if (st != SDA_OK) { sda_varint_codec_free(c); return st; }
+    *out = c;
+    return SDA_OK;
+}
+
+extern "C" void sda_varint_codec_free(sda_varint_codec_t* c) {
+    if (!c) return;
+    if (c->ctx.device >= 0) (void)hipSetDevice(c->ctx.device);
+    c->d_blocks.release(); c->d_offs.release(); c->d_total.release(); c->d_status.release();
+    c->d_in.release(); c->d_out.release(); c->d_rowoff.release();
+    delete c;
+}
+
+extern "C" size_t sda_varint_max_encoded_size(size_t count) { return count * 10; }
+
+extern "C" int sda_varint_encode_dev(sda_varint_codec_t* c, const int64_t* d_values, size_t rows, size_t len,
+                                     size_t row_stride, uint8_t* d_out, size_t out_cap, uint64_t* d_row_offsets,
+                                     uint64_t* total_bytes, void* stream) {
+    if (!c || !total_bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    *total_bytes = 0;
+    SDA_TRY(c->ctx.use());
+    hipStream_t s = c->ctx.pick(stream);
+    const size_t nb = varint_encode_blocks(rows, len);
+    if (nb == 0) {
+        if (d_row_offsets && rows + 1 > 0) HIP_TRY(hipMemsetAsync(d_row_offsets, 0, (rows + 1) * 8, s));
+        return SDA_OK;
+    }
+    if (!d_values || !d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (row_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "row_stride < len");
+    SDA_TRY(c->d_blocks.reserve(nb * 4));
+    SDA_TRY(c->d_offs.reserve(nb * 8));
+    VarintRows R{d_values, rows, len, row_stride};
+    HIP_TRY(launch_varint_lengths(R, c->d_blocks.as<uint32_t>(), s));
+    HIP_TRY(launch_scan_u32(c->d_blocks.as<uint32_t>(), c->d_offs.as<uint64_t>(), nb, c->d_total.as<uint64_t>(), s));
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->d_total.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (total > out_cap) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small: need %llu bytes", (unsigned long long)total);
+    HIP_TRY(launch_varint_write(R, c->d_offs.as<uint64_t>(), d_out, d_row_offsets, s));
+    if (d_row_offsets) HIP_TRY(hipMemcpyAsync(d_row_offsets + rows, c->d_total.p, 8, hipMemcpyDeviceToDevice, s));
+    *total_bytes = total;
+    return SDA_OK;
+}
+
+static int varint_count_scan(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t n_bytes, hipStream_t s) {
+    const size_t nb = varint_decode_blocks(n_bytes);
+    SDA_TRY(c->d_blocks.reserve((nb + 1) * 4));
+    SDA_TRY(c->d_offs.reserve((nb + 1) * 8));
+    HIP_TRY(launch_varint_count(d_bytes, n_bytes, c->d_blocks.as<uint32_t>(), s));
+    // one extra (zero) entry so that prefix(x) is defined for x == n_bytes on a block boundary
+    HIP_TRY(hipMemsetAsync(c->d_blocks.as<uint32_t>() + nb, 0, 4, s));
+    HIP_TRY(launch_scan_u32(c->d_blocks.as<uint32_t>(), c->d_offs.as<uint64_t>(), nb + 1, c->d_total.as<uint64_t>(), s));
+    return SDA_OK;
+}
+
+extern "C" int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t n_bytes,
+                                     const uint64_t* d_row_offsets, size_t rows, size_t len, int64_t* d_values,
+                                     size_t row_stride, uint32_t* d_status, void* stream) {
+    if (!c || !d_status) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!d_row_offsets && rows > 1) return fail(SDA_ERR_INVALID_ARGUMENT, "d_row_offsets is required for rows > 1");
+    if (row_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "row_stride < len");
+    SDA_TRY(c->ctx.use());
+    hipStream_t s = c->ctx.pick(stream);
+    if (n_bytes > 0 && (!d_bytes || !d_values)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    SDA_TRY(varint_count_scan(c, d_bytes, n_bytes, s));
+    HIP_TRY(launch_varint_decode(d_bytes, n_bytes, c->d_offs.as<uint64_t>(), rows, len, row_stride, d_values, d_status, s));
+    HIP_TRY(launch_varint_rowcheck(d_bytes, n_bytes, d_row_offsets, rows, len, c->d_offs.as<uint64_t>(), d_status, s));
+    return SDA_OK;
+}
+
+extern "C" int sda_varint_encode(sda_varint_codec_t* c, const int64_t* values, size_t len, uint8_t* out, size_t out_cap,
+                                 size_t* out_len) {
+    if (!c || !out_len) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_len = 0;
+    if (len == 0) return SDA_OK;
+    if (!values || !out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    SDA_TRY(c->ctx.use());
+    SDA_TRY(c->d_in.reserve(len * 8));
+    SDA_TRY(c->d_out.reserve(len * 10 + 16));
+    HIP_TRY(hipMemcpyAsync(c->d_in.p, values, len * 8, hipMemcpyHostToDevice, c->ctx.stream));
+    uint64_t total = 0;
+    SDA_TRY(sda_varint_encode_dev(c, c->d_in.as<int64_t>(), 1, len, len, c->d_out.as<uint8_t>(), len * 10, nullptr, &total, nullptr));
+    if (total > out_cap) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small: need %llu bytes", (unsigned long long)total);
+    HIP_TRY(hipMemcpyAsync(out, c->d_out.p, total, hipMemcpyDeviceToHost, c->ctx.stream));
+    SDA_TRY(c->ctx.sync());
+    *out_len = (size_t)total;
+    return SDA_OK;
+}
+
+extern "C" int sda_varint_decode(sda_varint_codec_t* c, const uint8_t* bytes, size_t n_bytes, int64_t* out, size_t out_cap,
+                                 size_t* out_len) {
+    if (!c || !out_len) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_len = 0;
+    if (n_bytes == 0) return SDA_OK;
+    if (!bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    SDA_TRY(c->ctx.use());
+    hipStream_t s = c->ctx.stream;
+    SDA_TRY(c->d_in.reserve(n_bytes + 16));
+    HIP_TRY(hipMemcpyAsync(c->d_in.p, bytes, n_bytes, hipMemcpyHostToDevice, s));
+    // first pass only to learn the value count
+    SDA_TRY(varint_count_scan(c, c->d_in.as<uint8_t>(), n_bytes, s));
+    uint64_t count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, c->d_total.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (count > out_cap) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small: %llu values", (unsigned long long)count);
+    SDA_TRY(c->d_out.reserve((count ? count : 1) * 8));
+    HIP_TRY(hipMemsetAsync(c->d_status.p, 0, 4, s));
+    SDA_TRY(sda_varint_decode_dev(c, c->d_in.as<uint8_t>(), n_bytes, nullptr, 1, count, c->d_out.as<int64_t>(), count,
+                                  c->d_status.as<uint32_t>(), nullptr));
+    uint32_t status = 0;
+    HIP_TRY(hipMemcpyAsync(&status, c->d_status.p, 4, hipMemcpyDeviceToHost, s));
+    if (count) HIP_TRY(hipMemcpyAsync(out, c->d_out.p, count * 8, hipMemcpyDeviceToHost, s));
+    SDA_TRY(c->ctx.sync());
+    if (status) return fail(SDA_ERR_INVALID_ARGUMENT, "malformed varint stream (status %u: 1 = over-long value, 4 = ends inside a value)", status);
+    *out_len = (size_t)count;
+    return SDA_OK;
+}
+
+// =================================================================================================
 // multi-GPU helper, synthetic input, timing
 // =================================================================================================
 static int device_ready() {

@@ -1,0 +1,320 @@
+// Zig-zag LEB128 codec of share vectors on gfx950: the wire format either side
+// of the path - client/src/crypto/encryption/sodium.rs:36-41 (encode: `share.encode_var`) and :83-89
+// (decode: `Share::decode_var` until the reader is empty); integer-encoding 1.0 `VarInt for i64`.
+//
+// Variable-length coding is a scan problem:
+//   encode: byte length per value (clz) -> workgroup sums -> exclusive scan -> bytes staged in LDS and
+//           copied out with dword stores;
+//   decode: a byte with the MSB clear terminates a value, so value index = number of terminators
+//           before it: terminator counts per 4 KiB -> exclusive scan -> every terminator's owner lane
+//           looks back <= 9 bytes in an LDS tile (16-byte halo) and assembles the value.
+// Both are HBM streams (about 9 B of wire + 8 B of value per 62-bit share).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace sda {
+
+static constexpr int kVT = 256;          // threads per workgroup
+static constexpr int kVals = 8;          // encode: values per lane  (2048 per workgroup)
+static constexpr int kBytes = 16;        // decode: bytes per lane   (4096 per workgroup)
+
+__device__ __forceinline__ uint64_t zigzag(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
+__device__ __forceinline__ uint32_t varint_len(uint64_t zz) {
+    const uint32_t x = (64u - (uint32_t)__clzll(zz | 1ull)) + 6u;     // bits + 6, in 7..70
+    return (x * 37u) >> 8;                                            // x / 7 for x <= 70
+}
+
+// workgroup exclusive scan of one u32 per lane; returns the lane's prefix, *total = workgroup sum
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* lds_waves, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) lds_waves[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kVT / 64; ++w) {
+        const uint32_t t = lds_waves[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    *total = tot;
+    __syncthreads();
+    return off + incl - v;
+}
+
+// ---- encode ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kVT) void varint_len_kernel(VarintRows R, uint32_t* __restrict__ block_bytes) {
+    __shared__ uint32_t waves[kVT / 64];
+    const uint64_t N = (uint64_t)R.rows * R.len;
+    const uint64_t g0 = ((uint64_t)blockIdx.x * kVT + threadIdx.x) * kVals;
+    uint32_t sum = 0;
+    if (g0 < N) {
+        uint64_t r = g0 / R.len, i = g0 - r * R.len;
+#pragma unroll
+        for (int k = 0; k < kVals; ++k) {
+            if (g0 + k < N) sum += varint_len(zigzag(R.values[r * R.row_stride + i]));
+            if (++i == R.len) { i = 0; ++r; }
+        }
+    }
+    uint32_t total;
+    (void)block_exscan(sum, waves, &total);
+    if (threadIdx.x == 0) block_bytes[blockIdx.x] = total;
+}
+
+// one workgroup walks the array: out[i] = sum of in[0..i), *total = sum of all
+__global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                        size_t n, uint64_t* __restrict__ total) {
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (size_t base = 0; base < n; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        const uint64_t v = i < n ? in[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint64_t off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wave_sum[w];
+        if (i < n) out[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(kVT) void varint_write_kernel(VarintRows R, const uint64_t* __restrict__ block_off,
+                                                           uint8_t* __restrict__ out, uint64_t* __restrict__ row_offsets) {
+    __shared__ uint32_t waves[kVT / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kVT * kVals * 10 + 16];
+    const uint64_t N = (uint64_t)R.rows * R.len;
+    const uint64_t g0 = ((uint64_t)blockIdx.x * kVT + threadIdx.x) * kVals;
+    uint64_t zz[kVals];
+    uint32_t ln[kVals];
+    uint32_t sum = 0;
+    uint64_t r0 = 0, i0 = 0;
+    if (g0 < N) { r0 = g0 / R.len; i0 = g0 - r0 * R.len; }
+    {
+        uint64_t r = r0, i = i0;
+#pragma unroll
+        for (int k = 0; k < kVals; ++k) {
+            zz[k] = 0; ln[k] = 0;
+            if (g0 + k < N) {
+                zz[k] = zigzag(R.values[r * R.row_stride + i]);
+                ln[k] = varint_len(zz[k]);
+                sum += ln[k];
+            }
+            if (++i == R.len) { i = 0; ++r; }
+        }
+    }
+    uint32_t total;
+    uint32_t pos = block_exscan(sum, waves, &total);
+    const uint64_t boff = block_off[blockIdx.x];
+    {
+        uint64_t r = r0, i = i0;
+#pragma unroll
+        for (int k = 0; k < kVals; ++k) {
+            if (g0 + k < N) {
+                if (i == 0 && row_offsets) row_offsets[r] = boff + pos;     // this value opens row r
+                uint64_t n = zz[k];
+                for (uint32_t b = 0; b + 1 < ln[k]; ++b) { stage[pos++] = (uint8_t)(0x80u | (n & 0x7Fu)); n >>= 7; }
+                stage[pos++] = (uint8_t)n;
+            }
+            if (++i == R.len) { i = 0; ++r; }
+        }
+    }
+    __syncthreads();
+    // copy out: bytes up to the first 4-byte boundary of the destination, then dwords, then the tail
+    uint8_t* dst = out + boff;
+    const uint32_t head = (uint32_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u);
+    const uint32_t h = head < total ? head : total;
+    if (threadIdx.x < h) dst[threadIdx.x] = stage[threadIdx.x];
+    const uint32_t n_dw = (total - h) >> 2;
+    const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
+    uint32_t* dst32 = reinterpret_cast<uint32_t*>(dst + h);
+    for (uint32_t d = threadIdx.x; d < n_dw; d += kVT) {
+        const uint32_t byte = h + 4u * d;                  // source byte offset in stage
+        const uint32_t lo = stage32[byte >> 2], hi = stage32[(byte >> 2) + 1];
+        dst32[d] = __builtin_amdgcn_alignbyte(hi, lo, byte & 3u);
+    }
+    const uint32_t done = h + 4u * n_dw;
+    if (threadIdx.x < total - done) dst[done + threadIdx.x] = stage[done + threadIdx.x];
+}
+
+// ---- decode -----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t count_terminators16(const uint32_t (&w)[4]) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c += __builtin_popcount(~w[k] & 0x80808080u);
+    return c;
+}
+
+__device__ __forceinline__ void load16(const uint8_t* __restrict__ bytes, uint64_t n_bytes, uint64_t p, uint32_t (&w)[4]) {
+    if (p + 16 <= n_bytes && ((uintptr_t)(bytes + p) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(bytes + p);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {                                            // ragged tail / unaligned base: bytes beyond the end read as
+#pragma unroll                                          // continuation bytes (0x80) so they are never terminators
+        for (int k = 0; k < 4; ++k) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint64_t q = p + 4 * k + b;
+                x |= (uint32_t)(q < n_bytes ? bytes[q] : 0x80u) << (8 * b);
+            }
+            w[k] = x;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kVT) void varint_count_kernel(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
+                                                           uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t waves[kVT / 64];
+    const uint64_t p = ((uint64_t)blockIdx.x * kVT + threadIdx.x) * kBytes;
+    uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    if (p < n_bytes) load16(bytes, n_bytes, p, w);
+    uint32_t total;
+    (void)block_exscan(count_terminators16(w), waves, &total);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+// status bits
+#define SDA_VARINT_MALFORMED 1u      // more than 10 bytes without a terminator
+#define SDA_VARINT_ROW_COUNT 2u      // a row does not hold exactly `len` values
+#define SDA_VARINT_UNTERMINATED 4u   // a row (or the stream) ends inside a value
+
+__global__ __launch_bounds__(kVT) void varint_decode_kernel(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
+                                                            const uint64_t* __restrict__ block_val_off, uint64_t rows,
+                                                            uint64_t len, uint64_t row_stride,
+                                                            int64_t* __restrict__ out, uint32_t* __restrict__ status) {
+    __shared__ uint32_t waves[kVT / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[16 + kVT * kBytes];
+    const uint64_t block_base = (uint64_t)blockIdx.x * kVT * kBytes;
+    const uint64_t p = block_base + (uint64_t)threadIdx.x * kBytes;
+    uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    if (p < n_bytes) load16(bytes, n_bytes, p, w);
+    uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile32[4 + threadIdx.x * 4 + k] = w[k];
+    if (threadIdx.x < 16) {                                 // halo: the 16 bytes before this workgroup's span
+        const uint64_t q = block_base + threadIdx.x;
+        tile[threadIdx.x] = q >= 16 ? bytes[q - 16] : 0u;   // before the stream: a terminator stops the look-back
+    }
+    uint32_t total;
+    uint32_t idx = block_exscan(count_terminators16(w), waves, &total);   // also orders the tile writes
+    uint64_t g = block_val_off[blockIdx.x] + idx;
+    const uint64_t N = rows * len;
+    uint64_t r = 0, i = 0;
+    bool have_ri = false;
+#pragma unroll
+    for (int k = 0; k < kBytes; ++k) {
+        const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        if (b & 0x80u) continue;
+        const int pos = 16 + threadIdx.x * kBytes + k;      // tile coordinate of the terminator
+        uint64_t acc = b;
+        int nb = 1;
+        for (; nb <= 9; ++nb) {                             // look back over continuation bytes
+            const uint64_t abs_q = p + k;                   // absolute position of the terminator
+            if ((uint64_t)nb > abs_q) break;                // start of stream
+            const uint32_t c = tile[pos - nb];
+            if (!(c & 0x80u)) break;
+            acc = (acc << 7) | (c & 0x7Fu);                 // bytes arrive most-significant first
+        }
+        if (nb == 10 && (p + k) >= 10 && (tile[pos - 10] & 0x80u)) atomicOr(status, SDA_VARINT_MALFORMED);
+        const int64_t v = (int64_t)((acc >> 1) ^ (uint64_t)(-(int64_t)(acc & 1)));
+        if (g < N) {
+            if (!have_ri) { r = g / len; i = g - r * len; have_ri = true; }
+            out[r * row_stride + i] = v;
+            if (++i == len) { i = 0; ++r; }
+        }
+        ++g;
+    }
+}
+
+// one lane per row: the row must end on a terminator and hold exactly `len` values
+__global__ __launch_bounds__(kVT) void varint_rowcheck_kernel(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
+                                                              const uint64_t* __restrict__ offsets, uint64_t rows,
+                                                              uint64_t len, const uint64_t* __restrict__ block_val_off,
+                                                              uint32_t* __restrict__ status) {
+    const uint64_t r = (uint64_t)blockIdx.x * kVT + threadIdx.x;
+    if (r >= rows) return;
+    const uint64_t a = offsets ? offsets[r] : 0, b = offsets ? offsets[r + 1] : n_bytes;
+    if (b < a || b > n_bytes) { atomicOr(status, SDA_VARINT_ROW_COUNT); return; }
+    auto prefix = [&](uint64_t x) {                         // terminators in [0, x)
+        const uint64_t blk = x / (kVT * kBytes);
+        uint64_t c = block_val_off[blk];
+        for (uint64_t q = blk * (kVT * kBytes); q < x; ++q) c += (bytes[q] & 0x80u) ? 0 : 1;
+        return c;
+    };
+    if (len == 0) { if (a != b) atomicOr(status, SDA_VARINT_ROW_COUNT); return; }
+    if (a == b || (bytes[b - 1] & 0x80u)) { atomicOr(status, SDA_VARINT_UNTERMINATED); return; }
+    if (prefix(b) - prefix(a) != len) atomicOr(status, SDA_VARINT_ROW_COUNT);
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+static inline uint64_t vceil(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+size_t varint_encode_blocks(size_t rows, size_t len) { return (size_t)vceil((uint64_t)rows * len, kVT * kVals); }
+size_t varint_decode_blocks(size_t n_bytes) { return (size_t)vceil(n_bytes, kVT * kBytes); }
+
+hipError_t launch_varint_lengths(const VarintRows& R, uint32_t* d_block_bytes, hipStream_t s) {
+    const size_t nb = varint_encode_blocks(R.rows, R.len);
+    if (nb == 0) return hipSuccess;
+    if (nb > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    varint_len_kernel<<<dim3((unsigned)nb), dim3(kVT), 0, s>>>(R, d_block_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_u32(const uint32_t* d_in, uint64_t* d_out, size_t n, uint64_t* d_total, hipStream_t s) {
+    scan_u32_kernel<<<dim3(1), dim3(1024), 0, s>>>(d_in, d_out, n, d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_varint_write(const VarintRows& R, const uint64_t* d_block_off, uint8_t* d_out, uint64_t* d_row_offsets,
+                               hipStream_t s) {
+    const size_t nb = varint_encode_blocks(R.rows, R.len);
+    if (nb == 0) return hipSuccess;
+    varint_write_kernel<<<dim3((unsigned)nb), dim3(kVT), 0, s>>>(R, d_block_off, d_out, d_row_offsets);
+    return hipGetLastError();
+}
+
+hipError_t launch_varint_count(const uint8_t* d_bytes, size_t n_bytes, uint32_t* d_block_counts, hipStream_t s) {
+    const size_t nb = varint_decode_blocks(n_bytes);
+    if (nb == 0) return hipSuccess;
+    if (nb > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    varint_count_kernel<<<dim3((unsigned)nb), dim3(kVT), 0, s>>>(d_bytes, n_bytes, d_block_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_varint_decode(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_block_val_off, size_t rows,
+                                size_t len, size_t row_stride, int64_t* d_out, uint32_t* d_status, hipStream_t s) {
+    const size_t nb = varint_decode_blocks(n_bytes);
+    if (nb == 0) return hipSuccess;
+    varint_decode_kernel<<<dim3((unsigned)nb), dim3(kVT), 0, s>>>(d_bytes, n_bytes, d_block_val_off, rows, len, row_stride,
+                                                                  d_out, d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_varint_rowcheck(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t rows, size_t len,
+                                  const uint64_t* d_block_val_off, uint32_t* d_status, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    varint_rowcheck_kernel<<<dim3((unsigned)vceil(rows, kVT)), dim3(kVT), 0, s>>>(d_bytes, n_bytes, d_offsets, rows, len,
+                                                                                   d_block_val_off, d_status);
+    return hipGetLastError();
+}
+
+}  // namespace sda

@@ -237,3 +237,22 @@ def test_positive_and_errors():
         po.AdditiveSecretSharing(3, 433).generate_for_batch([1, 2], [0, 0])
     assert po.combine([], 433) == [] and po.AdditiveSecretSharing(3, 433).reconstruct([]) == []
     assert po.trunc_rem(-394, 433) == -394 and po.trunc_rem(1 - 400, 433) == -399 and po.trunc_rem(-866, 433) == 0
+
+
+def test_varint_codec_oracle():
+    """integer-encoding 1.0 VarInt for i64 (sodium.rs:39,86): published zig-zag/LEB128 vectors + C == Python."""
+    assert po.varint_encode_i64(0) == b"\x00" and po.varint_encode_i64(-1) == b"\x01"
+    assert po.varint_encode_i64(1) == b"\x02" and po.varint_encode_i64(-2) == b"\x03"
+    assert po.varint_encode_i64(75) == bytes([0x96, 0x01])                      # zigzag(75) = 150: the LEB128 textbook case
+    assert po.varint_encode_i64(2147483647) == bytes([0xfe, 0xff, 0xff, 0xff, 0x0f])       # protobuf sint vectors
+    assert po.varint_encode_i64(-2147483648) == bytes([0xff, 0xff, 0xff, 0xff, 0x0f])
+    assert po.varint_encode_i64(2 ** 63 - 1) == bytes([0xfe] + [0xff] * 8 + [0x01])
+    assert po.varint_encode_i64(-2 ** 63) == bytes([0xff] * 9 + [0x01])
+    rnd = random.Random(4)
+    vals = [rnd.choice([0, 1, -1, 63, 64, -64, -65, P62 - 1, -(1 << 63), (1 << 63) - 1, rnd.randrange(-(1 << 63), 1 << 63),
+                        rnd.randrange(-1000, 1000)]) for _ in range(4000)]
+    enc = po.varint_encode(vals)
+    assert po.varint_decode(enc) == vals
+    assert coracle.varint_encode(vals) == enc and coracle.varint_decode(enc).tolist() == vals
+    assert po.varint_decode(bytes([0x02, 0x80])) == [1, 0]                      # unterminated tail: a partial value
+    assert coracle.varint_decode(bytes([0x02, 0x80])).tolist() == [1, 0]
