@@ -334,6 +334,20 @@ int sda_varint_encode_dev(sda_varint_codec_t* c, const int64_t* d_values, size_t
 int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_row_offsets,
                           size_t rows, size_t len, int64_t* d_values, size_t row_stride, uint32_t* d_status, void* stream);
 
+/* Streaming clerk (fixes the FIXME at client/src/clerk.rs:71-72): feed the opened
+ * sealed-box payloads straight into the accumulating combiner - decode tile -> clerk-sum update ->
+ * discard - instead of materialising all P decoded vectors (clerk.rs:80-86).
+ *   _dev : `rows` encoded vectors in one device byte stream (row r = d_bytes[off[r] .. off[r+1])), each
+ *          must decode to exactly the combiner's dimension; d_status as in sda_varint_decode_dev.
+ *   host : ONE participant's encoded vector; a wrong value count -> SDA_ERR_WRONG_DIMENSION
+ *          ("Wrong dimension", combiner.rs:21), a malformed stream -> SDA_ERR_INVALID_ARGUMENT.
+ * Call sda_share_combiner_begin[_dev] first (jobs == 1) and ..._finish[_dev] at the end. */
+int sda_share_combiner_update_varint_dev(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* d_bytes,
+                                         size_t n_bytes, const uint64_t* d_row_offsets, size_t rows,
+                                         uint32_t* d_status, void* stream);
+int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* bytes,
+                                     size_t n_bytes);
+
 /* =============================================================================================
  * Cross-GPU modular reduction helper (new; no reference counterpart - SURVEY.md 8e).
  * d_parts holds `parts` vectors of `len` canonical residues (part g at d_parts + g*part_stride);

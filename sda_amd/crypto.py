@@ -209,6 +209,16 @@ class ShareCombiner(_Handle):
         check(self._lib.sda_share_combiner_finish(self._h, _ptr(out)))
         return out[:dimension]
 
+    def update_encoded(self, codec: "VarintCodec", raw: bytes) -> None:
+        """one participant's wire-format share vector (the opened sealed-box payload, sodium.rs:83-89)"""
+        b = np.frombuffer(raw, dtype=np.uint8)
+        check(self._lib.sda_share_combiner_update_varint(self._h, codec._h, b.ctypes.data_as(capi.c_u8p), b.size))
+
+    def update_encoded_dev(self, codec: "VarintCodec", d_bytes: int, n_bytes: int, d_row_offsets: int, rows: int,
+                           d_status: int, stream: int = 0) -> None:
+        check(self._lib.sda_share_combiner_update_varint_dev(self._h, codec._h, d_bytes, n_bytes, d_row_offsets or None,
+                                                             rows, d_status, stream or None))
+
     def begin_dev(self, jobs: int, dimension: int, stream: int = 0):
         check(self._lib.sda_share_combiner_begin_dev(self._h, jobs, dimension, stream or None))
 

@@ -1200,6 +1200,46 @@ extern "C" int sda_varint_decode(sda_varint_codec_t* c, const uint8_t* bytes, si
     return SDA_OK;
 }
 
+// streaming clerk: wire-format vectors -> decode tile -> clerk-sum update -> discard (clerk.rs:71-86)
+extern "C" int sda_share_combiner_update_varint_dev(sda_share_combiner_t* c, sda_varint_codec_t* codec,
+                                                    const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_row_offsets,
+                                                    size_t rows, uint32_t* d_status, void* stream) {
+    if (!c || !codec) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (c->jobs != 1) return fail(SDA_ERR_STATE, "the wire-format update works on a single job (begin with jobs == 1)");
+    if (rows == 0) return SDA_OK;
+    const size_t L = c->dimension, stride = L + (L & 1);
+    SDA_TRY(c->ctx.use());
+    SDA_TRY(c->tile.reserve((rows * stride ? rows * stride : 1) * 8));
+    SDA_TRY(sda_varint_decode_dev(codec, d_bytes, n_bytes, d_row_offsets, rows, L, c->tile.as<int64_t>(), stride, d_status, stream));
+    if (L == 0) return SDA_OK;
+    return sda_share_combiner_update_dev(c, c->tile.as<int64_t>(), 0, rows, stride, stream);
+}
+
+extern "C" int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* bytes,
+                                                size_t n_bytes) {
+    if (!c || !codec) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (n_bytes > 0 && !bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    SDA_TRY(c->ctx.use());
+    hipStream_t s = c->ctx.stream;
+    SDA_TRY(codec->d_in.reserve(n_bytes + 16));
+    if (n_bytes) HIP_TRY(hipMemcpyAsync(codec->d_in.p, bytes, n_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(codec->d_status.p, 0, 4, s));
+    // a tile that fails the check must not pollute the running sums: decode first, test, then add
+    const size_t L = c->dimension, stride = L + (L & 1);
+    SDA_TRY(c->tile.reserve((stride ? stride : 1) * 8));
+    SDA_TRY(sda_varint_decode_dev(codec, codec->d_in.as<uint8_t>(), n_bytes, nullptr, 1, L, c->tile.as<int64_t>(), stride,
+                                  codec->d_status.as<uint32_t>(), nullptr));
+    uint32_t status = 0;
+    HIP_TRY(hipMemcpyAsync(&status, codec->d_status.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (status & 2u) return fail(SDA_ERR_WRONG_DIMENSION, "Wrong dimension");                       // combiner.rs:21
+    if (status) return fail(SDA_ERR_INVALID_ARGUMENT, "malformed varint stream (status %u)", status);
+    if (L == 0) return SDA_OK;
+    return sda_share_combiner_update_dev(c, c->tile.as<int64_t>(), 0, 1, stride, nullptr);
+}
+
 // =================================================================================================
 // multi-GPU helper, synthetic input, timing
 // =================================================================================================

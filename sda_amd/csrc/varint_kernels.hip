@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kVT) void varint_decode_kernel(const uint8_t* __res
                                                             uint64_t len, uint64_t row_stride,
                                                             int64_t* __restrict__ out, uint32_t* __restrict__ status) {
     __shared__ uint32_t waves[kVT / 64];
-    __shared__ __attribute__((aligned(16))) uint8_t tile[16 + kVT * kBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[16 + kVT * kBytes + 16];   // halo | span | read slack
     const uint64_t block_base = (uint64_t)blockIdx.x * kVT * kBytes;
     const uint64_t p = block_base + (uint64_t)threadIdx.x * kBytes;
     uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
@@ -220,22 +220,51 @@ __global__ __launch_bounds__(kVT) void varint_decode_kernel(const uint8_t* __res
     const uint64_t N = rows * len;
     uint64_t r = 0, i = 0;
     bool have_ri = false;
+    // continuation-bit map of this lane's 16 bytes (bit k = MSB of byte k) and of the 16 bytes before it
+    uint32_t own = 0;
 #pragma unroll
-    for (int k = 0; k < kBytes; ++k) {
-        const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        if (b & 0x80u) continue;
-        const int pos = 16 + threadIdx.x * kBytes + k;      // tile coordinate of the terminator
-        uint64_t acc = b;
-        int nb = 1;
-        for (; nb <= 9; ++nb) {                             // look back over continuation bytes
-            const uint64_t abs_q = p + k;                   // absolute position of the terminator
-            if ((uint64_t)nb > abs_q) break;                // start of stream
-            const uint32_t c = tile[pos - nb];
-            if (!(c & 0x80u)) break;
-            acc = (acc << 7) | (c & 0x7Fu);                 // bytes arrive most-significant first
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t m = w[k] & 0x80808080u;                      // bits 7,15,23,31 -> 0..3
+        own |= (((m >> 7) | (m >> 14) | (m >> 21) | (m >> 28)) & 0xFu) << (4 * k);
+    }
+    uint32_t prev = 0;
+    {
+        const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile) + threadIdx.x * 4;   // the 16 bytes before
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t m = t32[k] & 0x80808080u;
+            prev |= (((m >> 7) | (m >> 14) | (m >> 21) | (m >> 28)) & 0xFu) << (4 * k);
         }
-        if (nb == 10 && (p + k) >= 10 && (tile[pos - 10] & 0x80u)) atomicOr(status, SDA_VARINT_MALFORMED);
-        const int64_t v = (int64_t)((acc >> 1) ^ (uint64_t)(-(int64_t)(acc & 1)));
+        // (the halo before the start of the stream was filled with terminators, so prev == 0 there)
+    }
+    const uint32_t cont = (own << 16) | prev;                       // 32-byte window, bit q = byte q continues
+    uint32_t terms = ~own & 0xFFFFu;
+    if (p + 16 > n_bytes) terms &= p < n_bytes ? (1u << (uint32_t)(n_bytes - p)) - 1u : 0u;
+    while (terms) {
+        const int k = __builtin_ctz(terms);
+        terms &= terms - 1;
+        const int e = 16 + k;                                       // window position of the terminator
+        // previous non-continuation byte below e: the value starts right after it
+        const uint32_t below = ~cont & ((1u << e) - 1u);
+        const int prev_term = below ? 31 - __builtin_clz(below) : -1;
+        int nb = e - prev_term;                                     // bytes of this value
+        if (nb > 10) { atomicOr(status, SDA_VARINT_MALFORMED); nb = 10; }
+        const int start = 16 + (int)threadIdx.x * kBytes + k - (nb - 1);   // tile coordinate of the first byte
+        // 12 bytes from the tile at an arbitrary byte offset
+        const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile) + (start >> 2);
+        const uint32_t sh = (uint32_t)start & 3u;
+        const uint32_t d0 = __builtin_amdgcn_alignbyte(t32[1], t32[0], sh);
+        const uint32_t d1 = __builtin_amdgcn_alignbyte(t32[2], t32[1], sh);
+        const uint32_t d2 = __builtin_amdgcn_alignbyte(t32[3], t32[2], sh);
+        uint64_t x = ((uint64_t)d1 << 32) | d0;                     // bytes 0..7 of the value
+        if (nb < 8) x &= (1ull << (8 * nb)) - 1ull;
+        x &= 0x7F7F7F7F7F7F7F7Full;                                 // drop the continuation bits, then squeeze
+        x = ((x & 0x7F007F007F007F00ull) >> 1) | (x & 0x007F007F007F007Full);
+        x = ((x & 0x3FFF00003FFF0000ull) >> 2) | (x & 0x00003FFF00003FFFull);
+        x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);
+        if (nb > 8) x |= (uint64_t)(d2 & 0x7Fu) << 56;
+        if (nb > 9) x |= (uint64_t)((d2 >> 8) & 0x7Fu) << 63;
+        const int64_t v = (int64_t)((x >> 1) ^ (uint64_t)(-(int64_t)(x & 1)));
         if (g < N) {
             if (!have_ri) { r = g / len; i = g - r * len; have_ri = true; }
             out[r * row_stride + i] = v;
@@ -245,24 +274,44 @@ __global__ __launch_bounds__(kVT) void varint_decode_kernel(const uint8_t* __res
     }
 }
 
-// one lane per row: the row must end on a terminator and hold exactly `len` values
+// terminators in [block start, x) counted by a whole wave: 64 lanes x 16 B per step
+__device__ __forceinline__ uint64_t wave_prefix(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
+                                                const uint64_t* __restrict__ block_val_off, uint64_t x) {
+    const uint64_t blk = x / (kVT * kBytes);
+    const uint64_t base = blk * (kVT * kBytes);
+    const int lane = threadIdx.x & 63;
+    uint32_t c = 0;
+    for (uint64_t q = base + (uint64_t)lane * 16; q < x; q += 64 * 16) {
+        uint32_t w[4];
+        load16(bytes, n_bytes, q, w);
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t m = ~w[k] & 0x80808080u;
+            t |= (((m >> 7) | (m >> 14) | (m >> 21) | (m >> 28)) & 0xFu) << (4 * k);
+        }
+        if (q + 16 > x) t &= (1u << (uint32_t)(x - q)) - 1u;
+        c += __builtin_popcount(t);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    return block_val_off[blk] + c;
+}
+
+// one WAVE per row: the row must end on a terminator and hold exactly `len` values
 __global__ __launch_bounds__(kVT) void varint_rowcheck_kernel(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
                                                               const uint64_t* __restrict__ offsets, uint64_t rows,
                                                               uint64_t len, const uint64_t* __restrict__ block_val_off,
                                                               uint32_t* __restrict__ status) {
-    const uint64_t r = (uint64_t)blockIdx.x * kVT + threadIdx.x;
+    const uint64_t r = (uint64_t)blockIdx.x * (kVT / 64) + (threadIdx.x >> 6);
     if (r >= rows) return;
+    const bool lead = (threadIdx.x & 63) == 0;
     const uint64_t a = offsets ? offsets[r] : 0, b = offsets ? offsets[r + 1] : n_bytes;
-    if (b < a || b > n_bytes) { atomicOr(status, SDA_VARINT_ROW_COUNT); return; }
-    auto prefix = [&](uint64_t x) {                         // terminators in [0, x)
-        const uint64_t blk = x / (kVT * kBytes);
-        uint64_t c = block_val_off[blk];
-        for (uint64_t q = blk * (kVT * kBytes); q < x; ++q) c += (bytes[q] & 0x80u) ? 0 : 1;
-        return c;
-    };
-    if (len == 0) { if (a != b) atomicOr(status, SDA_VARINT_ROW_COUNT); return; }
-    if (a == b || (bytes[b - 1] & 0x80u)) { atomicOr(status, SDA_VARINT_UNTERMINATED); return; }
-    if (prefix(b) - prefix(a) != len) atomicOr(status, SDA_VARINT_ROW_COUNT);
+    if (b < a || b > n_bytes) { if (lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return; }
+    if (len == 0) { if (a != b && lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return; }
+    if (a == b || (bytes[b - 1] & 0x80u)) { if (lead) atomicOr(status, SDA_VARINT_UNTERMINATED); return; }
+    const uint64_t cnt = wave_prefix(bytes, n_bytes, block_val_off, b) - wave_prefix(bytes, n_bytes, block_val_off, a);
+    if (cnt != len && lead) atomicOr(status, SDA_VARINT_ROW_COUNT);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
@@ -312,7 +361,7 @@ hipError_t launch_varint_decode(const uint8_t* d_bytes, size_t n_bytes, const ui
 hipError_t launch_varint_rowcheck(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t rows, size_t len,
                                   const uint64_t* d_block_val_off, uint32_t* d_status, hipStream_t s) {
     if (rows == 0) return hipSuccess;
-    varint_rowcheck_kernel<<<dim3((unsigned)vceil(rows, kVT)), dim3(kVT), 0, s>>>(d_bytes, n_bytes, d_offsets, rows, len,
+    varint_rowcheck_kernel<<<dim3((unsigned)vceil(rows, kVT / 64)), dim3(kVT), 0, s>>>(d_bytes, n_bytes, d_offsets, rows, len,
                                                                                    d_block_val_off, d_status);
     return hipGetLastError();
 }

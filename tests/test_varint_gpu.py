@@ -119,3 +119,48 @@ def test_device_rows_roundtrip_feeds_the_combiner(gpu):
     d_status.zero()
     codec.decode_dev(d_bytes.ptr, total, d_off.ptr, rows, L - 1, d_dec.ptr, stride2, d_status.ptr)
     assert d_status.to_numpy()[0] & 2
+
+
+def test_streaming_clerk_over_wire_format(gpu):
+    """clerk.rs:78-86 without materialising the decoded vectors: every participation's opened payload goes
+    decode -> clerk-sum update -> discard; equals the reference flow decode-all-then-combine."""
+    from sda_amd import capi, crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle, pyoracle as po
+    rng = np.random.default_rng(21)
+    P, L = 19, 1237
+    q = 433
+    shares = rng.integers(-(q - 1), q, size=(P, L), dtype=np.int64)           # the reference's (-q, q) shares
+    payloads = [po.varint_encode(row.tolist()) for row in shares]             # what ShareEncryptor seals
+    codec = crypto.VarintCodec()
+    comb = crypto.ShareCombiner(crypto.Additive(3, q))
+    comb.begin(L)
+    for raw in payloads:
+        comb.update_encoded(codec, raw)
+    got = comb.finish(L)
+    want = po.combine([po.varint_decode(raw) for raw in payloads], q, "rust_signed")
+    assert got.tolist() == [v % q for v in want]
+    assert np.array_equal(got, coracle.combine(q, shares))
+    # a payload of the wrong length is refused like the reference's combiner ("Wrong dimension") and leaves
+    # the running sums untouched
+    comb.begin(L)
+    comb.update_encoded(codec, payloads[0])
+    with pytest.raises(capi.SdaError) as e:
+        comb.update_encoded(codec, po.varint_encode(shares[1][:-1].tolist()))
+    assert e.value.code == capi.ERR_WRONG_DIMENSION and "Wrong dimension" in e.value.message
+    with pytest.raises(capi.SdaError):
+        comb.update_encoded(codec, payloads[2][:-1] + b"\x80")
+    assert np.array_equal(comb.finish(L), np.mod(shares[0], q))
+    # device-resident batch form
+    big = rng.integers(0, P62, size=(64, 4001), dtype=np.int64)
+    raw = b"".join(coracle.varint_encode(r) for r in big)
+    offs = np.cumsum([0] + [len(coracle.varint_encode(r)) for r in big]).astype(np.int64)
+    d_bytes = DeviceBuffer.from_numpy(np.frombuffer(raw + b"\0" * (-len(raw) % 8), dtype=np.int64))
+    d_off = DeviceBuffer.from_numpy(offs)
+    st = DeviceBuffer(1).zero()
+    c2 = crypto.ShareCombiner(crypto.Additive(3, P62))
+    c2.begin_dev(1, 4001)
+    c2.update_encoded_dev(codec, d_bytes.ptr, len(raw), d_off.ptr, 64, st.ptr)
+    out = DeviceBuffer(4001)
+    c2.finish_dev(out.ptr)
+    assert st.to_numpy()[0] == 0 and np.array_equal(out.to_numpy(), coracle.combine(P62, big))

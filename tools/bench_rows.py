@@ -71,4 +71,34 @@ capi.check(lib.sda_fill_synthetic_dev(d.ptr, parts, L, L, 0, 5, P62, None))
 o = DeviceBuffer(L)
 dt = timed(lambda: capi.check(lib.sda_modsum_parts_dev(P62, d.ptr, parts, L, L, o.ptr, None)))
 out["modsum_parts_8x358MB"] = {"ms": dt * 1e3, "GBps_algorithmic": (parts + 1) * L * 8 / dt / 1e9}
+del d, o
+
+# 8f rank 1: wire codec on one clerk job tile: 2000 participants x L = 349526 canonical 62-bit shares
+rows, L, stride = 2000, 349526, 349536
+vals = DeviceBuffer(rows * stride)
+capi.check(lib.sda_fill_synthetic_dev(vals.ptr, rows, stride, stride, 0, 9, P62, None))
+codec = crypto.VarintCodec()
+cap = rows * L * 10
+d_bytes = DeviceBuffer((cap + 7) // 8)
+d_off = DeviceBuffer(rows + 1)
+total = [0]
+def enc():
+    total[0] = codec.encode_dev(vals.ptr, rows, L, stride, d_bytes.ptr, cap, d_off.ptr)
+dt = timed(enc, reps=3)
+nv = rows * L
+out["varint_encode_2000x349526"] = {"ms": dt * 1e3, "values_per_s": nv / dt, "wire_bytes": total[0],
+                                    "GBps_algorithmic": (nv * 8 + total[0]) / dt / 1e9}
+dec = DeviceBuffer(rows * stride)
+st = DeviceBuffer(1).zero()
+dt = timed(lambda: codec.decode_dev(d_bytes.ptr, total[0], d_off.ptr, rows, L, dec.ptr, stride, st.ptr), reps=3)
+assert st.to_numpy()[0] == 0
+out["varint_decode_2000x349526"] = {"ms": dt * 1e3, "values_per_s": nv / dt,
+                                    "GBps_algorithmic": (nv * 8 + total[0]) / dt / 1e9}
+comb = crypto.ShareCombiner(crypto.Additive(3, P62))
+o2 = DeviceBuffer(L)
+def dec_comb():
+    codec.decode_dev(d_bytes.ptr, total[0], d_off.ptr, rows, L, dec.ptr, stride, st.ptr)
+    comb.begin_dev(1, L); comb.update_dev(dec.ptr, 0, rows, stride); comb.finish_dev(o2.ptr)
+dt = timed(dec_comb, reps=3)
+out["varint_decode_then_clerk_sum_2000x349526"] = {"ms": dt * 1e3, "values_per_s": nv / dt}
 print(json.dumps(out, indent=1))
