@@ -745,8 +745,25 @@ __global__ __launch_bounds__(kThreads) void modsum_parts_kernel(const int64_t* _
 // =================================================================================================
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+// HIP limits a launch to < 2^32 work-items per grid dimension
+static constexpr uint64_t kMaxBlocks = (0xFFFFFFFFull / kThreads);
 static inline hipError_t grid_check(uint64_t blocks) {
-    return blocks > 0x7FFFFFFFull ? hipErrorInvalidConfiguration : hipSuccess;
+    return blocks > kMaxBlocks ? hipErrorInvalidConfiguration : hipSuccess;
+}
+// (participant, chunk)-indexed kernels are launched in slices of participants that respect the limit
+static inline uint64_t participants_per_launch(uint64_t chunks, uint64_t participants) {
+    if (chunks == 0 || chunks > kMaxBlocks) return 0;
+    const uint64_t m = kMaxBlocks / chunks;
+    return m < participants ? m : participants;
+}
+static inline GenLayout slice(const GenLayout& L, uint64_t p0, uint64_t count) {
+    GenLayout S = L;
+    S.secrets = L.secrets + p0 * L.secrets_stride;
+    if (L.rand) S.rand = L.rand + p0 * L.rand_stride;
+    S.out = L.out + p0 * L.out_stride_participant;
+    S.participants = count;
+    S.first_participant = L.first_participant + p0;
+    return S;
 }
 
 static bool gen_vec_ok(const GenLayout& L, size_t secrets_per_lane_even) {
@@ -759,14 +776,18 @@ template <int ROUNDS>
 static hipError_t additive_launch_r(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key,
                                     hipStream_t s) {
     const uint64_t chunks = ceil_div(ceil_div(L.len, 2), kThreads);
-    const uint64_t blocks = chunks * L.participants;
-    if (blocks == 0) return hipSuccess;
-    if (hipError_t e = grid_check(blocks)) return e;
-    if (gen_vec_ok(L, 0))
-        additive_gen_kernel<ROUNDS, true><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, key, chunks);
-    else
-        additive_gen_kernel<ROUNDS, false><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, key, chunks);
-    return hipGetLastError();
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    const bool vec = gen_vec_ok(L, 0);
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        const unsigned blocks = (unsigned)(chunks * S.participants);
+        if (vec) additive_gen_kernel<ROUNDS, true><<<dim3(blocks), dim3(kThreads), 0, s>>>(S, n, mod, key, chunks);
+        else additive_gen_kernel<ROUNDS, false><<<dim3(blocks), dim3(kThreads), 0, s>>>(S, n, mod, key, chunks);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_additive_generate(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key,
@@ -796,16 +817,18 @@ static hipError_t packed_launch_kt(const GenLayout& L, uint32_t n, const ModPara
                                    const MatArg& M, const DrbgKey& key, hipStream_t s) {
     const uint64_t batches = ceil_div(L.len, K);
     const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
-    const uint64_t blocks = chunks * L.participants;
-    if (blocks == 0) return hipSuccess;
-    if (hipError_t e = grid_check(blocks)) return e;
-    if (gen_vec_ok(L, 0))
-        packed_gen_kernel<K, T, ROUNDS, true><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, mont, M, key,
-                                                                                                 chunks, batches);
-    else
-        packed_gen_kernel<K, T, ROUNDS, false><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, mont, M, key,
-                                                                                                  chunks, batches);
-    return hipGetLastError();
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    const bool vec = gen_vec_ok(L, 0);
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        const unsigned blocks = (unsigned)(chunks * S.participants);
+        if (vec) packed_gen_kernel<K, T, ROUNDS, true><<<dim3(blocks), dim3(kThreads), 0, s>>>(S, n, mod, mont, M, key, chunks, batches);
+        else packed_gen_kernel<K, T, ROUNDS, false><<<dim3(blocks), dim3(kThreads), 0, s>>>(S, n, mod, mont, M, key, chunks, batches);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
 }
 
 template <int ROUNDS>
@@ -844,16 +867,18 @@ static hipError_t packed_l31_launch_kt(const GenLayout& L, uint32_t n, const Mod
                                        const MatArg& M, const DrbgKey& key, hipStream_t s) {
     const uint64_t batches = ceil_div(L.len, K);
     const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
-    const uint64_t blocks = chunks * L.participants;
-    if (blocks == 0) return hipSuccess;
-    if (hipError_t e = grid_check(blocks)) return e;
-    if (gen_vec_ok(L, 0))
-        packed_gen_l31_kernel<K, T, ROUNDS, true><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, lp, M, key,
-                                                                                                     chunks, batches);
-    else
-        packed_gen_l31_kernel<K, T, ROUNDS, false><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, mod, lp, M, key,
-                                                                                                      chunks, batches);
-    return hipGetLastError();
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    const bool vec = gen_vec_ok(L, 0);
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        const unsigned blocks = (unsigned)(chunks * S.participants);
+        if (vec) packed_gen_l31_kernel<K, T, ROUNDS, true><<<dim3(blocks), dim3(kThreads), 0, s>>>(S, n, mod, lp, M, key, chunks, batches);
+        else packed_gen_l31_kernel<K, T, ROUNDS, false><<<dim3(blocks), dim3(kThreads), 0, s>>>(S, n, mod, lp, M, key, chunks, batches);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
 }
 
 template <int ROUNDS>
@@ -882,28 +907,43 @@ hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32
     if (!L.rand && t > 0) return hipErrorInvalidValue;
     const uint64_t batches = ceil_div(L.len, k);
     const uint64_t chunks = ceil_div(batches, kThreads);
-    const uint64_t blocks = chunks * L.participants;
-    if (blocks == 0) return hipSuccess;
-    if (hipError_t e = grid_check(blocks)) return e;
-    packed_gen_generic_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(L, n, k, t, mod, mont, d_Mmont, chunks,
-                                                                                batches);
-    return hipGetLastError();
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        packed_gen_generic_kernel<<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(S, n, k, t, mod, mont,
+                                                                                                       d_Mmont, chunks, batches);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
+template <int ROUNDS>
+static hipError_t drbg_fill_r(int64_t* d_out, size_t stride, size_t participants, size_t batches, uint32_t T,
+                              uint64_t first_participant, const ModParams& mod, const DrbgKey& key, hipStream_t s) {
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    if (chunks * participants == 0 || T == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (uint64_t p0 = 0; p0 < participants; p0 += per) {
+        const uint64_t cnt = per < participants - p0 ? per : participants - p0;
+        drbg_fill_kernel<ROUNDS><<<dim3((unsigned)(chunks * cnt)), dim3(kThreads), 0, s>>>(d_out + p0 * stride, stride, batches, T,
+                                                                                           first_participant + p0, mod, key, chunks);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_drbg_fill(int64_t* d_out, size_t stride, size_t participants, size_t batches, uint32_t T,
                             uint64_t first_participant, const ModParams& mod, const DrbgKey& key, int rounds,
                             hipStream_t s) {
-    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
-    const uint64_t blocks = chunks * participants;
-    if (blocks == 0 || T == 0) return hipSuccess;
-    if (hipError_t e = grid_check(blocks)) return e;
     switch (rounds) {
-        case 20: drbg_fill_kernel<20><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_out, stride, batches, T, first_participant, mod, key, chunks); break;
-        case 12: drbg_fill_kernel<12><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_out, stride, batches, T, first_participant, mod, key, chunks); break;
-        case 8: drbg_fill_kernel<8><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_out, stride, batches, T, first_participant, mod, key, chunks); break;
+        case 20: return drbg_fill_r<20>(d_out, stride, participants, batches, T, first_participant, mod, key, s);
+        case 12: return drbg_fill_r<12>(d_out, stride, participants, batches, T, first_participant, mod, key, s);
+        case 8: return drbg_fill_r<8>(d_out, stride, participants, batches, T, first_participant, mod, key, s);
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const int64_t* d_shares, size_t jobs,
@@ -1018,12 +1058,16 @@ hipError_t launch_modsum_parts(const int64_t* d_parts, size_t parts, size_t part
 hipError_t launch_fill_synthetic(int64_t* d_out, size_t participants, size_t len, size_t stride,
                                  uint64_t first_participant, uint64_t seed, const ModParams& mod, hipStream_t s) {
     const uint64_t chunks = ceil_div(len, kThreads);
-    const uint64_t blocks = chunks * participants;
-    if (blocks == 0) return hipSuccess;
-    if (hipError_t e = grid_check(blocks)) return e;
-    fill_synthetic_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_out, len, stride, first_participant, seed,
-                                                                            mod, chunks);
-    return hipGetLastError();
+    if (chunks * participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (uint64_t p0 = 0; p0 < participants; p0 += per) {
+        const uint64_t cnt = per < participants - p0 ? per : participants - p0;
+        fill_synthetic_kernel<<<dim3((unsigned)(chunks * cnt)), dim3(kThreads), 0, s>>>(d_out + p0 * stride, len, stride,
+                                                                                        first_participant + p0, seed, mod, chunks);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace sda

@@ -323,7 +323,7 @@ size_t varint_decode_blocks(size_t n_bytes) { return (size_t)vceil(n_bytes, kVT 
 hipError_t launch_varint_lengths(const VarintRows& R, uint32_t* d_block_bytes, hipStream_t s) {
     const size_t nb = varint_encode_blocks(R.rows, R.len);
     if (nb == 0) return hipSuccess;
-    if (nb > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    if (nb > 0xFFFFFFFFull / kVT) return hipErrorInvalidConfiguration;   // < 2^32 work-items per launch
     varint_len_kernel<<<dim3((unsigned)nb), dim3(kVT), 0, s>>>(R, d_block_bytes);
     return hipGetLastError();
 }
@@ -344,7 +344,7 @@ hipError_t launch_varint_write(const VarintRows& R, const uint64_t* d_block_off,
 hipError_t launch_varint_count(const uint8_t* d_bytes, size_t n_bytes, uint32_t* d_block_counts, hipStream_t s) {
     const size_t nb = varint_decode_blocks(n_bytes);
     if (nb == 0) return hipSuccess;
-    if (nb > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    if (nb > 0xFFFFFFFFull / kVT) return hipErrorInvalidConfiguration;
     varint_count_kernel<<<dim3((unsigned)nb), dim3(kVT), 0, s>>>(d_bytes, n_bytes, d_block_counts);
     return hipGetLastError();
 }

@@ -520,3 +520,24 @@ def test_bench_under_torchrun_single_rank_rccl(gpu):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["verified_reconstruct_equals_sum"] is True
     assert d["roofline"]["bound"] == "hbm" and d["value"] > 0
+
+
+def test_launch_slicing_over_the_grid_limit(gpu):
+    """(participant, chunk) grids beyond HIP's 2^32 work-items per launch are issued in participant slices;
+    results must not depend on the slicing (checked against the oracle on sampled participants)."""
+    from sda_amd import crypto
+    from sda_amd.capi import check
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    # additive, n = 1: share = secret mod q.  1024 workgroups per participant x 18000 participants =
+    # 18.4 M workgroups > 2^24 (and twice that for the fill kernel), forcing several slices.  2 x 75 GB of HBM.
+    P, dim = 18_000, 1 << 19
+    gen = crypto.ShareGenerator(crypto.Additive(1, P62))
+    secrets = DeviceBuffer(P * dim)
+    check(gpu.sda_fill_synthetic_dev(secrets.ptr, P, dim, dim, 5, 11, P62, None))      # sliced too
+    out = DeviceBuffer(P * dim)
+    gen.generate_batch_dev(secrets.ptr, P, dim, dim, out.ptr, dim, P * dim, first_participant=5)
+    for p in (0, 8_191, 8_192, 16_383, 16_384, P - 1):
+        want = coracle.fill_synthetic(1, dim, 5 + p, 11, P62)[0]
+        assert np.array_equal(secrets.to_numpy(dim, p * dim), want)
+        assert np.array_equal(out.to_numpy(dim, p * dim), want)
