@@ -2,12 +2,13 @@
 """bench.py - share-gen + clerk-sum elements/sec (mod q) on MI355X, the metric of BASELINE.json.
 
 One "step" = one pass of the hot path over one tile of synthetic participants resident in HBM:
-  share generation (device CSPRNG)  ->  shares materialised in HBM, job-major [n][P_tile][B]
+  share generation (device CSPRNG)  ->  shares materialised in HBM, job-major [n][P_tile][Bs]
   per-clerk modular sum             ->  exact 128-bit accumulators [n][B]
 An *element* is one (participant, vector component) pair, so a step processes P_tile * dim elements.
 Default workload = BASELINE config 3 (configs[2]): packed Shamir t=1, k=3, n=8, dim 1,048,576, 62-bit
 prime, 100k participants = 50 steps of a 2000-participant tile (the configuration the north-star
-target is quoted on).  `--workload additive` = config 2 (configs[1]).
+target is quoted on).  `--workload additive` = config 2 (configs[1]); at N=1 a short run of it is
+attached to the JSON line as `additional_workloads`.
 
 N > 1: one process per GPU (torchrun), participants sharded across ranks (weak scaling: the per-GPU
 tile is fixed), no collective on the data path, ONE modular reduce of the partial clerk sums over
@@ -34,13 +35,14 @@ KEY = bytes((i * 7 + 1) & 0xFF for i in range(32))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (scheme kind, n, k, t, omega_secrets order, omega_shares order, total participants, description)
     "packed": dict(kind="packed", n=8, k=3, t=1, o2=8, o3=9, participants=100_000,
                    desc="BASELINE config 3: packed Shamir t=1 k=3 n=8, dim 1048576, 62-bit prime, 100k participants"),
     "packed_ref": dict(kind="packed", n=8, k=3, t=4, o2=8, o3=9, participants=100_000,
                        desc="reference-valid tss shape t=4 k=3 n=8 (t+k+1 = 8), dim 1048576, 62-bit prime"),
     "packed26": dict(kind="packed", n=26, k=8, t=2, o2=16, o3=27, participants=1_000_000,
                      desc="BASELINE config 4 shape: packed Shamir t=2 k=8 n=26, dim 1048576, 62-bit prime"),
+    "packed26_ref": dict(kind="packed", n=26, k=8, t=7, o2=16, o3=27, participants=1_000_000,
+                         desc="reference-valid tss shape t=7 k=8 n=26 (t+k+1 = 16, n+1 = 27), dim 1048576"),
     "additive": dict(kind="additive", n=3, k=1, t=2, o2=8, o3=9, participants=10_000,
                      desc="BASELINE config 2: additive 3-way, dim 1048576, 62-bit modulus, 10k participants"),
 }
@@ -48,9 +50,7 @@ WORKLOADS = {
 
 def algorithmic_bytes_per_element(n, k):
     """share-gen reads 8 B (secret) and writes 8n/k B; clerk-sum reads 8n/k B."""
-    gen = 8.0 + 8.0 * n / k
-    comb = 8.0 * n / k
-    return gen, comb
+    return 8.0 + 8.0 * n / k, 8.0 * n / k
 
 
 def cpu_baseline(w, dim, budget_s=15.0):
@@ -58,13 +58,13 @@ def cpu_baseline(w, dim, budget_s=15.0):
     reference, on a bounded sample of the same workload.  Reported, never the thing shipped."""
     from oracle import coracle
     packed = 1 if w["kind"] == "packed" else 0
-    args = (packed, P62, w["n"], w["k"], w["t"], OMEGA[w["o2"]], OMEGA[w["o3"]])
+    a = (packed, P62, w["n"], w["k"], w["t"], OMEGA[w["o2"]], OMEGA[w["o3"]])
     t0 = time.perf_counter()
-    coracle.baseline_pass(*args, 1, dim, 0, SEED, KEY)
+    coracle.baseline_pass(*a, 1, dim, 0, SEED, KEY)
     one = time.perf_counter() - t0
     parts = max(1, min(1024, int(budget_s / max(one, 1e-3))))
     t0 = time.perf_counter()
-    done, _ = coracle.baseline_pass(*args, parts, dim, 0, SEED, KEY)
+    done, _ = coracle.baseline_pass(*a, parts, dim, 0, SEED, KEY)
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "elements/s", "cores": 1, "kind": "port",
             "sample": f"{parts} participants x dim {dim} (share-gen incl. buffered ChaCha20 draws + clerk-sum), "
@@ -72,61 +72,60 @@ def cpu_baseline(w, dim, budget_s=15.0):
             "host_cpus": os.cpu_count()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="packed", choices=sorted(WORKLOADS))
-    ap.add_argument("--dim", type=int, default=1 << 20)
-    ap.add_argument("--tile", type=int, default=2000, help="participants per step and per GPU")
-    ap.add_argument("--row-align", type=int, default=16, help="pad share rows to a multiple of this many elements")
-    ap.add_argument("--overlap", type=int, default=0,
-                    help="1: share-gen of tile i+1 runs concurrently with clerk-sum of tile i (two streams, "
-                         "double-buffered shares); 0: one stream, strictly serial")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
-    args = ap.parse_args()
+class Env:
+    """process-wide state: device, distributed group, library"""
 
-    import torch
-    import torch.distributed as dist
-    from sda_amd import capi, crypto
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        from sda_amd import capi
+        self.torch, self.dist, self.capi = torch, dist, capi
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=self.dev)
+        self.lib = capi.load()
+        capi.check(self.lib.sda_set_device(self.local_rank))
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+
+def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=True):
+    """K timed steps of workload `name`; returns the metric dict (valid on every rank)."""
+    torch, dist, capi, lib, dev = env.torch, env.dist, env.capi, env.lib, env.dev
+    from sda_amd import crypto
     from sda_amd.distributed import modular_allreduce
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # launched by torch.distributed.run
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-    lib = capi.load()
-    capi.check(lib.sda_set_device(local_rank))
-
-    w = WORKLOADS[args.workload]
-    n, k, t, dim, P = w["n"], w["k"], w["t"], args.dim, args.tile
+    rank, world = env.rank, env.world
+    w = WORKLOADS[name]
+    n, k, t = w["n"], w["k"], w["t"]
     if w["kind"] == "packed":
         scheme = crypto.PackedShamir(k, n, t, P62, OMEGA[w["o2"]], OMEGA[w["o3"]])
     else:
         scheme = crypto.Additive(n, P62)
     B = (dim + k - 1) // k
-    Bs = (B + args.row_align - 1) // args.row_align * args.row_align
+    Bs = (B + row_align - 1) // row_align * row_align      # 128-byte aligned rows (row_align = 16 elements)
 
     gen = crypto.ShareGenerator(scheme)
     gen.set_drbg_key(KEY)
     comb = crypto.ShareCombiner(scheme)
+    if overlap:
+        comb.set_residency(2)            # 8 waves per CU saturate HBM; the rest stay with share generation
 
     # resident tile: secrets [P][dim], shares job-major [n][P][Bs]  (server snapshot layout, stores.rs:86-101)
-    nbuf = 2 if args.overlap else 1
+    nbuf = 2 if overlap else 1
     secrets = torch.empty((P, dim), dtype=torch.int64, device=dev)
     shares = [torch.empty((n, P, Bs), dtype=torch.int64, device=dev) for _ in range(nbuf)]
-    if args.overlap:
+    if overlap:
         s_gen, s_comb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     else:
         s_gen = s_comb = torch.cuda.current_stream(dev)
@@ -141,31 +140,28 @@ def main():
         """share-gen of tile i into shares[slot] on s_gen; clerk-sum of it on s_comb"""
         first = (i * world + rank) * P                      # participant ids of this tile (CSPRNG stream ids)
         buf = shares[slot]
-        s_gen.wait_event(comb_done[slot])                   # the previous reader of this buffer is done
+        if overlap:
+            s_gen.wait_event(comb_done[slot])               # the previous reader of this buffer is done
         if evs:
             capi.check(lib.sda_event_record(evs[0], h_gen))
         gen.generate_batch_dev(secrets.data_ptr(), P, dim, dim, buf.data_ptr(), Bs, P * Bs,
                                first_participant=first, stream=h_gen or 0)
         if evs:
             capi.check(lib.sda_event_record(evs[1], h_gen))
-        gen_done[slot].record(s_gen)
-        s_comb.wait_event(gen_done[slot])
+        if overlap:
+            gen_done[slot].record(s_gen)
+            s_comb.wait_event(gen_done[slot])
         if evs:
             capi.check(lib.sda_event_record(evs[2], h_comb))
         comb.update_dev(buf.data_ptr(), P * Bs, P, Bs, stream=h_comb or 0)
         if evs:
             capi.check(lib.sda_event_record(evs[3], h_comb))
-        comb_done[slot].record(s_comb)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        if overlap:
+            comb_done[slot].record(s_comb)
 
     for e in comb_done:
         e.record(s_comb)
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(-1 - i, i % nbuf)
     torch.cuda.synchronize(dev)
     comb.begin_dev(n, B, h_comb or 0)                       # discard the warm-up contributions
@@ -174,106 +170,139 @@ def main():
 
     # per-kernel HIP events on the streams the kernels are launched on (4 per step)
     evs = []
-    for _ in range(4 * args.steps):
+    for _ in range(4 * steps):
         e = C.c_void_p()
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
 
     sums = torch.empty((n, B), dtype=torch.int64, device=dev)
-    barrier()
+    env.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i, i % nbuf, evs[4 * i:4 * i + 4])
     comb.finish_dev(sums.data_ptr(), h_comb or 0)
     with torch.cuda.stream(s_comb):
-        total = modular_allreduce(sums, P62) if use_dist else sums     # X1: the only exchange step
-    barrier()
+        total = modular_allreduce(sums, P62) if env.use_dist else sums     # X1: the only exchange step
+    env.barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
+    if env.use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    stream = None
 
     gen_ms = comb_ms = 0.0
     ms = C.c_float()
-    for i in range(args.steps):
+    for i in range(steps):
         capi.check(lib.sda_event_elapsed_ms(evs[4 * i], evs[4 * i + 1], C.byref(ms))); gen_ms += ms.value
         capi.check(lib.sda_event_elapsed_ms(evs[4 * i + 2], evs[4 * i + 3], C.byref(ms))); comb_ms += ms.value
-    gen_ms /= args.steps
-    comb_ms /= args.steps
+    gen_ms /= steps
+    comb_ms /= steps
     for e in evs:
         lib.sda_event_destroy(e)
 
     # size-independent check of the full result: reconstruct(clerk sums) == K * world * (sum of the tile's
     # secrets) mod p -- every step re-shares the same resident tile with fresh randomness
     verified = None
-    if not args.no_verify:
+    if verify:
         rec = crypto.SecretReconstructor(scheme, dim)
         out = torch.empty(dim, dtype=torch.int64, device=dev)
         idx = list(range(scheme.reconstruction_threshold()))
         rows = total[:len(idx)].contiguous()
-        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim, stream=stream or 0)
-        # expected: sum over ranks and steps of the column sums of each rank's secrets tile
-        cs = crypto.ShareCombiner(crypto.Additive(2, P62))
-        cs.begin_dev(1, dim, stream or 0)
-        for _ in range(args.steps):
-            cs.update_dev(secrets.data_ptr(), 0, P, dim, stream=stream or 0)
+        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim)
+        cs = crypto.ShareCombiner(crypto.Additive(2, P62))   # expected: column sums of the secrets tile, K times
+        cs.begin_dev(1, dim)
+        for _ in range(steps):
+            cs.update_dev(secrets.data_ptr(), 0, P, dim)
         exp = torch.empty(dim, dtype=torch.int64, device=dev)
-        cs.finish_dev(exp.data_ptr(), stream or 0)
-        exp_total = modular_allreduce(exp, P62) if use_dist else exp
+        cs.finish_dev(exp.data_ptr())
+        exp_total = modular_allreduce(exp, P62) if env.use_dist else exp
         torch.cuda.synchronize(dev)
         verified = bool(torch.equal(out, exp_total))
 
-    if rank == 0:
-        elements = float(world) * args.steps * P * dim
-        value = elements / dt
-        gen_b, comb_b = algorithmic_bytes_per_element(n, k)
-        per_launch = P * dim
-        gen_gbs = per_launch * gen_b / (gen_ms * 1e-3) / 1e9
-        comb_gbs = per_launch * comb_b / (comb_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}:tile{P}:dim{dim}", {}).get("gen_bytes_per_launch")
-            except Exception:
-                traffic = None
-        dominant_gen = gen_ms >= comb_ms
-        line = {
-            "metric": "share-gen + clerk-sum elements/sec (mod q)", "value": value, "unit": "elements/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": w["desc"], "name": args.workload, "dim": dim, "tile_participants": P,
-                       "participants_total": world * args.steps * P, "share_count": n, "secret_count": k,
-                       "privacy_threshold": t, "modulus": P62, "randomness": "on-device ChaCha20 (sda-drbg-v1)",
-                       "row_stride_elements": Bs,
-                       "schedule": ("share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares"
-                                    if args.overlap else "one stream, serial"),
-                       "parallelism": f"participants sharded x{world}, one modular reduce at the end"},
-            "roofline": {"bound": "hbm",
-                         "kernel": "packed_gen_kernel" if w["kind"] == "packed" else "additive_gen_kernel",
-                         "achieved": gen_gbs if dominant_gen else comb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (gen_gbs if dominant_gen else comb_gbs) / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_launch * (gen_b if dominant_gen else comb_b),
-                         "avg_launch_ms": gen_ms if dominant_gen else comb_ms},
-            "kernels": {"share_gen": {"avg_ms": gen_ms, "bytes_per_element": gen_b, "GBps": gen_gbs,
-                                      "frac_of_hbm_peak": gen_gbs / HBM_PEAK_GBS},
-                        "clerk_sum": {"avg_ms": comb_ms, "bytes_per_element": comb_b, "GBps": comb_gbs,
-                                      "frac_of_hbm_peak": comb_gbs / HBM_PEAK_GBS}},
-            "path_roofline": {"bytes_per_element": gen_b + comb_b,
-                              "achieved_GBps": value / world * (gen_b + comb_b) / 1e9,
-                              "frac_of_hbm_peak": value / world * (gen_b + comb_b) / 1e9 / HBM_PEAK_GBS},
-            "verified_reconstruct_equals_sum": verified,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(w, dim)
+    elements = float(world) * steps * P * dim
+    value = elements / dt
+    gen_b, comb_b = algorithmic_bytes_per_element(n, k)
+    per_launch = P * dim
+    gen_gbs = per_launch * gen_b / (gen_ms * 1e-3) / 1e9
+    comb_gbs = per_launch * comb_b / (comb_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    dominant_gen = gen_ms >= comb_ms
+    if os.path.exists(tpath):
+        try:
+            tr = json.load(open(tpath)).get(f"{name}:tile{P}:dim{dim}", {})
+            traffic = tr.get("gen_bytes_per_launch" if dominant_gen else "comb_bytes_per_launch")
+        except Exception:
+            traffic = None
+    gen_kernel = ("packed_gen_l31_kernel" if w["kind"] == "packed" else "additive_gen_kernel")
+    res = {
+        "metric": "share-gen + clerk-sum elements/sec (mod q)", "value": value, "unit": "elements/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": w["desc"], "name": name, "dim": dim, "tile_participants": P,
+                   "participants_total": world * steps * P, "share_count": n, "secret_count": k,
+                   "privacy_threshold": t, "modulus": P62, "randomness": "on-device ChaCha20 (sda-drbg-v1)",
+                   "row_stride_elements": Bs,
+                   "schedule": ("share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares"
+                                if overlap else "one stream, serial"),
+                   "parallelism": f"participants sharded x{world}, one modular reduce at the end"},
+        "roofline": {"bound": "hbm", "kernel": gen_kernel if dominant_gen else "combine_update_kernel",
+                     "achieved": gen_gbs if dominant_gen else comb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (gen_gbs if dominant_gen else comb_gbs) / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": per_launch * (gen_b if dominant_gen else comb_b),
+                     "avg_launch_ms": gen_ms if dominant_gen else comb_ms,
+                     "note": "the share-gen kernel is VALU-bound as measured (SQ PMC: VALU active 94 %), see DESIGN.md"},
+        "kernels": {"share_gen": {"avg_ms": gen_ms, "bytes_per_element": gen_b, "GBps": gen_gbs,
+                                  "frac_of_hbm_peak": gen_gbs / HBM_PEAK_GBS},
+                    "clerk_sum": {"avg_ms": comb_ms, "bytes_per_element": comb_b, "GBps": comb_gbs,
+                                  "frac_of_hbm_peak": comb_gbs / HBM_PEAK_GBS}},
+        "path_roofline": {"bytes_per_element": gen_b + comb_b,
+                          "achieved_GBps": value / world * (gen_b + comb_b) / 1e9,
+                          "frac_of_hbm_peak": value / world * (gen_b + comb_b) / 1e9 / HBM_PEAK_GBS},
+        "verified_reconstruct_equals_sum": verified,
+    }
+    del secrets, shares, sums, total
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="packed", choices=sorted(WORKLOADS))
+    ap.add_argument("--dim", type=int, default=1 << 20)
+    ap.add_argument("--tile", type=int, default=2000, help="participants per step and per GPU")
+    ap.add_argument("--row-align", type=int, default=16, help="pad share rows to a multiple of this many elements")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="1: share-gen of tile i+1 runs concurrently with clerk-sum of tile i (two streams, "
+                         "double-buffered shares, clerk-sum capped at 2 workgroups per CU); 0: one stream, serial")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-additional", action="store_true", help="skip the short config-2 (additive) run")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    env = Env()
+    line = measure(env, args.workload, args.dim, args.tile, args.steps, args.warmup, args.row_align, args.overlap,
+                   verify=not args.no_verify)
+    if env.world == 1 and not args.no_additional and args.workload == "packed":
+        # BASELINE config 2 (additive 3-way, 10k participants = 5 steps of the 2000-participant tile)
+        add = measure(env, "additive", args.dim, args.tile, 5, 2, args.row_align, 0, verify=not args.no_verify)
+        line["additional_workloads"] = {"additive": {k: add[k] for k in ("value", "unit", "ms_per_step", "config", "kernels",
+                                                                          "path_roofline", "verified_reconstruct_equals_sum")}}
+    if env.rank == 0:
+        if not args.no_cpu_baseline and env.world == 1:
+            line["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.dim)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if env.use_dist:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -212,6 +212,12 @@ int sda_share_combiner_update_dev(sda_share_combiner_t* c,
                                   size_t n_rows, size_t row_stride, void* stream);
 int sda_share_combiner_finish_dev(sda_share_combiner_t* c, int64_t* d_out, void* stream);
 
+/* Scheduling knob for the device form: cap the clerk-sum kernel at `max_workgroups_per_cu` resident
+ * workgroups per CU (0 = no cap).  The kernel is HBM-bound and 2 workgroups (8 waves) per CU already
+ * saturate HBM; capping it lets a VALU-bound kernel on ANOTHER stream (share generation of the next
+ * tile) keep the remaining wave slots, so the two overlap (measured +6 % on BASELINE config 3). */
+int sda_share_combiner_set_residency(sda_share_combiner_t* c, unsigned max_workgroups_per_cu);
+
 /* host-buffer streaming form (tiles are uploaded, accumulated, discarded) */
 int sda_share_combiner_begin(sda_share_combiner_t* c, size_t dimension);
 int sda_share_combiner_update(sda_share_combiner_t* c, const int64_t* shares, size_t n_rows,

@@ -88,6 +88,7 @@ SIGNATURES = {
     "sda_share_combiner_begin_dev": (C.c_int, [_H, C.c_size_t, C.c_size_t, C.c_void_p]),
     "sda_share_combiner_update_dev": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
     "sda_share_combiner_finish_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "sda_share_combiner_set_residency": (C.c_int, [_H, C.c_uint]),
     "sda_share_combiner_begin": (C.c_int, [_H, C.c_size_t]),
     "sda_share_combiner_update": (C.c_int, [_H, c_i64p, C.c_size_t, C.c_size_t]),
     "sda_share_combiner_finish": (C.c_int, [_H, c_i64p]),

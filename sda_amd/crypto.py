@@ -219,6 +219,9 @@ class ShareCombiner(_Handle):
         check(self._lib.sda_share_combiner_update_varint_dev(self._h, codec._h, d_bytes, n_bytes, d_row_offsets or None,
                                                              rows, d_status, stream or None))
 
+    def set_residency(self, max_workgroups_per_cu: int) -> None:
+        check(self._lib.sda_share_combiner_set_residency(self._h, max_workgroups_per_cu))
+
     def begin_dev(self, jobs: int, dimension: int, stream: int = 0):
         check(self._lib.sda_share_combiner_begin_dev(self._h, jobs, dimension, stream or None))
 

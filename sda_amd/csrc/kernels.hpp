@@ -83,7 +83,7 @@ hipError_t launch_drbg_fill(int64_t* d_out, size_t stride, size_t participants, 
 // acc (lo, hi) += sum over rows; element (job, row, i) at shares + job*job_stride + row*row_stride + i
 hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const int64_t* d_shares,
                                  size_t jobs, size_t job_stride, size_t n_rows, size_t row_stride,
-                                 size_t dimension, hipStream_t s);
+                                 size_t dimension, hipStream_t s, unsigned max_wg_per_cu = 0);
 hipError_t launch_combine_finish(const uint64_t* d_acc_lo, const int64_t* d_acc_hi, size_t count,
                                  const ModParams& mod, int64_t* d_out, hipStream_t s);
 

@@ -582,6 +582,7 @@ struct sda_share_combiner {
     DevBuf tile, d_out;
     size_t jobs = 0, dimension = 0;
     bool begun = false;
+    unsigned max_wg_per_cu = 0;          // 0 = no cap (sda_share_combiner_set_residency)
 };
 
 extern "C" int sda_share_combiner_new(const sda_sharing_scheme_t* scheme, sda_share_combiner_t** out) {
@@ -640,7 +641,14 @@ extern "C" int sda_share_combiner_update_dev(sda_share_combiner_t* c, const int6
     if (!d_shares) return fail(SDA_ERR_INVALID_ARGUMENT, "d_shares is NULL");
     SDA_TRY(c->ctx.use());
     HIP_TRY(launch_combine_update(c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_shares, c->jobs, job_stride, n_rows,
-                                  row_stride, c->dimension, c->ctx.pick(stream)));
+                                  row_stride, c->dimension, c->ctx.pick(stream), c->max_wg_per_cu));
+    return SDA_OK;
+}
+
+extern "C" int sda_share_combiner_set_residency(sda_share_combiner_t* c, unsigned max_workgroups_per_cu) {
+    if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
+    if (max_workgroups_per_cu > 8) return fail(SDA_ERR_INVALID_ARGUMENT, "max_workgroups_per_cu must be 0 (no cap) .. 8");
+    c->max_wg_per_cu = max_workgroups_per_cu;
     return SDA_OK;
 }
 

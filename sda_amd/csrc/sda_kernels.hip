@@ -15,6 +15,7 @@
 // addsub_mod        full.rs:28-31,60-63; chacha.rs:42-45,86-89                    tiny
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "chacha.hpp"
 #include "kernels.hpp"
@@ -948,7 +949,7 @@ hipError_t launch_drbg_fill(int64_t* d_out, size_t stride, size_t participants, 
 
 hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const int64_t* d_shares, size_t jobs,
                                  size_t job_stride, size_t n_rows, size_t row_stride, size_t dimension,
-                                 hipStream_t s) {
+                                 hipStream_t s, unsigned max_wg_per_cu) {
     if (jobs == 0 || n_rows == 0 || dimension == 0) return hipSuccess;
     if (jobs > 65535) return hipErrorInvalidConfiguration;
     const uint64_t col_blocks = ceil_div(ceil_div(dimension, 2), kThreads);
@@ -966,8 +967,12 @@ hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const in
     const bool atomic = split > 1;
     const bool vec = aligned16(d_shares) && (job_stride % 2 == 0) && (row_stride % 2 == 0);
     dim3 grid((unsigned)col_blocks, (unsigned)jobs, (unsigned)split);
+    // max_wg_per_cu > 0: an unused dynamic-LDS request caps the resident workgroups per CU, so that this
+    // HBM-bound kernel (8 waves per CU already saturate HBM) leaves wave slots to a VALU-bound kernel
+    // running on another stream
+    const unsigned lds_pad = max_wg_per_cu > 0 ? (160u * 1024u) / max_wg_per_cu - 256u : 0u;
     if (vec)
-        combine_update_kernel<true, 8><<<grid, dim3(kThreads), 0, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows,
+        combine_update_kernel<true, 8><<<grid, dim3(kThreads), lds_pad, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows,
                                                                        row_stride, dimension, rows_per_split, atomic);
     else
         combine_update_kernel<false, 1><<<grid, dim3(kThreads), 0, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows,
