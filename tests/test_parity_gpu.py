@@ -541,3 +541,17 @@ def test_launch_slicing_over_the_grid_limit(gpu):
         want = coracle.fill_synthetic(1, dim, 5 + p, 11, P62)[0]
         assert np.array_equal(secrets.to_numpy(dim, p * dim), want)
         assert np.array_equal(out.to_numpy(dim, p * dim), want)
+
+
+def test_mont64_kernel_equals_limb31_kernel(gpu, monkeypatch):
+    """the superseded 64-bit Montgomery share-gen kernel (kept for A/B) stays bit-identical to the shipped one"""
+    from sda_amd import crypto
+    rng = np.random.default_rng(6)
+    for (k, t, n, o2, o3) in [(3, 1, 8, 8, 9), (8, 2, 26, 16, 27)]:
+        sch = crypto.PackedShamir(k, n, t, P62, W[o2], W[o3])
+        secrets = rng.integers(-(1 << 63), (1 << 63) - 1, size=4099, dtype=np.int64)
+        a = crypto.ShareGenerator(sch); a.set_drbg_key(KEY)
+        monkeypatch.setenv("SDA_FORCE_MONT64", "1")
+        b = crypto.ShareGenerator(sch); b.set_drbg_key(KEY)
+        monkeypatch.delenv("SDA_FORCE_MONT64")
+        assert np.array_equal(a.generate(secrets), b.generate(secrets))
