@@ -175,7 +175,14 @@ def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=Tr
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
 
-    sums = torch.empty((n, B), dtype=torch.int64, device=dev)
+    sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
+    if env.use_dist:
+        # RCCL connects lazily on the first collective of each kind: do that outside the timed region,
+        # with the real message sizes
+        with torch.cuda.stream(s_comb):
+            modular_allreduce(sums, P62)
+        tw = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     env.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
