@@ -555,3 +555,74 @@ def test_mont64_kernel_equals_limb31_kernel(gpu, monkeypatch):
         b = crypto.ShareGenerator(sch); b.set_drbg_key(KEY)
         monkeypatch.delenv("SDA_FORCE_MONT64")
         assert np.array_equal(a.generate(secrets), b.generate(secrets))
+
+
+def _is_prime(n):
+    if n < 2:
+        return False
+    for q in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % q == 0:
+            return n == q
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+@pytest.mark.parametrize("bits", [7, 13, 31, 32, 33, 47, 61, 62])
+def test_packed_random_primes_and_roots(gpu, bits):
+    """any odd prime < 2^62 and any omegas with distinct nodes: generate -> combine -> reconstruct vs the oracle"""
+    import random
+    from sda_amd import crypto
+    from oracle import coracle
+    rnd = random.Random(bits)
+    for trial in range(3):
+        for _ in range(100000):
+            p = rnd.randrange(1 << (bits - 1), 1 << bits) | 1
+            if _is_prime(p) and p > 64:
+                break
+        else:
+            raise AssertionError("no prime found")
+        k, t, n = rnd.choice([(3, 1, 8), (2, 2, 6), (3, 4, 8), (8, 2, 12), (1, 1, 3)])
+        for _ in range(100000):
+            w2, w3 = rnd.randrange(2, p), rnd.randrange(2, p)
+            if len({pow(w2, e, p) for e in range(k + t + 1)}) == k + t + 1 and \
+               len({1} | {pow(w3, j + 1, p) for j in range(n)}) == n + 1:
+                break
+        else:
+            raise AssertionError("no suitable roots found")
+        sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+        dim = rnd.choice([1, 17, 1000, 4097])
+        B = (dim + k - 1) // k
+        rng = np.random.default_rng(trial)
+        P = 5
+        secrets = rng.integers(-(1 << 63), (1 << 63) - 1, size=(P, dim), dtype=np.int64)
+        rand = rng.integers(-(1 << 63), (1 << 63) - 1, size=(P, B * t), dtype=np.int64)
+        gen = crypto.ShareGenerator(sch)
+        shares = [gen.generate(secrets[i], rand[i]) for i in range(P)]
+        for i in range(P):
+            assert np.array_equal(shares[i], coracle.packed_generate(p, k, t, n, w2, w3, secrets[i], rand[i])), (p, k, t)
+        comb = crypto.ShareCombiner(sch)
+        sums = [comb.combine([shares[i][c] for i in range(P)]) for c in range(n)]
+        subset = sorted(rnd.sample(range(n), k + t))
+        got = crypto.SecretReconstructor(sch, dim).reconstruct([(c, sums[c]) for c in subset])
+        want = [sum(int(secrets[i][j]) for i in range(P)) % p for j in range(dim)]
+        assert got.tolist() == want
+        # device CSPRNG path: reconstruct(sum of fresh sharings) is independent of the draws
+        gen.set_drbg_key(KEY)
+        shares2 = [gen.generate(secrets[i]) for i in range(P)]
+        sums2 = [comb.combine([shares2[i][c] for i in range(P)]) for c in range(n)]
+        assert crypto.SecretReconstructor(sch, dim).reconstruct([(c, sums2[c]) for c in subset]).tolist() == want
+        rnd_draws = coracle.drbg_fill(KEY, 0, B, t, p) if t else np.zeros(0, dtype=np.int64)
+        assert np.array_equal(shares2[0], coracle.packed_generate(p, k, t, n, w2, w3, secrets[0], rnd_draws))
