@@ -626,3 +626,39 @@ def test_packed_random_primes_and_roots(gpu, bits):
         assert crypto.SecretReconstructor(sch, dim).reconstruct([(c, sums2[c]) for c in subset]).tolist() == want
         rnd_draws = coracle.drbg_fill(KEY, 0, B, t, p) if t else np.zeros(0, dtype=np.int64)
         assert np.array_equal(shares2[0], coracle.packed_generate(p, k, t, n, w2, w3, secrets[0], rnd_draws))
+
+
+def test_odd_strides_and_unaligned_bases_dev(gpu):
+    """caller layouts that rule out 16-byte accesses (odd strides, 8-byte-aligned bases) take the scalar
+    paths of the kernels; results must be identical"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(31)
+    P, dim = 5, 1001
+    for sch, k, t, n in ((crypto.PackedShamir(3, 8, 1, P62, W[8], W[9]), 3, 1, 8), (crypto.Additive(3, P62), 1, 2, 3)):
+        B = (dim + k - 1) // k
+        sec_stride, out_sp, out_sc = dim + 2, B + 1, P * (B + 1) + 3        # odd strides
+        host = rng.integers(0, P62, size=(P, sec_stride), dtype=np.int64)
+        d_sec = DeviceBuffer.from_numpy(np.concatenate([[0], host.reshape(-1)]))     # +1 element: base only 8-byte aligned
+        rand = rng.integers(0, P62, size=(P, B * t), dtype=np.int64)
+        d_rand = DeviceBuffer.from_numpy(rand)
+        d_out = DeviceBuffer(n * out_sc + 8).zero()
+        gen = crypto.ShareGenerator(sch)
+        gen.generate_batch_dev(d_sec.at(1), P, dim, sec_stride, d_out.at(1), out_sp, out_sc, d_rand=d_rand.ptr, rand_stride=B * t)
+        got = d_out.to_numpy()[1:]
+        for p in range(P):
+            want = (coracle.packed_generate(P62, k, t, n, W[8], W[9], host[p, :dim], rand[p]) if k == 3 else
+                    coracle.additive_generate(P62, n, host[p, :dim], rand[p]))
+            for j in range(n):
+                assert np.array_equal(got[j * out_sc + p * out_sp: j * out_sc + p * out_sp + B], want[j]), (k, p, j)
+        # clerk-sum straight from that odd-strided, misaligned layout
+        comb = crypto.ShareCombiner(sch)
+        d_sum = DeviceBuffer(n * B)
+        comb.begin_dev(n, B)
+        comb.update_dev(d_out.at(1), out_sc, P, out_sp)
+        comb.finish_dev(d_sum.ptr)
+        S = d_sum.to_numpy().reshape(n, B)
+        for j in range(n):
+            rows = np.stack([got[j * out_sc + p * out_sp: j * out_sc + p * out_sp + B] for p in range(P)])
+            assert np.array_equal(S[j], coracle.combine(P62, rows))
