@@ -112,3 +112,47 @@ def test_missing_library_raises(built, monkeypatch):
     monkeypatch.setattr(capi, "LIB_PATH", os.path.join(ROOT, "sda_amd", "lib", "nope.so"))
     with pytest.raises(OSError, match="no fallback"):
         capi.load()
+
+
+def test_abi_misuse_returns_codes_not_crashes(built):
+    """NULL handles / NULL out-pointers are answered with SDA_ERR_INVALID_ARGUMENT (nothing throws or aborts
+    across the ABI; argument checks come before any device access, so this runs without a GPU)."""
+    from sda_amd import capi
+    lib = capi.load()
+    n = C.c_size_t()
+    buf = (C.c_int64 * 4)()
+    u8 = (C.c_uint8 * 16)()
+    bad = capi.ERR_INVALID_ARGUMENT
+    assert lib.sda_share_generator_new(None, None) == bad
+    assert lib.sda_share_generator_generate(None, buf, 4, None, 0, buf, 4) == bad
+    assert lib.sda_share_generator_generate_batch_dev(None, None, 1, 1, 1, None, 0, 0, None, 1, 1, None) == bad
+    assert lib.sda_share_generator_set_drbg_key(None, None) == bad
+    assert lib.sda_share_combiner_new(None, None) == bad
+    assert lib.sda_share_combiner_combine(None, None, None, 0, buf, 4, C.byref(n)) == bad
+    assert lib.sda_share_combiner_begin(None, 4) == bad and lib.sda_share_combiner_update(None, buf, 1, 4) == bad
+    assert lib.sda_share_combiner_finish(None, buf) == bad and lib.sda_share_combiner_set_residency(None, 2) == bad
+    assert lib.sda_share_combiner_update_varint(None, None, u8, 1) == bad
+    assert lib.sda_secret_reconstructor_new(None, 4, None) == bad
+    assert lib.sda_secret_reconstructor_reconstruct(None, None, None, None, 0, buf, 4, C.byref(n)) == bad
+    assert lib.sda_secret_masker_new(None, None) == bad
+    assert lib.sda_secret_masker_mask(None, buf, 4, None, 0, buf, 4, C.byref(n), buf) == bad
+    assert lib.sda_mask_combiner_combine(None, None, None, 0, buf, 4, C.byref(n)) == bad
+    assert lib.sda_secret_unmasker_unmask(None, buf, 4, buf, 4, buf) == bad
+    assert lib.sda_varint_codec_new(None) == bad
+    assert lib.sda_varint_encode(None, buf, 4, u8, 16, C.byref(n)) == bad
+    assert lib.sda_varint_decode(None, u8, 4, buf, 4, C.byref(n)) == bad
+    assert lib.sda_positive(None, 4, 433, None) == bad and lib.sda_positive(None, 0, 433, None) == capi.OK
+    assert lib.sda_event_create(None) == bad and lib.sda_dev_malloc(None, 8) == bad
+    assert lib.sda_last_error() != b""
+    # free functions accept NULL
+    for f in ("sda_share_generator_free", "sda_share_combiner_free", "sda_secret_reconstructor_free",
+              "sda_secret_masker_free", "sda_mask_combiner_free", "sda_secret_unmasker_free", "sda_varint_codec_free"):
+        getattr(lib, f)(None)
+    # unknown scheme kinds and out-of-range parameters are refused before any device work
+    s = capi.SharingScheme(7, 3, 433, 0, 0, 0, 0)
+    h = C.c_void_p()
+    assert lib.sda_share_generator_new(C.byref(s), C.byref(h)) == bad and not h.value
+    m = capi.MaskingScheme(9, 433, 4, 128)
+    assert lib.sda_secret_masker_new(C.byref(m), C.byref(h)) == bad and not h.value
+    s = capi.SharingScheme(capi.SHARING_ADDITIVE, 3, 1 << 62, 0, 0, 0, 0)
+    assert lib.sda_share_combiner_new(C.byref(s), C.byref(h)) == capi.ERR_UNSUPPORTED

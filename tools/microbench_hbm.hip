@@ -1,0 +1,61 @@
+// HBM floor of the share-gen access pattern on gfx950: each lane reads 48 contiguous bytes (3 x 16 B) and
+// writes one 16-byte non-temporal store to each of 8 row streams (rows 128-byte aligned), no arithmetic.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench_hbm.hip -o tools/microbench_hbm
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+typedef long long ll2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>   // 0: gen pattern, 1: writes only, 2: reads only (sum), 3: gen pattern with plain (non-NT) stores
+__global__ __launch_bounds__(256) void k(const long long* __restrict__ in, long long* __restrict__ out, size_t dim,
+                                         size_t B, size_t Bs, size_t P, size_t chunks, long long* sink) {
+    const size_t p = blockIdx.x / chunks, chunk = blockIdx.x - p * chunks;
+    const size_t pair = chunk * 256 + threadIdx.x, b0 = 2 * pair;
+    if (b0 + 1 >= B || b0 * 3 + 6 > dim) return;
+    ll2 v[3];
+    long long acc = 0;
+    if (MODE != 1) {
+        const long long* sp = in + p * dim + b0 * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[i] = *reinterpret_cast<const ll2*>(sp + 2 * i); acc += v[i].x ^ v[i].y; }
+    } else { acc = (long long)b0; }
+    if (MODE == 2) { if (acc == 0x1234567) *sink = acc; return; }
+    long long* op = out + p * Bs + b0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ll2 w; w.x = acc + j; w.y = acc - j;
+        if (MODE == 3) *reinterpret_cast<ll2*>(op + (size_t)j * P * Bs) = w;
+        else __builtin_nontemporal_store(w, reinterpret_cast<ll2*>(op + (size_t)j * P * Bs));
+    }
+}
+
+template <int MODE>
+int run(const char* name, const long long* in, long long* out, size_t dim, size_t B, size_t Bs, size_t P, long long* sink, double bytes) {
+    const size_t chunks = (B / 2 + 255) / 256;
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    k<MODE><<<dim3((unsigned)(chunks * P)), dim3(256)>>>(in, out, dim, B, Bs, P, chunks, sink);
+    CHK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        CHK(hipEventRecord(e0));
+        k<MODE><<<dim3((unsigned)(chunks * P)), dim3(256)>>>(in, out, dim, B, Bs, P, chunks, sink);
+        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    printf("%-44s %7.3f ms  %6.2f TB/s\n", name, best, bytes / (best * 1e-3) / 1e12);
+    return 0;
+}
+
+int main() {
+    const size_t P = 2000, dim = 1 << 20, B = 349526, Bs = 349536;
+    long long *in, *out, *sink;
+    CHK(hipMalloc(&in, P * dim * 8)); CHK(hipMalloc(&out, 8 * P * Bs * 8)); CHK(hipMalloc(&sink, 8));
+    CHK(hipMemset(in, 1, P * dim * 8));
+    const double rd = (double)P * dim * 8, wr = 8.0 * P * B * 8;
+    run<0>("gen pattern: 16.8 GB read + 44.7 GB NT write", in, out, dim, B, Bs, P, sink, rd + wr);
+    run<3>("gen pattern, plain stores", in, out, dim, B, Bs, P, sink, rd + wr);
+    run<1>("writes only (44.7 GB, NT)", in, out, dim, B, Bs, P, sink, wr);
+    run<2>("reads only (16.8 GB)", in, out, dim, B, Bs, P, sink, rd);
+    return 0;
+}
