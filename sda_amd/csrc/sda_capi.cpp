@@ -554,11 +554,10 @@ extern "C" int sda_share_generator_generate(sda_share_generator_t* g, const int6
     SDA_TRY(g->d_out.reserve((size_t)g->n * Bs * 8));
     HIP_TRY(hipMemcpyAsync(g->d_secrets.p, secrets, len * 8, hipMemcpyHostToDevice, g->ctx.stream));
     const int64_t* d_rand = nullptr;
-    DevBuf staged_rand;
-    if (rand && want_rand) {
-        SDA_TRY(staged_rand.reserve(want_rand * 8));
-        HIP_TRY(hipMemcpyAsync(staged_rand.p, rand, want_rand * 8, hipMemcpyHostToDevice, g->ctx.stream));
-        d_rand = staged_rand.as<int64_t>();
+    if (rand && want_rand) {                        // injected draws are staged in the handle's own scratch
+        SDA_TRY(g->d_rand.reserve(want_rand * 8));
+        HIP_TRY(hipMemcpyAsync(g->d_rand.p, rand, want_rand * 8, hipMemcpyHostToDevice, g->ctx.stream));
+        d_rand = g->d_rand.as<int64_t>();
     }
     const uint64_t stream_id = g->drbg.next_stream++;
     int st = sda_share_generator_generate_batch_dev(g, g->d_secrets.as<int64_t>(), 1, len, len, d_rand, want_rand, stream_id,
@@ -568,7 +567,6 @@ extern "C" int sda_share_generator_generate(sda_share_generator_t* g, const int6
         if (e != hipSuccess) st = fail(SDA_ERR_HIP, "hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
     }
     if (st == SDA_OK) st = g->ctx.sync(); else (void)hipStreamSynchronize(g->ctx.stream);
-    staged_rand.release();
     return st;
 }
 

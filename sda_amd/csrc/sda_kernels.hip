@@ -327,7 +327,6 @@ __device__ __forceinline__ uint64_t l31_dot(const uint64_t* __restrict__ row, co
     uint64_t r = 0;
 #pragma unroll
     for (int g = 0; g < KT; g += 4) {
-        constexpr int dummy = 0; (void)dummy;
         int64_t top;
         const int left = KT - g;
         if (left >= 4) top = l31_group<4>(row + g, v0 + g, v1 + g, P);
@@ -394,7 +393,6 @@ __global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, u
     }
 
     int64_t* op = L.out + p * L.out_stride_participant + b0;
-#pragma unroll 2
     for (uint32_t j = 0; j < n; ++j) {
         const uint64_t* row = &M.e[(size_t)j * KT];
         const uint64_t a = l31_dot<KT>(row, a0, a1, lp);
