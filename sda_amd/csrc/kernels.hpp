@@ -128,7 +128,9 @@ struct VarintRows {
 size_t varint_encode_blocks(size_t rows, size_t len);     // workgroups (= entries of the block-sum arrays)
 size_t varint_decode_blocks(size_t n_bytes);
 hipError_t launch_varint_lengths(const VarintRows& R, uint32_t* d_block_bytes, hipStream_t s);
-hipError_t launch_scan_u32(const uint32_t* d_in, uint64_t* d_out, size_t n, uint64_t* d_total, hipStream_t s);
+size_t scan_aux_entries(size_t n);                        // u64 scratch entries launch_scan_u32 needs
+hipError_t launch_scan_u32(const uint32_t* d_in, uint64_t* d_out, size_t n, uint64_t* d_total, uint64_t* d_aux,
+                           hipStream_t s);
 hipError_t launch_varint_write(const VarintRows& R, const uint64_t* d_block_off, uint8_t* d_out,
                                uint64_t* d_row_offsets, hipStream_t s);
 hipError_t launch_varint_count(const uint8_t* d_bytes, size_t n_bytes, uint32_t* d_block_counts, hipStream_t s);

@@ -1077,7 +1077,7 @@ extern "C" int sda_positive(const int64_t* values, size_t len, int64_t modulus, 
 // =================================================================================================
 struct sda_varint_codec {
     Ctx ctx;
-    DevBuf d_blocks, d_offs, d_total, d_status, d_in, d_out, d_rowoff;
+    DevBuf d_blocks, d_offs, d_aux, d_total, d_status, d_in, d_out, d_rowoff;
 };
 
 extern "C" int sda_varint_codec_new(sda_varint_codec_t** out) {
@@ -1096,7 +1096,7 @@ extern "C" int sda_varint_codec_new(sda_varint_codec_t** out) {
 extern "C" void sda_varint_codec_free(sda_varint_codec_t* c) {
     if (!c) return;
     if (c->ctx.device >= 0) (void)hipSetDevice(c->ctx.device);
-    c->d_blocks.release(); c->d_offs.release(); c->d_total.release(); c->d_status.release();
+    c->d_blocks.release(); c->d_offs.release(); c->d_aux.release(); c->d_total.release(); c->d_status.release();
     c->d_in.release(); c->d_out.release(); c->d_rowoff.release();
     delete c;
 }
@@ -1119,9 +1119,11 @@ extern "C" int sda_varint_encode_dev(sda_varint_codec_t* c, const int64_t* d_val
     if (row_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "row_stride < len");
     SDA_TRY(c->d_blocks.reserve(nb * 4));
     SDA_TRY(c->d_offs.reserve(nb * 8));
+    SDA_TRY(c->d_aux.reserve(scan_aux_entries(nb) * 8));
     VarintRows R{d_values, rows, len, row_stride};
     HIP_TRY(launch_varint_lengths(R, c->d_blocks.as<uint32_t>(), s));
-    HIP_TRY(launch_scan_u32(c->d_blocks.as<uint32_t>(), c->d_offs.as<uint64_t>(), nb, c->d_total.as<uint64_t>(), s));
+    HIP_TRY(launch_scan_u32(c->d_blocks.as<uint32_t>(), c->d_offs.as<uint64_t>(), nb, c->d_total.as<uint64_t>(),
+                            c->d_aux.as<uint64_t>(), s));
     uint64_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, c->d_total.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1136,10 +1138,12 @@ static int varint_count_scan(sda_varint_codec_t* c, const uint8_t* d_bytes, size
     const size_t nb = varint_decode_blocks(n_bytes);
     SDA_TRY(c->d_blocks.reserve((nb + 1) * 4));
     SDA_TRY(c->d_offs.reserve((nb + 1) * 8));
+    SDA_TRY(c->d_aux.reserve(scan_aux_entries(nb + 1) * 8));
     HIP_TRY(launch_varint_count(d_bytes, n_bytes, c->d_blocks.as<uint32_t>(), s));
     // one extra (zero) entry so that prefix(x) is defined for x == n_bytes on a block boundary
     HIP_TRY(hipMemsetAsync(c->d_blocks.as<uint32_t>() + nb, 0, 4, s));
-    HIP_TRY(launch_scan_u32(c->d_blocks.as<uint32_t>(), c->d_offs.as<uint64_t>(), nb + 1, c->d_total.as<uint64_t>(), s));
+    HIP_TRY(launch_scan_u32(c->d_blocks.as<uint32_t>(), c->d_offs.as<uint64_t>(), nb + 1, c->d_total.as<uint64_t>(),
+                            c->d_aux.as<uint64_t>(), s));
     return SDA_OK;
 }
 

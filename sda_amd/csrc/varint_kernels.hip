@@ -68,33 +68,58 @@ __global__ __launch_bounds__(kVT) void varint_len_kernel(VarintRows R, uint32_t*
     if (threadIdx.x == 0) block_bytes[blockIdx.x] = total;
 }
 
-// one workgroup walks the array: out[i] = sum of in[0..i), *total = sum of all
-__global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out,
-                                                        size_t n, uint64_t* __restrict__ total) {
-    __shared__ uint64_t wave_sum[16];
-    __shared__ uint64_t carry_s;
+// ---- exclusive scan of u32 -> u64, three small kernels: scan 1024-entry chunks in parallel, scan the
+// chunk totals with one workgroup, add the chunk offsets back ------------------------------------------------
+__device__ __forceinline__ uint64_t block1024_exscan(uint64_t v, uint64_t* wave_sum, uint64_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t i = base + threadIdx.x;
-        const uint64_t v = i < n ? in[i] : 0;
-        uint64_t incl = v;
+    uint64_t incl = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        uint64_t off = carry_s;
-        for (int w = 0; w < wave; ++w) off += wave_sum[w];
-        if (i < n) out[i] = off + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = off + incl;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
     }
-    if (threadIdx.x == 0) *total = carry_s;
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint64_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint64_t t = wave_sum[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    *total = tot;
+    __syncthreads();
+    return off + incl - v;
+}
+
+__global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                           uint64_t* __restrict__ chunk_tot, size_t n) {
+    __shared__ uint64_t wave_sum[16];
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    uint64_t total;
+    const uint64_t ex = block1024_exscan(i < n ? in[i] : 0, wave_sum, &total);
+    if (i < n) out[i] = ex;
+    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = total;
+}
+
+// one workgroup: in-place exclusive scan of the chunk totals, *total = grand total
+__global__ __launch_bounds__(1024) void scan_totals_kernel(uint64_t* __restrict__ tot, size_t m, uint64_t* __restrict__ total) {
+    __shared__ uint64_t wave_sum[16];
+    uint64_t carry = 0;
+    for (size_t base = 0; base < m; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        uint64_t t;
+        const uint64_t ex = block1024_exscan(i < m ? tot[i] : 0, wave_sum, &t);
+        if (i < m) tot[i] = carry + ex;
+        carry += t;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(1024) void scan_add_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ chunk_off,
+                                                        size_t n) {
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += chunk_off[blockIdx.x];
 }
 
 __global__ __launch_bounds__(kVT) void varint_write_kernel(VarintRows R, const uint64_t* __restrict__ block_off,
@@ -328,8 +353,16 @@ hipError_t launch_varint_lengths(const VarintRows& R, uint32_t* d_block_bytes, h
     return hipGetLastError();
 }
 
-hipError_t launch_scan_u32(const uint32_t* d_in, uint64_t* d_out, size_t n, uint64_t* d_total, hipStream_t s) {
-    scan_u32_kernel<<<dim3(1), dim3(1024), 0, s>>>(d_in, d_out, n, d_total);
+size_t scan_aux_entries(size_t n) { return (n + 1023) / 1024 + 1; }
+
+hipError_t launch_scan_u32(const uint32_t* d_in, uint64_t* d_out, size_t n, uint64_t* d_total, uint64_t* d_aux,
+                           hipStream_t s) {
+    const size_t m = (n + 1023) / 1024;
+    if (m == 0) return hipMemsetAsync(d_total, 0, 8, s);
+    if (m > 0xFFFFFFFFull / 1024) return hipErrorInvalidConfiguration;
+    scan_chunks_kernel<<<dim3((unsigned)m), dim3(1024), 0, s>>>(d_in, d_out, d_aux, n);
+    scan_totals_kernel<<<dim3(1), dim3(1024), 0, s>>>(d_aux, m, d_total);
+    scan_add_kernel<<<dim3((unsigned)m), dim3(1024), 0, s>>>(d_out, d_aux, n);
     return hipGetLastError();
 }
 
