@@ -256,3 +256,48 @@ def test_varint_codec_oracle():
     assert coracle.varint_encode(vals) == enc and coracle.varint_decode(enc).tolist() == vals
     assert po.varint_decode(bytes([0x02, 0x80])) == [1, 0]                      # unterminated tail: a partial value
     assert coracle.varint_decode(bytes([0x02, 0x80])).tolist() == [1, 0]
+
+
+# ---- algebraic properties under hypothesis ------------------------------------------------------
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(min_value=0, max_value=2 ** 32), st.integers(min_value=1, max_value=4), st.integers(min_value=1, max_value=9),
+       st.sampled_from(["None", "Full", "ChaCha"]), st.booleans())
+def test_linear_invariant_property(seed, participants, dim, mask_kind, packed):
+    """reveal(aggregate) == sum of inputs mod q for every masking scheme x sharing scheme, every
+    >= (t+k)-subset of clerks, any randomness, in both value modes - the invariant the reference's
+    full_loop tests assert on one fixed input."""
+    rnd = random.Random(seed)
+    q = 433
+    if packed:
+        shr = dict(po.PSS_433)
+        k, t, n = 3, 4, 8
+        subset = sorted(rnd.sample(range(n), rnd.randrange(t + k, n + 1)))
+    else:
+        n = rnd.randrange(1, 5)
+        shr = dict(kind="Additive", share_count=n, modulus=q)
+        k, t, subset = 1, n - 1, None
+    msk = {"None": dict(kind="None"), "Full": dict(kind="Full", modulus=q),
+           "ChaCha": dict(kind="ChaCha", modulus=q, dimension=dim, seed_bitsize=rnd.choice([32, 64, 128, 256]))}[mask_kind]
+    a = dict(vector_dimension=dim, modulus=q, masking_scheme=msk, committee_sharing_scheme=shr)
+    inputs = [[rnd.randrange(-500, 1000) for _ in range(dim)] for _ in range(participants)]
+    nb = (dim + k - 1) // k
+    mr = [([rnd.randrange(q) for _ in range(dim)] if mask_kind == "Full" else
+           [rnd.getrandbits(32) for _ in range((msk.get("seed_bitsize", 0) + 31) // 32)]) for _ in inputs]
+    sr = [[rnd.randrange(q - 1) for _ in range(nb * t)] for _ in inputs]
+    want = [sum(col) % q for col in zip(*inputs)]
+    for mode in ("rust_signed", "canonical"):
+        r = po.full_aggregation(a, inputs, mr, sr, subset, mode)
+        assert r["positive"] == want
+        assert [v % q for v in r["output"]] == want
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.integers(min_value=-(2 ** 63), max_value=2 ** 63 - 1), min_size=0, max_size=200))
+def test_varint_roundtrip_property(values):
+    enc = po.varint_encode(values)
+    assert po.varint_decode(enc) == values
+    assert coracle.varint_encode(values) == enc
+    assert len(enc) == sum(max(1, ((((v << 1) ^ (v >> 63)) & po.MASK64).bit_length() + 6) // 7) for v in values)
