@@ -38,12 +38,14 @@ def test_library_is_gfx950_only_and_links_no_oracle(built):
 
 
 def test_product_does_not_import_oracle():
-    """The product path must not route through the oracle or any CPU fallback."""
+    """The product path must not route through the oracle or any CPU fallback: nothing under sda_amd/
+    (Python, C++ or HIP) may mention oracle/, and the loader has no alternative implementation."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "sda_amd")):
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
-                text = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in text.replace("# oracle", "").lower() or f in (), (f, "mentions the oracle")
+                text = open(os.path.join(dirpath, f)).read().lower()
+                assert "oracle" not in text, (f, "mentions the oracle")
+    assert "oracle" not in open(os.path.join(ROOT, "include", "sda_hip.h")).read().lower()
 
 
 def test_scheme_derived_sizes(built):
