@@ -100,6 +100,133 @@ class Env:
         self.torch.cuda.synchronize(self.dev)
 
 
+def measure_fused(env, name, dim, P, steps, warmup, row_align=16, verify=True):
+    """Software-pipelined schedule: ONE dual-role launch per step generates tile i while the clerk sums of
+    tile i-1 are accumulated (sda_share_generator_generate_combine_dev); K + 1 launches cover K tiles."""
+    torch, dist, capi, lib, dev = env.torch, env.dist, env.capi, env.lib, env.dev
+    from sda_amd import crypto
+    from sda_amd.distributed import modular_allreduce
+    rank, world = env.rank, env.world
+    w = WORKLOADS[name]
+    n, k, t = w["n"], w["k"], w["t"]
+    scheme = (crypto.PackedShamir(k, n, t, P62, OMEGA[w["o2"]], OMEGA[w["o3"]]) if w["kind"] == "packed"
+              else crypto.Additive(n, P62))
+    B = (dim + k - 1) // k
+    Bs = (B + row_align - 1) // row_align * row_align
+    gen = crypto.ShareGenerator(scheme)
+    gen.set_drbg_key(KEY)
+    comb = crypto.ShareCombiner(scheme)
+    secrets = torch.empty((P, dim), dtype=torch.int64, device=dev)
+    shares = [torch.empty((n, P, Bs), dtype=torch.int64, device=dev) for _ in range(2)]
+    capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, rank * P, SEED, P62, None))
+    torch.cuda.synchronize(dev)
+
+    def launch(i, total, ev=None):
+        """launch i of total+1: generate tile i (if i < total), sum tile i-1 (if i > 0)"""
+        cur, prev = shares[i % 2], shares[(i - 1) % 2]
+        if ev:
+            capi.check(lib.sda_event_record(ev[0], None))
+        gen.generate_combine_dev(comb, secrets.data_ptr(), P if i < total else 0, dim, dim, cur.data_ptr(), Bs, P * Bs,
+                                 d_prev=prev.data_ptr() if i > 0 else 0, prev_participants=P if i > 0 else 0,
+                                 first_participant=(i * world + rank) * P)
+        if ev:
+            capi.check(lib.sda_event_record(ev[1], None))
+
+    comb.begin_dev(n, B)
+    for i in range(warmup + 1):
+        launch(i, warmup)
+    torch.cuda.synchronize(dev)
+    comb.begin_dev(n, B)                                     # discard the warm-up contributions
+    evs = []
+    for _ in range(2 * (steps + 1)):
+        e = C.c_void_p()
+        capi.check(lib.sda_event_create(C.byref(e)))
+        evs.append(e)
+    sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
+    if env.use_dist:
+        modular_allreduce(sums, P62)
+        tw = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    env.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps + 1):
+        launch(i, steps, evs[2 * i:2 * i + 2])
+    comb.finish_dev(sums.data_ptr())
+    total = modular_allreduce(sums, P62) if env.use_dist else sums
+    env.barrier()
+    dt = time.perf_counter() - t0
+    if env.use_dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms = C.c_float()
+    launch_ms = []
+    for i in range(steps + 1):
+        capi.check(lib.sda_event_elapsed_ms(evs[2 * i], evs[2 * i + 1], C.byref(ms)))
+        launch_ms.append(ms.value)
+    all_ms = sum(launch_ms) / len(launch_ms)                 # what rocprofv3 --stats averages (K+1 launches)
+    full = launch_ms[1:steps]                                # launches that carry both roles
+    full_ms = sum(full) / len(full) if full else float("nan")
+    for e in evs:
+        lib.sda_event_destroy(e)
+    verified = None
+    if verify:
+        rec = crypto.SecretReconstructor(scheme, dim)
+        out = torch.empty(dim, dtype=torch.int64, device=dev)
+        idx = list(range(scheme.reconstruction_threshold()))
+        rows = total[:len(idx)].contiguous()
+        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim)
+        cs = crypto.ShareCombiner(crypto.Additive(2, P62))
+        cs.begin_dev(1, dim)
+        for _ in range(steps):
+            cs.update_dev(secrets.data_ptr(), 0, P, dim)
+        exp = torch.empty(dim, dtype=torch.int64, device=dev)
+        cs.finish_dev(exp.data_ptr())
+        exp_total = modular_allreduce(exp, P62) if env.use_dist else exp
+        torch.cuda.synchronize(dev)
+        verified = bool(torch.equal(out, exp_total))
+    elements = float(world) * steps * P * dim
+    value = elements / dt
+    gen_b, comb_b = algorithmic_bytes_per_element(n, k)
+    per_launch_bytes = P * dim * (gen_b + comb_b)
+    gbs = steps * per_launch_bytes / (sum(launch_ms) * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{name}:tile{P}:dim{dim}", {}).get("fused_bytes_per_launch")
+        except Exception:
+            traffic = None
+    kern = "fused_packed_l31_kernel" if w["kind"] == "packed" else "fused_additive_kernel"
+    res = {
+        "metric": "share-gen + clerk-sum elements/sec (mod q)", "value": value, "unit": "elements/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": w["desc"], "name": name, "dim": dim, "tile_participants": P,
+                   "participants_total": world * steps * P, "share_count": n, "secret_count": k,
+                   "privacy_threshold": t, "modulus": P62, "randomness": "on-device ChaCha20 (sda-drbg-v1)",
+                   "row_stride_elements": Bs,
+                   "schedule": "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid "
+                               "(shares materialised in HBM by one launch, read back by the next); K+1 launches for K tiles",
+                   "parallelism": f"participants sharded x{world}, one modular reduce at the end"},
+        "roofline": {"bound": "hbm", "kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": all_ms,
+                     "launches": steps + 1, "both_roles_launch_ms": full_ms,
+                     "first_launch_ms_share_gen_only": launch_ms[0], "last_launch_ms_clerk_sum_only": launch_ms[-1],
+                     "note": "one launch = share-gen of a tile (8 + 8n/k B/element) + clerk-sum of the previous tile "
+                             "(8n/k B/element); K tiles take K+1 launches (the first only generates, the last only "
+                             "sums), achieved = K x algorithmic_bytes_per_launch / sum of the K+1 launch durations"},
+        "path_roofline": {"bytes_per_element": gen_b + comb_b,
+                          "achieved_GBps": value / world * (gen_b + comb_b) / 1e9,
+                          "frac_of_hbm_peak": value / world * (gen_b + comb_b) / 1e9 / HBM_PEAK_GBS},
+        "verified_reconstruct_equals_sum": verified,
+    }
+    del secrets, shares, sums, total
+    torch.cuda.empty_cache()
+    return res
+
+
 def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=True):
     """K timed steps of workload `name`; returns the metric dict (valid on every rank)."""
     torch, dist, capi, lib, dev = env.torch, env.dist, env.capi, env.lib, env.dev
@@ -285,6 +412,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: share-gen of tile i+1 runs concurrently with clerk-sum of tile i (two streams, "
                          "double-buffered shares, clerk-sum capped at 2 workgroups per CU); 0: one stream, serial")
+    ap.add_argument("--schedule", default="fused", choices=["serial", "fused"],
+                    help="serial: share-gen launch then clerk-sum launch per tile; fused: one dual-role launch per "
+                         "step (tile i generated while tile i-1 is summed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-additional", action="store_true", help="skip the short config-2 (additive) run")
@@ -294,13 +424,18 @@ def main():
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     env = Env()
-    line = measure(env, args.workload, args.dim, args.tile, args.steps, args.warmup, args.row_align, args.overlap,
-                   verify=not args.no_verify)
+    def run(name, steps, warmup):
+        if args.schedule == "fused" and not args.overlap:
+            return measure_fused(env, name, args.dim, args.tile, steps, warmup, args.row_align, verify=not args.no_verify)
+        return measure(env, name, args.dim, args.tile, steps, warmup, args.row_align, args.overlap, verify=not args.no_verify)
+
+    line = run(args.workload, args.steps, args.warmup)
     if env.world == 1 and not args.no_additional and args.workload == "packed":
         # BASELINE config 2 (additive 3-way, 10k participants = 5 steps of the 2000-participant tile)
-        add = measure(env, "additive", args.dim, args.tile, 5, 2, args.row_align, 0, verify=not args.no_verify)
+        add = run("additive", 5, 2)
         line["additional_workloads"] = {"additive": {k: add[k] for k in ("value", "unit", "ms_per_step", "config", "kernels",
-                                                                          "path_roofline", "verified_reconstruct_equals_sum")}}
+                                                                          "roofline", "path_roofline",
+                                                                          "verified_reconstruct_equals_sum") if k in add}}
     if env.rank == 0:
         if not args.no_cpu_baseline and env.world == 1:
             line["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.dim)

@@ -218,6 +218,20 @@ int sda_share_combiner_finish_dev(sda_share_combiner_t* c, int64_t* d_out, void*
  * tile) keep the remaining wave slots, so the two overlap (measured +6 % on BASELINE config 3). */
 int sda_share_combiner_set_residency(sda_share_combiner_t* c, unsigned max_workgroups_per_cu);
 
+/* Software-pipelined step (the performance form of generate_batch_dev + combiner update_dev): ONE
+ * dual-role launch generates tile i+1's shares into d_out while the clerk sums of tile i's shares
+ * (d_prev, written by the previous call, SAME layout and strides as d_out) are accumulated into `c`.
+ * Share generation is VALU-bound and the clerk sum HBM-bound, so interleaving their workgroups in one grid
+ * overlaps the two; the shares are still materialised in HBM and read back.  `c` must have been begun with
+ * jobs = share_count and dimension = batches.  participants == 0 -> clerk-sum only (last tile);
+ * prev_participants == 0 -> generation only (first tile).  Randomness: the on-device CSPRNG, stream ids
+ * first_participant + p - identical shares to sda_share_generator_generate_batch_dev. */
+int sda_share_generator_generate_combine_dev(sda_share_generator_t* g, sda_share_combiner_t* c,
+                                             const int64_t* d_secrets, size_t participants, size_t len,
+                                             size_t secrets_stride, uint64_t first_participant,
+                                             int64_t* d_out, size_t out_stride_participant, size_t out_stride_clerk,
+                                             const int64_t* d_prev, size_t prev_participants, void* stream);
+
 /* host-buffer streaming form (tiles are uploaded, accumulated, discarded) */
 int sda_share_combiner_begin(sda_share_combiner_t* c, size_t dimension);
 int sda_share_combiner_update(sda_share_combiner_t* c, const int64_t* shares, size_t n_rows,

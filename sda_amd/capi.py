@@ -81,6 +81,9 @@ SIGNATURES = {
     "sda_share_generator_generate_batch_dev": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                                          C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p,
                                                          C.c_size_t, C.c_size_t, C.c_void_p]),
+    "sda_share_generator_generate_combine_dev": (C.c_int, [_H, _H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64,
+                                                           C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                           C.c_void_p]),
     "sda_share_combiner_new": (C.c_int, [_SS, _HP]),
     "sda_share_combiner_free": (None, [_H]),
     "sda_share_combiner_combine": (C.c_int, [_H, c_i64pp, c_sizep, C.c_size_t, c_i64p, C.c_size_t, c_sizep]),

@@ -177,6 +177,15 @@ class ShareGenerator(_Handle):
             first_participant, d_out, out_stride_participant, out_stride_clerk, stream or None))
 
 
+    def generate_combine_dev(self, combiner: "ShareCombiner", d_secrets: int, participants: int, length: int,
+                             secrets_stride: int, d_out: int, out_stride_participant: int, out_stride_clerk: int,
+                             d_prev: int = 0, prev_participants: int = 0, first_participant: int = 0, stream: int = 0):
+        """software-pipelined step: generate this tile while the previous tile (d_prev) is summed into `combiner`"""
+        check(self._lib.sda_share_generator_generate_combine_dev(
+            self._h, combiner._h, d_secrets or None, participants, length, secrets_stride, first_participant,
+            d_out or None, out_stride_participant, out_stride_clerk, d_prev or None, prev_participants, stream or None))
+
+
 class ShareCombiner(_Handle):
     """sharing/mod.rs:23-25; impl combiner.rs:15-29."""
     _free = "sda_share_combiner_free"

@@ -87,6 +87,19 @@ hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const in
 hipError_t launch_combine_finish(const uint64_t* d_acc_lo, const int64_t* d_acc_hi, size_t count,
                                  const ModParams& mod, int64_t* d_out, hipStream_t s);
 
+// ---- dual-role launch: share generation of one tile + clerk-sum of the previous tile in ONE grid ----------
+// d_prev holds the previous tile's shares in the SAME layout as L.out (job stride = L.out_stride_clerk, row
+// stride = L.out_stride_participant), prev_rows participants; L.participants may be 0 (clerk-sum only) and
+// d_prev may be null (generation only).  *fused = false (and nothing launched) when the layout or the shape
+// rules the fused form out - the caller then issues the two ordinary launches.
+hipError_t launch_fused_packed_l31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                   const L31Params& lp, const MatArg& M, const DrbgKey& key, int rounds,
+                                   uint64_t* acc_lo, int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows,
+                                   size_t jobs, size_t dimension, hipStream_t s, bool* fused);
+hipError_t launch_fused_additive(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,
+                                 uint64_t* acc_lo, int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows,
+                                 size_t jobs, size_t dimension, hipStream_t s, bool* fused);
+
 // ---- packed reconstruct (batched.rs:68-97 + tss reconstruct as a k x n' Lagrange matrix) ------------
 hipError_t launch_packed_reconstruct(const int64_t* d_shares, size_t row_stride, uint32_t n_rows,
                                      uint32_t k, size_t batches, size_t dimension,

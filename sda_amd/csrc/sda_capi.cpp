@@ -643,6 +643,45 @@ extern "C" int sda_share_combiner_update_dev(sda_share_combiner_t* c, const int6
     return SDA_OK;
 }
 
+// software-pipelined step: tile i+1 is generated while tile i is summed, in one dual-role launch
+extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g, sda_share_combiner_t* c,
+                                                        const int64_t* d_secrets, size_t participants, size_t len,
+                                                        size_t secrets_stride, uint64_t first_participant,
+                                                        int64_t* d_out, size_t out_stride_participant,
+                                                        size_t out_stride_clerk, const int64_t* d_prev,
+                                                        size_t prev_participants, void* stream) {
+    if (!g || !c) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (!c->begun) return fail(SDA_ERR_STATE, "combiner: update before begin");
+    const size_t B = (size_t)sda_share_generator_batch_count(g, len);
+    if (c->jobs != g->n || c->dimension != B)
+        return fail(SDA_ERR_INVALID_ARGUMENT, "combiner must have been begun with jobs = share_count (%u) and dimension = batches (%zu)", g->n, B);
+    if (participants > 0 && (!d_secrets || !d_out)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (prev_participants > 0 && !d_prev) return fail(SDA_ERR_INVALID_ARGUMENT, "d_prev is NULL");
+    SDA_TRY(g->ctx.use());
+    hipStream_t s = g->ctx.pick(stream);
+    GenLayout L;
+    L.secrets = d_secrets; L.secrets_stride = secrets_stride; L.rand = nullptr; L.rand_stride = 0;
+    L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
+    L.participants = len ? participants : 0; L.len = len; L.first_participant = first_participant;
+    bool fused = false;
+    if (g->additive) {
+        HIP_TRY(launch_fused_additive(L, g->n, g->mod, g->drbg.key, g->drbg.rounds, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(),
+                                      d_prev, prev_participants, c->jobs, c->dimension, s, &fused));
+    } else if (g->l31) {
+        HIP_TRY(launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, g->drbg.key, g->drbg.rounds,
+                                        c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
+                                        c->dimension, s, &fused));
+    }
+    if (fused) return SDA_OK;
+    // layouts / shapes the dual-role kernel does not cover: the two ordinary launches, same result
+    if (prev_participants > 0)
+        SDA_TRY(sda_share_combiner_update_dev(c, d_prev, out_stride_clerk, prev_participants, out_stride_participant, stream));
+    if (participants > 0 && len > 0)
+        SDA_TRY(sda_share_generator_generate_batch_dev(g, d_secrets, participants, len, secrets_stride, nullptr, 0, first_participant,
+                                                       d_out, out_stride_participant, out_stride_clerk, stream));
+    return SDA_OK;
+}
+
 extern "C" int sda_share_combiner_set_residency(sda_share_combiner_t* c, unsigned max_workgroups_per_cu) {
     if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
     if (max_workgroups_per_cu > 8) return fail(SDA_ERR_INVALID_ARGUMENT, "max_workgroups_per_cu must be 0 (no cap) .. 8");

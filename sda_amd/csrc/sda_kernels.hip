@@ -118,10 +118,10 @@ __device__ __forceinline__ void split_item(uint64_t item, uint64_t chunks, uint6
 //     shares 0..n-2 are the uniform draws, share n-1 = secret - sum(draws) mod q  (additive.rs:42-47)
 // =================================================================================================
 template <int ROUNDS, bool VEC>
-__global__ __launch_bounds__(kThreads) void additive_gen_kernel(GenLayout L, uint32_t n, ModParams mod,
-                                                                DrbgKey key, uint64_t chunks) {
+__device__ __forceinline__ void additive_gen_body(const GenLayout& L, uint32_t n, const ModParams& mod,
+                                                  const DrbgKey& key, uint64_t chunks, uint64_t item) {
     uint64_t p, chunk;
-    split_item(blockIdx.x, chunks, p, chunk);
+    split_item(item, chunks, p, chunk);
     const uint64_t pair = chunk * kThreads + threadIdx.x;
     const uint64_t b0 = 2 * pair;
     const bool in0 = b0 < L.len, in1 = b0 + 1 < L.len;
@@ -165,6 +165,12 @@ __global__ __launch_bounds__(kThreads) void additive_gen_kernel(GenLayout L, uin
         if (in0) o[0] = (int64_t)s0;
         if (in1) o[1] = (int64_t)s1;
     }
+}
+
+template <int ROUNDS, bool VEC>
+__global__ __launch_bounds__(kThreads) void additive_gen_kernel(GenLayout L, uint32_t n, ModParams mod,
+                                                                DrbgKey key, uint64_t chunks) {
+    additive_gen_body<ROUNDS, VEC>(L, n, mod, key, chunks, blockIdx.x);
 }
 
 // =================================================================================================
@@ -340,12 +346,12 @@ __device__ __forceinline__ uint64_t l31_dot(const uint64_t* __restrict__ row, co
 }
 
 template <int K, int T, int ROUNDS, bool VEC>
-__global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, uint32_t n, ModParams mod,
-                                                                  L31Params lp, MatArg M, DrbgKey key,
-                                                                  uint64_t chunks, uint64_t batches) {
+__device__ __forceinline__ void packed_gen_l31_body(const GenLayout& L, uint32_t n, const ModParams& mod,
+                                                    const L31Params& lp, const MatArg& M, const DrbgKey& key,
+                                                    uint64_t chunks, uint64_t batches, uint64_t item) {
     constexpr int KT = K + T;
     uint64_t p, chunk;
-    split_item(blockIdx.x, chunks, p, chunk);
+    split_item(item, chunks, p, chunk);
     const uint64_t pair = chunk * kThreads + threadIdx.x;
     const uint64_t b0 = 2 * pair;
     const bool in0 = b0 < batches, in1 = b0 + 1 < batches;
@@ -404,6 +410,13 @@ __global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, u
             if (in1) o[1] = (int64_t)b;
         }
     }
+}
+
+template <int K, int T, int ROUNDS, bool VEC>
+__global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, uint32_t n, ModParams mod,
+                                                                  L31Params lp, MatArg M, DrbgKey key,
+                                                                  uint64_t chunks, uint64_t batches) {
+    packed_gen_l31_body<K, T, ROUNDS, VEC>(L, n, mod, lp, M, key, chunks, batches, blockIdx.x);
 }
 
 // any-shape fallback: one lane = one batch, matrix and randomness read from global memory
@@ -475,18 +488,16 @@ __device__ __forceinline__ void acc_atomic_add(uint64_t* lo_p, int64_t* hi_p, ui
 }
 
 template <bool VEC, int UNROLL>
-__global__ __launch_bounds__(kThreads) void combine_update_kernel(uint64_t* __restrict__ acc_lo,
-                                                                  int64_t* __restrict__ acc_hi,
-                                                                  const int64_t* __restrict__ shares,
-                                                                  size_t job_stride, size_t n_rows,
-                                                                  size_t row_stride, size_t dimension,
-                                                                  size_t rows_per_split, bool atomic) {
-    const size_t pair = (size_t)blockIdx.x * kThreads + threadIdx.x;
+__device__ __forceinline__ void combine_body(uint64_t* __restrict__ acc_lo, int64_t* __restrict__ acc_hi,
+                                             const int64_t* __restrict__ shares, size_t job_stride, size_t n_rows,
+                                             size_t row_stride, size_t dimension, size_t rows_per_split, bool atomic,
+                                             size_t bx, size_t by, size_t bz) {
+    const size_t pair = bx * kThreads + threadIdx.x;
     const size_t c0 = 2 * pair;
     if (c0 >= dimension) return;
     const bool two = c0 + 1 < dimension;
-    const size_t job = blockIdx.y;
-    const size_t r_begin = (size_t)blockIdx.z * rows_per_split;
+    const size_t job = by;
+    const size_t r_begin = bz * rows_per_split;
     size_t r_end = r_begin + rows_per_split;
     if (r_end > n_rows) r_end = n_rows;
     const int64_t* base = shares + job * job_stride + c0;
@@ -528,6 +539,73 @@ __global__ __launch_bounds__(kThreads) void combine_update_kernel(uint64_t* __re
             acc_lo[idx + 1] = nl; acc_hi[idx + 1] = h;
         }
     }
+}
+
+template <bool VEC, int UNROLL>
+__global__ __launch_bounds__(kThreads) void combine_update_kernel(uint64_t* __restrict__ acc_lo,
+                                                                  int64_t* __restrict__ acc_hi,
+                                                                  const int64_t* __restrict__ shares,
+                                                                  size_t job_stride, size_t n_rows,
+                                                                  size_t row_stride, size_t dimension,
+                                                                  size_t rows_per_split, bool atomic) {
+    combine_body<VEC, UNROLL>(acc_lo, acc_hi, shares, job_stride, n_rows, row_stride, dimension, rows_per_split, atomic,
+                              blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// =================================================================================================
+// Dual-role launch: software pipelining across tiles inside ONE grid.
+// Share generation is VALU-bound, the clerk sum HBM-bound; run back to back each leaves the other
+// resource idle, and two streams do not mix well (the long-lived clerk-sum workgroups take every wave
+// slot the short-lived share-gen workgroups free).  Here one grid carries both kinds of workgroup at a
+// fixed ratio - position c * period is the c-th clerk-sum item of tile i (a column block x job x row
+// split, accumulated with carry-propagating atomics), every other position a share-gen chunk of tile
+// i+1 - so every CU holds a steady mix and the VALU and HBM phases overlap by construction.  The
+// shares are still written to HBM by one tile's launch and read back by the next one's (the unfused
+// contract of SURVEY.md 8d); only the schedule changes.
+// =================================================================================================
+#ifndef SDA_FUSE_UNROLL
+#define SDA_FUSE_UNROLL 16
+#endif
+struct FuseArgs {
+    uint64_t* acc_lo; int64_t* acc_hi; const int64_t* prev;       // clerk-sum of the previous tile
+    size_t job_stride, n_rows, row_stride, dimension, rows_per_split;
+    uint32_t col_blocks, jobs, splits;
+    uint64_t n_gen, n_comb, period, grid;                          // grid >= n_gen + n_comb
+};
+
+__device__ __forceinline__ bool fuse_role(const FuseArgs& F, uint64_t b, uint64_t& idx) {   // true: clerk-sum item
+    const uint64_t q = b / F.period, rem = b - q * F.period;
+    if (rem == 0 && q < F.n_comb) { idx = q; return true; }
+    const uint64_t before = q + (rem ? 1 : 0);                      // clerk-sum positions below b
+    idx = b - (before < F.n_comb ? before : F.n_comb);
+    return false;
+}
+
+__device__ __forceinline__ void fuse_combine(const FuseArgs& F, uint64_t q) {
+    const size_t bx = q % F.col_blocks, t = q / F.col_blocks;
+    combine_body<true, SDA_FUSE_UNROLL>(F.acc_lo, F.acc_hi, F.prev, F.job_stride, F.n_rows, F.row_stride, F.dimension, F.rows_per_split,
+                          F.splits > 1, bx, t % F.jobs, t / F.jobs);
+}
+
+// role of workgroup b: true = done (clerk-sum item or idle surplus position), false = share-gen chunk idx
+__device__ __forceinline__ bool fuse_dispatch(const FuseArgs& F, uint64_t b, uint64_t& idx) {
+    if (fuse_role(F, b, idx)) { fuse_combine(F, idx); return true; }
+    return idx >= F.n_gen;
+}
+
+template <int K, int T, int ROUNDS>
+__global__ __launch_bounds__(kThreads) void fused_packed_l31_kernel(GenLayout L, uint32_t n, ModParams mod, L31Params lp,
+                                                                    MatArg M, DrbgKey key, uint64_t chunks,
+                                                                    uint64_t batches, FuseArgs F) {
+    uint64_t idx;
+    if (!fuse_dispatch(F, blockIdx.x, idx)) packed_gen_l31_body<K, T, ROUNDS, true>(L, n, mod, lp, M, key, chunks, batches, idx);
+}
+
+template <int ROUNDS>
+__global__ __launch_bounds__(kThreads) void fused_additive_kernel(GenLayout L, uint32_t n, ModParams mod, DrbgKey key,
+                                                                  uint64_t chunks, FuseArgs F) {
+    uint64_t idx;
+    if (!fuse_dispatch(F, blockIdx.x, idx)) additive_gen_body<ROUNDS, true>(L, n, mod, key, chunks, idx);
 }
 
 __global__ __launch_bounds__(kThreads) void combine_finish_kernel(const uint64_t* __restrict__ acc_lo,
@@ -975,6 +1053,77 @@ hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const in
     else
         combine_update_kernel<false, 1><<<grid, dim3(kThreads), 0, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows,
                                                                         row_stride, dimension, rows_per_split, atomic);
+    return hipGetLastError();
+}
+
+// ---- dual-role launch ----------------------------------------------------------------------------------
+static bool fuse_plan(const GenLayout& L, uint64_t chunks, uint64_t* acc_lo, int64_t* acc_hi, const int64_t* d_prev,
+                      size_t prev_rows, size_t jobs, size_t dimension, FuseArgs& F) {
+    F.acc_lo = acc_lo; F.acc_hi = acc_hi; F.prev = d_prev;
+    F.job_stride = L.out_stride_clerk; F.row_stride = L.out_stride_participant;
+    F.n_rows = prev_rows; F.dimension = dimension; F.jobs = (uint32_t)jobs;
+    F.n_gen = chunks * L.participants;
+    F.col_blocks = (uint32_t)ceil_div(ceil_div(dimension, 2), kThreads);
+    const bool have_comb = d_prev && prev_rows > 0 && jobs > 0 && dimension > 0;
+    // clerk-sum items of up to 512 rows (measured best of 16..2000: 64 and fewer cost 5 % in atomics, one item per
+    // column block loses the even mix)
+    uint64_t splits = have_comb ? ceil_div(prev_rows, 512) : 1;
+    if (splits > 64) splits = 64;
+    F.rows_per_split = have_comb ? ceil_div(prev_rows, splits) : 1;
+    splits = have_comb ? ceil_div(prev_rows, F.rows_per_split) : 1;
+    F.splits = (uint32_t)splits;
+    F.n_comb = have_comb ? (uint64_t)F.col_blocks * jobs * splits : 0;
+    // XCD-aware role map: workgroup b runs on XCD b % 8, so the period must be odd or the clerk-sum items
+    // would pile up on a few XCDs (a period of 16 put ALL of them on XCD 0: 3x slower than serial)
+    F.period = F.n_comb ? F.n_gen / F.n_comb + 1 : 1;
+    if (F.n_comb && (F.period & 1) == 0) F.period = F.period > 2 ? F.period - 1 : 3;
+    F.grid = F.n_gen + F.n_comb;
+    if (F.n_comb && (F.n_comb - 1) * F.period + 1 > F.grid) F.grid = (F.n_comb - 1) * F.period + 1;   // surplus positions idle
+    if (F.grid == 0 || F.grid > kMaxBlocks) return false;
+    if (F.n_gen && !gen_vec_ok(L, 0)) return false;
+    if (have_comb && !(aligned16(d_prev) && (F.job_stride % 2 == 0) && (F.row_stride % 2 == 0))) return false;
+    return true;
+}
+
+
+template <int K, int T, int ROUNDS>
+static hipError_t fused_l31_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const L31Params& lp, const MatArg& M,
+                               const DrbgKey& key, const FuseArgs& F, uint64_t chunks, uint64_t batches, hipStream_t s) {
+    fused_packed_l31_kernel<K, T, ROUNDS><<<dim3((unsigned)F.grid), dim3(kThreads), 0, s>>>(L, n, mod, lp, M, key,
+                                                                                                       chunks, batches, F);
+    return hipGetLastError();
+}
+
+// the shapes the dual-role launch is compiled for (the BASELINE ones and their tss-valid neighbours)
+#define SDA_FUSED_SHAPES(X) X(3, 1) X(3, 4) X(8, 2) X(8, 7)
+
+hipError_t launch_fused_packed_l31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                   const L31Params& lp, const MatArg& M, const DrbgKey& key, int rounds, uint64_t* acc_lo,
+                                   int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs, size_t dimension,
+                                   hipStream_t s, bool* fused) {
+    *fused = false;
+    if (rounds != 20 || L.rand) return hipSuccess;
+    const uint64_t batches = ceil_div(L.len, k);
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    FuseArgs F;
+    if (!fuse_plan(L, chunks, acc_lo, acc_hi, d_prev, prev_rows, jobs, dimension, F)) return hipSuccess;
+#define X(K_, T_) if (k == K_ && t == T_) { *fused = true; return fused_l31_kt<K_, T_, 20>(L, n, mod, lp, M, key, F, chunks, batches, s); }
+    SDA_FUSED_SHAPES(X)
+#undef X
+    return hipSuccess;
+}
+
+hipError_t launch_fused_additive(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,
+                                 uint64_t* acc_lo, int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs,
+                                 size_t dimension, hipStream_t s, bool* fused) {
+    *fused = false;
+    if (rounds != 20 || L.rand) return hipSuccess;
+    const uint64_t chunks = ceil_div(ceil_div(L.len, 2), kThreads);
+    FuseArgs F;
+    if (!fuse_plan(L, chunks, acc_lo, acc_hi, d_prev, prev_rows, jobs, dimension, F)) return hipSuccess;
+    *fused = true;
+   
+    fused_additive_kernel<20><<<dim3((unsigned)F.grid), dim3(kThreads), 0, s>>>(L, n, mod, key, chunks, F);
     return hipGetLastError();
 }
 
