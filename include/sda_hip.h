@@ -358,10 +358,13 @@ int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t 
  * sealed-box payloads straight into the accumulating combiner - decode tile -> clerk-sum update ->
  * discard - instead of materialising all P decoded vectors (clerk.rs:80-86).
  *   _dev : `rows` encoded vectors in one device byte stream (row r = d_bytes[off[r] .. off[r+1])), each
- *          must decode to exactly the combiner's dimension; d_status as in sda_varint_decode_dev.
+ *          must decode to exactly the combiner's dimension; d_status as in sda_varint_decode_dev (if it
+ *          comes back non-zero the running sums are invalid).  rows must be a multiple of the jobs the
+ *          combiner was begun with, job-major: rows [j*rows/jobs, (j+1)*rows/jobs) belong to job j.  From
+ *          1536 rows on nothing is materialised: the rows are streamed straight into the accumulators.
  *   host : ONE participant's encoded vector; a wrong value count -> SDA_ERR_WRONG_DIMENSION
  *          ("Wrong dimension", combiner.rs:21), a malformed stream -> SDA_ERR_INVALID_ARGUMENT.
- * Call sda_share_combiner_begin[_dev] first (jobs == 1) and ..._finish[_dev] at the end. */
+ * Call sda_share_combiner_begin[_dev] first (the host form needs jobs == 1) and ..._finish[_dev] at the end. */
 int sda_share_combiner_update_varint_dev(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* d_bytes,
                                          size_t n_bytes, const uint64_t* d_row_offsets, size_t rows,
                                          uint32_t* d_status, void* stream);

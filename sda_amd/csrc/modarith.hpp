@@ -120,6 +120,23 @@ SDA_HD uint64_t mod_i128(uint64_t lo, int64_t hi, uint64_t m, uint64_t mu) {
     return (neg && r != 0) ? m - r : r;
 }
 
+#if defined(__HIPCC__)
+// ---- exact 128-bit column accumulators (lo u64, hi i64 two's complement) -------------------------------
+SDA_D void acc_add(uint64_t& lo, int64_t& hi, int64_t v) {
+    const uint64_t nl = lo + (uint64_t)v;
+    hi += (v >> 63) + (nl < lo ? 1 : 0);
+    lo = nl;
+}
+// accumulator in memory += (hi:lo), carry propagated from the value the low-word atomic returns
+SDA_D void acc_atomic_add(uint64_t* lo_p, int64_t* hi_p, uint64_t lo, int64_t hi) {
+    if (lo != 0) {
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(lo_p), (unsigned long long)lo);
+        if (old + lo < old) hi += 1;
+    }
+    if (hi != 0) atomicAdd(reinterpret_cast<unsigned long long*>(hi_p), (unsigned long long)hi);
+}
+#endif
+
 // ---- Lemire uniform sampling in [0, m) from a 64-bit word ------------------------------------
 // returns true (accepted) and the value; rejected iff lo(x*m) < (2^64 mod m) = lemire_thr
 SDA_HD bool lemire_sample(uint64_t x, uint64_t m, uint64_t lemire_thr, uint64_t& out) {

@@ -1186,6 +1186,18 @@ static int varint_count_scan(sda_varint_codec_t* c, const uint8_t* d_bytes, size
     return SDA_OK;
 }
 
+// Row streaming needs a wave per row to keep the chip busy; fewer rows take the three-pass scan form,
+// which parallelises inside a row.  SDA_VARINT_PATH=stream|scan pins one form (A/B runs, parity tests).
+static bool varint_use_stream(size_t rows) {
+    if (const char* e = getenv("SDA_VARINT_PATH")) {
+        if (!strcmp(e, "stream")) return rows > 0;
+        if (!strcmp(e, "scan")) return false;
+    }
+    // measured (profiles/r01/wire_bench.json, rows of 349526 values): 1024 rows - decode equal, fused clerk sum 100
+    // vs 123 Gvalues/s; 2000 rows - 229 vs 153 and 195 vs 125; 16000 rows - 260 vs 156 and 304 vs 127
+    return rows >= 1536;
+}
+
 extern "C" int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t n_bytes,
                                      const uint64_t* d_row_offsets, size_t rows, size_t len, int64_t* d_values,
                                      size_t row_stride, uint32_t* d_status, void* stream) {
@@ -1195,6 +1207,10 @@ extern "C" int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_byt
     SDA_TRY(c->ctx.use());
     hipStream_t s = c->ctx.pick(stream);
     if (n_bytes > 0 && (!d_bytes || !d_values)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (varint_use_stream(rows)) {       // many rows: one wave streams each row, the bytes are read once
+        HIP_TRY(launch_varint_stream_decode(d_bytes, n_bytes, d_row_offsets, rows, len, row_stride, d_values, d_status, s));
+        return SDA_OK;
+    }
     SDA_TRY(varint_count_scan(c, d_bytes, n_bytes, s));
     HIP_TRY(launch_varint_decode(d_bytes, n_bytes, c->d_offs.as<uint64_t>(), rows, len, row_stride, d_values, d_status, s));
     HIP_TRY(launch_varint_rowcheck(d_bytes, n_bytes, d_row_offsets, rows, len, c->d_offs.as<uint64_t>(), d_status, s));
@@ -1255,20 +1271,31 @@ extern "C" int sda_share_combiner_update_varint_dev(sda_share_combiner_t* c, sda
                                                     size_t rows, uint32_t* d_status, void* stream) {
     if (!c || !codec) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
     if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
-    if (c->jobs != 1) return fail(SDA_ERR_STATE, "the wire-format update works on a single job (begin with jobs == 1)");
-    if (rows == 0) return SDA_OK;
-    const size_t L = c->dimension, stride = L + (L & 1);
+    if (rows == 0 || c->jobs == 0) return SDA_OK;
+    if (rows % c->jobs) return fail(SDA_ERR_INVALID_ARGUMENT, "rows (%zu) must be a multiple of the combiner's jobs (%zu): job-major rows", rows, c->jobs);
+    if (!d_status) return fail(SDA_ERR_INVALID_ARGUMENT, "d_status is NULL");
+    if (!d_row_offsets && rows > 1) return fail(SDA_ERR_INVALID_ARGUMENT, "d_row_offsets is required for rows > 1");
+    if (n_bytes > 0 && !d_bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    const size_t L = c->dimension, stride = L + (L & 1), rows_per_job = rows / c->jobs;
     SDA_TRY(c->ctx.use());
+    if (varint_use_stream(rows)) {
+        // many rows: 16 rows of a job per workgroup, decoded values summed in an LDS column window - no decoded tile
+        HIP_TRY(launch_varint_stream_combine(d_bytes, n_bytes, d_row_offsets, c->jobs, rows_per_job, L, c->acc.lo.as<uint64_t>(),
+                                             c->acc.hi.as<int64_t>(), d_status, c->ctx.pick(stream)));
+        if (L == 0) HIP_TRY(launch_varint_stream_decode(d_bytes, n_bytes, d_row_offsets, rows, 0, 0, nullptr, d_status, c->ctx.pick(stream)));
+        return SDA_OK;
+    }
     SDA_TRY(c->tile.reserve((rows * stride ? rows * stride : 1) * 8));
     SDA_TRY(sda_varint_decode_dev(codec, d_bytes, n_bytes, d_row_offsets, rows, L, c->tile.as<int64_t>(), stride, d_status, stream));
     if (L == 0) return SDA_OK;
-    return sda_share_combiner_update_dev(c, c->tile.as<int64_t>(), 0, rows, stride, stream);
+    return sda_share_combiner_update_dev(c, c->tile.as<int64_t>(), rows_per_job * stride, rows_per_job, stride, stream);
 }
 
 extern "C" int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* bytes,
                                                 size_t n_bytes) {
     if (!c || !codec) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
     if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (c->jobs != 1) return fail(SDA_ERR_STATE, "the host form takes one participant's vector for ONE job (begin with jobs == 1)");
     if (n_bytes > 0 && !bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
     SDA_TRY(c->ctx.use());
     hipStream_t s = c->ctx.stream;

@@ -473,19 +473,7 @@ __global__ __launch_bounds__(kThreads) void drbg_fill_kernel(int64_t* out, size_
 // K3  clerk combine: exact 128-bit column sums over rows, reduced once at finish.
 //     One lane = two adjacent columns; UNROLL independent 16-byte loads in flight.
 // =================================================================================================
-__device__ __forceinline__ void acc_add(uint64_t& lo, int64_t& hi, int64_t v) {
-    const uint64_t nl = lo + (uint64_t)v;
-    hi += (v >> 63) + (nl < lo ? 1 : 0);
-    lo = nl;
-}
-
-__device__ __forceinline__ void acc_atomic_add(uint64_t* lo_p, int64_t* hi_p, uint64_t lo, int64_t hi) {
-    if (lo != 0) {
-        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(lo_p), (unsigned long long)lo);
-        if (old + lo < old) hi += 1;
-    }
-    if (hi != 0) atomicAdd(reinterpret_cast<unsigned long long*>(hi_p), (unsigned long long)hi);
-}
+// acc_add / acc_atomic_add: modarith.hpp
 
 template <bool VEC, int UNROLL>
 __device__ __forceinline__ void combine_body(uint64_t* __restrict__ acc_lo, int64_t* __restrict__ acc_hi,

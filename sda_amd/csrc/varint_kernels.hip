@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "kernels.hpp"
+#include "modarith.hpp"
 
 namespace sda {
 
@@ -339,6 +340,280 @@ __global__ __launch_bounds__(kVT) void varint_rowcheck_kernel(const uint8_t* __r
     if (cnt != len && lead) atomicOr(status, SDA_VARINT_ROW_COUNT);
 }
 
+// ---- single-pass row streaming ----------------------------------------------------------------------
+// Every encoded vector (row) is its own message with a known byte range, so the only sequential dependence is
+// inside a row.  One WAVE streams one row in fixed 1 KiB chunks (64 lanes x 16 B) laid on the 16-byte grid below
+// the row start: chunk addresses do not depend on the content, so the next chunks are prefetched into registers
+// while the current one is decoded; what is carried from chunk to chunk is the column index, the continuation
+// bitmap of the last 16 bytes and those 16 bytes themselves (the halo a value crossing the chunk boundary needs).
+// The bytes are read ONCE (the three-pass form reads them twice and needs the block scan in between).
+static constexpr int kStreamWaves = 4;                 // rows per workgroup
+static constexpr int kStreamDepth = 4;                 // chunks in flight per wave
+static constexpr int kStreamTile = 16 + 64 * 16 + 16;  // halo | chunk | read slack, per wave
+
+
+// bit k = MSB of byte k.  (m >> 7) has the four flags at bits 0, 8, 16, 24; the multiplier moves them to bits
+// 28..31 (partial products below bit 28 never collide, so nothing carries in).
+__device__ __forceinline__ uint32_t cont_bits16(const uint4& v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r |= ((((w[k] & 0x80808080u) >> 7) * 0x10204080u) >> 28) << (4 * k);
+    return r;
+}
+
+// wave64 inclusive scan with DPP row shifts / broadcasts (no LDS crossbar, no waits)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t x, uint32_t src) {
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    uint32_t x = dpp_add<0x111, 0xf, 0xf>(v, v);      // row_shr:1
+    x = dpp_add<0x112, 0xf, 0xf>(x, v);               // row_shr:2
+    x = dpp_add<0x113, 0xf, 0xf>(x, v);               // row_shr:3  -> lanes hold the sum of up to 4 neighbours
+    x = dpp_add<0x114, 0xf, 0xe>(x, x);               // row_shr:4, banks 1-3
+    x = dpp_add<0x118, 0xf, 0xc>(x, x);               // row_shr:8, banks 2-3 -> inclusive scan inside each row of 16
+    x = dpp_add<0x142, 0xa, 0xf>(x, x);               // row_bcast:15 into rows 1 and 3
+    x = dpp_add<0x143, 0xc, 0xf>(x, x);               // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// 16 bytes at bytes + rel (rel may reach 15 bytes below the buffer: same 16-byte granule as its first byte).
+// Addressed from the kernel argument so that it stays a GLOBAL load: a flat load would also count as an LDS
+// operation and every LDS wait would then drain the prefetch queue.
+__device__ __forceinline__ uint4 stream_load(const uint8_t* __restrict__ bytes, int64_t rel, int64_t end_rel) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (rel < end_rel) {                                           // aligned, and the granule holds a byte of the row
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bytes + rel));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+}
+
+// One value out of the LDS tile: `start` = tile coordinate of its first byte, nb = 1..10 bytes.
+__device__ __forceinline__ int64_t tile_value(const uint32_t* tile32, int start, int nb) {
+    const uint32_t* t32 = tile32 + (start >> 2);
+    const uint32_t sh = (uint32_t)start & 3u;
+    uint32_t d0 = __builtin_amdgcn_alignbyte(t32[1], t32[0], sh);       // bytes 0..3
+    uint32_t d1 = __builtin_amdgcn_alignbyte(t32[2], t32[1], sh);       // bytes 4..7
+    const uint32_t d2 = __builtin_amdgcn_alignbyte(t32[3], t32[2], sh); // bytes 8..9 (+2 foreign)
+    // squeeze 4 x 7 bits per dword (the MSBs are dropped by the masks)
+    d0 = (d0 & 0x007F007Fu) | ((d0 >> 1) & 0x3F803F80u);
+    d1 = (d1 & 0x007F007Fu) | ((d1 >> 1) & 0x3F803F80u);
+    d0 = (d0 & 0x00003FFFu) | ((d0 >> 2) & 0x0FFFC000u);
+    d1 = (d1 & 0x00003FFFu) | ((d1 >> 2) & 0x0FFFC000u);
+    uint64_t x = (uint64_t)d0 | ((uint64_t)d1 << 28);                   // 56 bits of bytes 0..7
+    const int keep = 7 * (nb < 8 ? nb : 8);                             // bits that belong to this value
+    x = (x << (64 - keep)) >> (64 - keep);
+    const uint32_t top = (nb > 8 ? (d2 & 0x7Fu) : 0u) | (nb > 9 ? (d2 & 0x100u) >> 1 : 0u);   // byte 8, bit 0 of byte 9
+    x |= (uint64_t)top << 56;
+    return (int64_t)((x >> 1) ^ (uint64_t)(-(int64_t)(x & 1)));         // zig-zag
+}
+
+// A row being streamed by one wave.  next_group() decodes up to kStreamDepth chunks and hands every value to
+// sink(column, value); the state between calls is the column index, the continuation bitmap of the last 16 bytes,
+// the halo in the wave's LDS tile and the prefetched chunks.
+struct RowStream {
+    const uint8_t* bytes;
+    int64_t rel0, end_rel;            // this lane's byte offset in chunk 0; end of the row
+    int lo0;                          // bytes of this lane that precede the row in chunk 0 (0..16)
+    uint64_t n_chunks, j0, len, col;
+    uint32_t carry_prev, flags;
+    uint32_t* tile32;
+    uint4 w[kStreamDepth];
+
+    __device__ __forceinline__ void open(const uint8_t* __restrict__ bytes_, uint64_t a, uint64_t b, uint64_t len_, uint8_t* tile) {
+        const int lane = threadIdx.x & 63;
+        bytes = bytes_;
+        const uintptr_t start_addr = (uintptr_t)bytes + a;
+        const uintptr_t base0 = start_addr & ~(uintptr_t)15;
+        n_chunks = ((uintptr_t)bytes + b - base0 + 1023) / 1024;
+        rel0 = (int64_t)(base0 - (uintptr_t)bytes) + lane * 16;
+        end_rel = (int64_t)b;
+        const int64_t before = (int64_t)a - rel0;
+        lo0 = before <= 0 ? 0 : (before >= 16 ? 16 : (int)before);
+        j0 = 0; len = len_; col = 0; carry_prev = 0; flags = 0;   // before the row every byte "terminates"
+        tile32 = reinterpret_cast<uint32_t*>(tile);
+#pragma unroll
+        for (int d = 0; d < kStreamDepth; ++d) w[d] = stream_load(bytes, rel0 + (int64_t)d * 1024, end_rel);
+    }
+    __device__ __forceinline__ bool done() const { return j0 >= n_chunks; }
+
+    template <class Sink>
+    __device__ __forceinline__ void next_group(Sink&& sink) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int d = 0; d < kStreamDepth; ++d) {
+            const uint64_t j = j0 + d;
+            if (j >= n_chunks) continue;                          // wave-uniform
+            uint4 cur = w[d];
+            // Refill the slot only after `cur` has landed: the variable number of stores in the decode loop makes
+            // the compiler wait for EVERY outstanding memory operation (vmcnt(0)) at the first use of `cur`; the
+            // empty asm is that first use, so the wait sits before the new load, which then has a whole chunk's
+            // work to arrive while the other kStreamDepth - 1 slots have long been in flight.
+            asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w));
+            __builtin_amdgcn_sched_barrier(0);
+            w[d] = stream_load(bytes, rel0 + (int64_t)(j + kStreamDepth) * 1024, end_rel);
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t own = cont_bits16(cur), terms = ~own & 0xFFFFu;
+            if (j == 0 || j + 1 >= n_chunks) {                    // wave-uniform: only the edge chunks hold foreign bytes
+                const int64_t q = rel0 + (int64_t)j * 1024;
+                const int lo = j == 0 ? lo0 : 0;
+                const int hi = q >= end_rel ? 0 : (end_rel - q >= 16 ? 16 : (int)(end_rel - q));
+                const uint32_t below_lo = (1u << lo) - 1u;
+                own &= ~below_lo;                                 // bytes before the row stop the look-back
+                terms = ~own & ((1u << hi) - 1u) & ~below_lo & 0xFFFFu;
+            }
+            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_prev, (int)own, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            carry_prev = __builtin_amdgcn_readlane(own, 63);
+            const uint32_t cnt = __builtin_popcount(terms);
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            uint64_t g = col + (incl - cnt);
+            // stage the chunk behind the halo (LDS operations of one wave execute in order)
+            tile32[4 + lane * 4 + 0] = cur.x; tile32[4 + lane * 4 + 1] = cur.y;
+            tile32[4 + lane * 4 + 2] = cur.z; tile32[4 + lane * 4 + 3] = cur.w;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t cont = (own << 16) | prev;
+            uint32_t t = terms;
+            while (t) {
+                const int k = __builtin_ctz(t);
+                t &= t - 1;
+                const int e = 16 + k;
+                const uint32_t below = ~cont & ((1u << e) - 1u);
+                const int prev_term = 31 - __builtin_clz(below | 1u);   // none in the window: nb >= 16, refused either way
+                int nb = e - prev_term;
+                if (nb > 10) { flags |= SDA_VARINT_MALFORMED; nb = 10; }
+                const int64_t v = tile_value(tile32, 16 + lane * 16 + k - (nb - 1), nb);
+                if (g < len) sink(g, v);
+                ++g;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 63) { tile32[0] = cur.x; tile32[1] = cur.y; tile32[2] = cur.z; tile32[3] = cur.w; }   // next halo
+            col += total;
+        }
+        j0 += kStreamDepth;
+    }
+    // row verdict once the stream is exhausted
+    __device__ __forceinline__ void close(uint32_t* __restrict__ status) {
+        if (col != len) flags |= SDA_VARINT_ROW_COUNT;
+        if (flags) atomicOr(status, flags);
+    }
+};
+
+struct StoreSink {
+    int64_t* row;
+    __device__ __forceinline__ void operator()(uint64_t c, int64_t v) const { row[c] = v; }
+};
+
+// row checks shared by the streaming kernels; true = stream the row
+__device__ __forceinline__ bool stream_row_range(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
+                                                 const uint64_t* __restrict__ offsets, uint64_t r, uint64_t len,
+                                                 uint32_t* __restrict__ status, uint64_t& a, uint64_t& b) {
+    const bool lead = (threadIdx.x & 63) == 0;
+    a = offsets ? offsets[r] : 0; b = offsets ? offsets[r + 1] : n_bytes;
+    if (b < a || b > n_bytes) { if (lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return false; }
+    if (len == 0) { if (a != b && lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return false; }
+    if (a == b || (bytes[b - 1] & 0x80u)) { if (lead) atomicOr(status, SDA_VARINT_UNTERMINATED); return false; }
+    return true;
+}
+
+__global__ __launch_bounds__(kStreamWaves * 64) void varint_stream_decode_kernel(const uint8_t* __restrict__ bytes,
+                                                                                 uint64_t n_bytes,
+                                                                                 const uint64_t* __restrict__ offsets,
+                                                                                 uint64_t rows, uint64_t len,
+                                                                                 uint64_t row_stride,
+                                                                                 int64_t* __restrict__ out,
+                                                                                 uint32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[kStreamWaves][kStreamTile];
+    const int wave = threadIdx.x >> 6;
+    const uint64_t r = (uint64_t)blockIdx.x * kStreamWaves + wave;
+    if (r >= rows) return;
+    uint64_t a, b;
+    if (!stream_row_range(bytes, n_bytes, offsets, r, len, status, a, b)) return;
+    RowStream rs;
+    rs.open(bytes, a, b, len, tiles[wave]);
+    const StoreSink sink{out + r * row_stride};
+    while (!rs.done()) rs.next_group(sink);
+    rs.close(status);
+}
+
+// ---- wire format -> clerk sums without the decoded tile ---------------------------------
+// The 16 (or 8) waves of a workgroup stream as many rows of ONE job in lockstep (a group of kStreamDepth chunks each, then a
+// barrier).  Values go into a sliding window of kCombWindow columns in LDS, two 64-bit planes per column (sum of
+// the low 32 bits, sum of the arithmetic high 32 bits: no carries, plain ds_add_u64).  After every group the columns
+// below min(current column of the 16 rows) can no longer be touched: they are folded into (lo, hi) and added to
+// the global 128-bit accumulators, one pair of atomics per column and workgroup.  A value beyond the window (rows
+// drifting apart by more than ~1500 columns: only with wildly different value sizes) goes to the global
+// accumulator directly, so the result is exact for any input.
+static constexpr int kCombWindow = 2048;
+
+struct WindowSink {
+    unsigned long long* lo32; unsigned long long* hi32;   // LDS planes
+    uint64_t base;                                         // first column of the window
+    uint64_t* acc_lo; int64_t* acc_hi;                     // this job's accumulators
+    __device__ __forceinline__ void operator()(uint64_t c, int64_t v) const {
+        if (c - base < (uint64_t)kCombWindow) {
+            const uint32_t i = (uint32_t)c & (kCombWindow - 1);
+            atomicAdd(&lo32[i], (unsigned long long)((uint64_t)v & 0xFFFFFFFFull));
+            atomicAdd(&hi32[i], (unsigned long long)(v >> 32));
+        } else {
+            acc_atomic_add(acc_lo + c, acc_hi + c, (uint64_t)v, v >> 63);
+        }
+    }
+};
+
+template <int kCombWaves>       // rows per workgroup: 16 (one pair of global atomics per column and 16 rows), 8 when rows are few
+__global__ __launch_bounds__(kCombWaves * 64) void varint_stream_combine_kernel(
+    const uint8_t* __restrict__ bytes, uint64_t n_bytes, const uint64_t* __restrict__ offsets, uint64_t rows_per_job,
+    uint64_t groups_per_job, uint64_t len, uint64_t* __restrict__ acc_lo, int64_t* __restrict__ acc_hi,
+    uint32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[kCombWaves][kStreamTile];
+    __shared__ unsigned long long lo32[kCombWindow], hi32[kCombWindow];
+    __shared__ uint64_t cols[kCombWaves];
+    const int wave = threadIdx.x >> 6;
+    const uint64_t job = blockIdx.x / groups_per_job, grp = blockIdx.x - job * groups_per_job;
+    const uint64_t rj = grp * kCombWaves + wave;                  // row inside the job
+    for (int i = threadIdx.x; i < kCombWindow; i += kCombWaves * 64) { lo32[i] = 0; hi32[i] = 0; }
+    RowStream rs;
+    bool live = false;
+    if (rj < rows_per_job) {
+        uint64_t a, b;
+        live = stream_row_range(bytes, n_bytes, offsets, job * rows_per_job + rj, len, status, a, b);
+        if (live) rs.open(bytes, a, b, len, tiles[wave]);
+    }
+    WindowSink sink{lo32, hi32, 0, acc_lo + job * len, acc_hi + job * len};
+    __syncthreads();
+    for (;;) {
+        if (live) {
+            rs.next_group(sink);
+            if (rs.done()) { rs.close(status); live = false; }
+        }
+        if ((threadIdx.x & 63) == 0) cols[wave] = live ? rs.col : len;     // a finished row no longer holds the window
+        __syncthreads();
+        uint64_t nb = len;
+#pragma unroll
+        for (int w = 0; w < kCombWaves; ++w) nb = cols[w] < nb ? cols[w] : nb;
+        // every later value has column >= nb: fold and flush [base, nb)
+        uint64_t end = nb < sink.base + kCombWindow ? nb : sink.base + kCombWindow;
+        for (uint64_t c = sink.base + threadIdx.x; c < end; c += kCombWaves * 64) {
+            const uint32_t i = (uint32_t)c & (kCombWindow - 1);
+            const uint64_t A = lo32[i];
+            const int64_t Bq = (int64_t)hi32[i];
+            if (A | (uint64_t)Bq) {
+                lo32[i] = 0; hi32[i] = 0;
+                const uint64_t lo = A + ((uint64_t)Bq << 32);
+                acc_atomic_add(sink.acc_lo + c, sink.acc_hi + c, lo, (Bq >> 32) + (lo < A ? 1 : 0));
+            }
+        }
+        sink.base = nb;
+        __syncthreads();
+        if (nb >= len) break;                                     // all 16 rows are through
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 static inline uint64_t vceil(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
@@ -388,6 +663,31 @@ hipError_t launch_varint_decode(const uint8_t* d_bytes, size_t n_bytes, const ui
     if (nb == 0) return hipSuccess;
     varint_decode_kernel<<<dim3((unsigned)nb), dim3(kVT), 0, s>>>(d_bytes, n_bytes, d_block_val_off, rows, len, row_stride,
                                                                   d_out, d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_varint_stream_decode(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t rows,
+                                       size_t len, size_t row_stride, int64_t* d_out, uint32_t* d_status, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    varint_stream_decode_kernel<<<dim3((unsigned)vceil(rows, kStreamWaves)), dim3(kStreamWaves * 64), 0, s>>>(
+        d_bytes, n_bytes, d_offsets, rows, len, row_stride, d_out, d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_varint_stream_combine(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t jobs,
+                                        size_t rows_per_job, size_t len, uint64_t* d_acc_lo, int64_t* d_acc_hi,
+                                        uint32_t* d_status, hipStream_t s) {
+    if (jobs == 0 || rows_per_job == 0 || len == 0) return hipSuccess;
+    // 16 rows per workgroup once that still gives every CU two workgroups, else 8 (more workgroups, twice the atomics)
+    const bool wide = vceil(rows_per_job, 16) * jobs >= 512;
+    const uint64_t groups = vceil(rows_per_job, wide ? 16 : 8);
+    if (groups * jobs > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    if (wide)
+        varint_stream_combine_kernel<16><<<dim3((unsigned)(groups * jobs)), dim3(16 * 64), 0, s>>>(
+            d_bytes, n_bytes, d_offsets, rows_per_job, groups, len, d_acc_lo, d_acc_hi, d_status);
+    else
+        varint_stream_combine_kernel<8><<<dim3((unsigned)(groups * jobs)), dim3(8 * 64), 0, s>>>(
+            d_bytes, n_bytes, d_offsets, rows_per_job, groups, len, d_acc_lo, d_acc_hi, d_status);
     return hipGetLastError();
 }
 

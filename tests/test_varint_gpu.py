@@ -28,9 +28,16 @@ def test_published_vectors(gpu):
     assert c.encode([]) == b"" and c.decode(b"").size == 0
 
 
+@pytest.fixture(params=["scan", "stream"])
+def decode_path(request, monkeypatch):
+    """the two decode forms: three-pass block scan (few rows) and single-pass row streaming (many rows)"""
+    monkeypatch.setenv("SDA_VARINT_PATH", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("n,kind", [(1, "edge"), (7, "small"), (2047, "shares"), (2048, "shares"), (2049, "mixed"),
                                     (100_003, "mixed"), (1_000_000, "shares"), (300_000, "signed")])
-def test_encode_decode_vs_oracle(gpu, n, kind):
+def test_encode_decode_vs_oracle(gpu, n, kind, decode_path):
     from sda_amd import crypto
     from oracle import coracle
     rng = np.random.default_rng(n)
@@ -63,7 +70,7 @@ def test_pyoracle_agrees_on_small_case(gpu):
     assert c.decode(po.varint_encode(v.tolist())).tolist() == po.varint_decode(po.varint_encode(v.tolist()))
 
 
-def test_malformed_streams_are_refused(gpu):
+def test_malformed_streams_are_refused(gpu, decode_path):
     from sda_amd import capi, crypto
     c = crypto.VarintCodec()
     with pytest.raises(capi.SdaError):                      # ends inside a value
@@ -77,7 +84,7 @@ def test_malformed_streams_are_refused(gpu):
     assert c.decode(ten_hi).tolist() == po.varint_decode(ten_hi) == coracle.varint_decode(ten_hi).tolist()
 
 
-def test_device_rows_roundtrip_feeds_the_combiner(gpu):
+def test_device_rows_roundtrip_feeds_the_combiner(gpu, decode_path):
     """participants' share vectors for one clerk: encode on device -> per-row byte ranges (what would be
     sealed) -> decode on device -> clerk combine; equals combining the originals."""
     import ctypes as C
@@ -164,3 +171,126 @@ def test_streaming_clerk_over_wire_format(gpu):
     out = DeviceBuffer(4001)
     c2.finish_dev(out.ptr)
     assert st.to_numpy()[0] == 0 and np.array_equal(out.to_numpy(), coracle.combine(P62, big))
+
+
+def _mixed(rng, n):
+    bits = rng.integers(0, 64, size=n)
+    return (rng.integers(-(2 ** 63), 2 ** 63 - 1, size=n, dtype=np.int64) >> (63 - bits)).astype(np.int64)
+
+
+@pytest.mark.parametrize("rows,L,kind,shift", [(1, 1, "mixed", 0), (3, 7, "mixed", 1), (70, 113, "mixed", 5), (9, 5001, "shares", 0),
+                                               (5, 3000, "tiny", 3), (4, 2500, "huge", 15), (2100, 257, "mixed", 0),
+                                               (33, 1024, "tiny", 0)])
+def test_row_streaming_decode(gpu, monkeypatch, rows, L, kind, shift):
+    """single-pass row streaming == three-pass scan == oracle, for every value length, rows that start at any
+    byte alignment (also a byte stream that itself starts off the 16-byte grid), 1-byte values (1024 per chunk)
+    and 10-byte values; the status flags of damaged rows agree too."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(rows * 1000 + L)
+    if kind == "mixed":
+        v = _mixed(rng, rows * L).reshape(rows, L)
+    elif kind == "shares":
+        v = rng.integers(0, P62, size=(rows, L), dtype=np.int64)
+    elif kind == "tiny":
+        v = rng.integers(-64, 64, size=(rows, L), dtype=np.int64)               # one byte each
+    else:
+        v = rng.integers(2 ** 62, 2 ** 63 - 1, size=(rows, L), dtype=np.int64) * rng.choice([-1, 1], size=(rows, L))
+    enc = [coracle.varint_encode(r) for r in v]
+    raw = b"".join(enc)
+    offs = np.cumsum([0] + [len(e) for e in enc]).astype(np.int64)
+    host = b"\xff" * shift + raw                                                # the stream starts `shift` bytes in
+    d_bytes = DeviceBuffer.from_numpy(np.frombuffer(host + b"\0" * (-len(host) % 8), dtype=np.int64))
+    d_off = DeviceBuffer.from_numpy(offs)
+    codec = crypto.VarintCodec()
+    stride = L + 3
+    got = {}
+    for path in ("scan", "stream"):
+        monkeypatch.setenv("SDA_VARINT_PATH", path)
+        d_dec = DeviceBuffer(rows * stride).zero()
+        st = DeviceBuffer(1).zero()
+        codec.decode_dev(d_bytes.ptr + shift, len(raw), d_off.ptr, rows, L, d_dec.ptr, stride, st.ptr)
+        assert st.to_numpy()[0] == 0, path
+        m = d_dec.to_numpy().reshape(rows, stride)
+        assert np.array_equal(m[:, :L], v), path
+        assert not m[:, L:].any(), path                                         # nothing written past a row
+        got[path] = m
+    # damaged rows: same verdicts from both forms
+    def status(path, raw_b, offs_b, want_len):
+        monkeypatch.setenv("SDA_VARINT_PATH", path)
+        db = DeviceBuffer.from_numpy(np.frombuffer(raw_b + b"\0" * (-len(raw_b) % 8 or 8), dtype=np.int64))
+        do = DeviceBuffer.from_numpy(np.asarray(offs_b, dtype=np.int64))
+        st = DeviceBuffer(1).zero()
+        dd = DeviceBuffer(rows * stride + 8).zero()
+        codec.decode_dev(db.ptr, len(raw_b), do.ptr, rows, want_len, dd.ptr, max(stride, want_len), st.ptr)
+        return int(st.to_numpy()[0])
+    cases = [(raw, offs, L + 1), (raw, offs, max(L - 1, 0))]                     # wrong expected length
+    if L > 1:
+        bad = bytearray(raw); bad[int(offs[rows // 2 + 1]) - 1] |= 0x80          # a row that ends inside a value
+        cases.append((bytes(bad), offs, L))
+        moved = offs.copy(); moved[rows // 2 + 1 if rows > 1 else 0] += 0        # unchanged: control
+        cases.append((raw, moved, L))
+    if kind == "huge":
+        over = bytearray(raw); over[3] |= 0x80; over[9] |= 0x80                  # >= 11 bytes without a terminator
+        cases.append((bytes(over), offs, L))
+    for raw_b, offs_b, want in cases:
+        a, b = status("scan", raw_b, offs_b, want), status("stream", raw_b, offs_b, want)
+        assert (a != 0) == (b != 0), (a, b, want)
+        if a:
+            assert a & b, (a, b, want)                                           # at least one common reason
+
+
+@pytest.mark.parametrize("jobs,rpj,L,kind", [(1, 40, 5001, "shares"), (3, 17, 3000, "mixed"), (2, 16, 9000, "tiny"),
+                                             (1, 33, 2500, "signed"), (8, 5, 1, "mixed"), (1, 1, 70_000, "shares"),
+                                             (2, 35, 4097, "drift")])
+def test_wire_format_clerk_sums(gpu, monkeypatch, jobs, rpj, L, kind):
+    """clerk.rs:78-86 on wire-format rows, job-major: the single-pass form (rows streamed in lockstep, sums in an LDS
+    column window, no decoded tile) == decode-then-combine == the oracle, bit-exact.  'tiny' overflows the window in
+    one step (1024 one-byte values per chunk), 'drift' gives every row its own value size so the rows run apart, both
+    exercising the direct-to-accumulator path; two updates check that the window state does not leak between calls."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(jobs * 100 + rpj)
+    rows = jobs * rpj
+    if kind == "shares":
+        v = rng.integers(0, P62, size=(rows, L), dtype=np.int64)
+    elif kind == "signed":
+        v = rng.integers(-(P62 - 1), P62, size=(rows, L), dtype=np.int64)
+    elif kind == "tiny":
+        v = rng.integers(-64, 64, size=(rows, L), dtype=np.int64)
+    elif kind == "drift":
+        v = np.stack([rng.integers(0, 2 ** int(rng.integers(3, 62)), size=L, dtype=np.int64) for _ in range(rows)])
+    else:
+        v = _mixed(rng, rows * L).reshape(rows, L)
+    enc = [coracle.varint_encode(r) for r in v]
+    raw = b"".join(enc)
+    offs = np.cumsum([0] + [len(e) for e in enc]).astype(np.int64)
+    d_bytes = DeviceBuffer.from_numpy(np.frombuffer(raw + b"\0" * (-len(raw) % 8 or 8), dtype=np.int64))
+    d_off = DeviceBuffer.from_numpy(offs)
+    codec = crypto.VarintCodec()
+    q = P62
+    want = np.stack([coracle.combine(q, np.concatenate([v[j * rpj:(j + 1) * rpj]] * 2)) for j in range(jobs)])
+    for path in ("scan", "stream"):
+        monkeypatch.setenv("SDA_VARINT_PATH", path)
+        comb = crypto.ShareCombiner(crypto.Additive(3, q))
+        st = DeviceBuffer(1).zero()
+        out = DeviceBuffer(jobs * L)
+        comb.begin_dev(jobs, L)
+        comb.update_encoded_dev(codec, d_bytes.ptr, len(raw), d_off.ptr, rows, st.ptr)
+        comb.update_encoded_dev(codec, d_bytes.ptr, len(raw), d_off.ptr, rows, st.ptr)
+        comb.finish_dev(out.ptr)
+        assert st.to_numpy()[0] == 0, path
+        assert np.array_equal(out.to_numpy().reshape(jobs, L), want), path
+    # a damaged row is reported by both forms
+    if L > 1:
+        bad = bytearray(raw); bad[int(offs[rows // 2 + 1]) - 1] |= 0x80
+        db = DeviceBuffer.from_numpy(np.frombuffer(bytes(bad) + b"\0" * (-len(raw) % 8 or 8), dtype=np.int64))
+        for path in ("scan", "stream"):
+            monkeypatch.setenv("SDA_VARINT_PATH", path)
+            comb = crypto.ShareCombiner(crypto.Additive(3, q))
+            st = DeviceBuffer(1).zero()
+            comb.begin_dev(jobs, L)
+            comb.update_encoded_dev(codec, db.ptr, len(raw), d_off.ptr, rows, st.ptr)
+            assert st.to_numpy()[0] != 0, path
