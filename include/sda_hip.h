@@ -354,6 +354,17 @@ int sda_varint_encode_dev(sda_varint_codec_t* c, const int64_t* d_values, size_t
 int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_row_offsets,
                           size_t rows, size_t len, int64_t* d_values, size_t row_stride, uint32_t* d_status, void* stream);
 
+/* Slotted rows (single pass on both sides): every vector is sealed / opened on its own (sodium.rs:36-43, :78-89),
+ * so the rows need not be contiguous.  Row r lives at d_bytes + r*slot_bytes (slot_bytes >= sda_varint_slot_size(len),
+ * a multiple of 16; the buffer 16-byte aligned) and d_row_bytes[r] (device u64) is its encoded length.  Encoding
+ * writes the lengths, decoding reads them; d_status as in sda_varint_decode_dev.  The bytes of a row are exactly
+ * those of sda_varint_encode for that vector. */
+size_t sda_varint_slot_size(size_t len);
+int sda_varint_encode_rows_dev(sda_varint_codec_t* c, const int64_t* d_values, size_t rows, size_t len, size_t row_stride,
+                               uint8_t* d_out, size_t slot_bytes, uint64_t* d_row_bytes, void* stream);
+int sda_varint_decode_rows_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t slot_bytes, const uint64_t* d_row_bytes,
+                               size_t rows, size_t len, int64_t* d_values, size_t row_stride, uint32_t* d_status, void* stream);
+
 /* Streaming clerk (fixes the FIXME at client/src/clerk.rs:71-72): feed the opened
  * sealed-box payloads straight into the accumulating combiner - decode tile -> clerk-sum update ->
  * discard - instead of materialising all P decoded vectors (clerk.rs:80-86).
@@ -368,6 +379,9 @@ int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t 
 int sda_share_combiner_update_varint_dev(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* d_bytes,
                                          size_t n_bytes, const uint64_t* d_row_offsets, size_t rows,
                                          uint32_t* d_status, void* stream);
+int sda_share_combiner_update_varint_rows_dev(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* d_bytes,
+                                              size_t slot_bytes, const uint64_t* d_row_bytes, size_t rows,
+                                              uint32_t* d_status, void* stream);   /* slotted rows, always streamed */
 int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* bytes,
                                      size_t n_bytes);
 

@@ -228,6 +228,11 @@ class ShareCombiner(_Handle):
         check(self._lib.sda_share_combiner_update_varint_dev(self._h, codec._h, d_bytes, n_bytes, d_row_offsets or None,
                                                              rows, d_status, stream or None))
 
+    def update_encoded_rows_dev(self, codec: "VarintCodec", d_bytes: int, slot_bytes: int, d_row_bytes: int, rows: int,
+                                d_status: int, stream: int = 0) -> None:
+        check(self._lib.sda_share_combiner_update_varint_rows_dev(self._h, codec._h, d_bytes, slot_bytes, d_row_bytes,
+                                                                  rows, d_status, stream or None))
+
     def set_residency(self, max_workgroups_per_cu: int) -> None:
         check(self._lib.sda_share_combiner_set_residency(self._h, max_workgroups_per_cu))
 
@@ -437,6 +442,20 @@ class VarintCodec(_Handle):
         check(self._lib.sda_varint_encode_dev(self._h, d_values, rows, length, row_stride, d_out, out_cap,
                                               d_row_offsets or None, C.byref(total), stream or None))
         return total.value
+
+    def slot_size(self, length: int) -> int:
+        return self._lib.sda_varint_slot_size(length)
+
+    def encode_rows_dev(self, d_values: int, rows: int, length: int, row_stride: int, d_out: int, slot_bytes: int,
+                        d_row_bytes: int, stream: int = 0) -> None:
+        """single pass: row r -> d_out + r*slot_bytes, its length -> d_row_bytes[r]"""
+        check(self._lib.sda_varint_encode_rows_dev(self._h, d_values, rows, length, row_stride, d_out, slot_bytes,
+                                                   d_row_bytes, stream or None))
+
+    def decode_rows_dev(self, d_bytes: int, slot_bytes: int, d_row_bytes: int, rows: int, length: int, d_values: int,
+                        row_stride: int, d_status: int, stream: int = 0) -> None:
+        check(self._lib.sda_varint_decode_rows_dev(self._h, d_bytes, slot_bytes, d_row_bytes, rows, length, d_values,
+                                                   row_stride, d_status, stream or None))
 
     def decode_dev(self, d_bytes: int, n_bytes: int, d_row_offsets: int, rows: int, length: int, d_values: int,
                    row_stride: int, d_status: int, stream: int = 0) -> None:

@@ -150,12 +150,22 @@ hipError_t launch_varint_count(const uint8_t* d_bytes, size_t n_bytes, uint32_t*
 hipError_t launch_varint_decode(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_block_val_off,
                                 size_t rows, size_t len, size_t row_stride, int64_t* d_out, uint32_t* d_status,
                                 hipStream_t s);
+// where the encoded rows lie in the byte buffer: contiguous (row r = [offsets[r], offsets[r+1]), offsets == nullptr:
+// one row = the whole buffer) or slotted (lengths != nullptr: row r = [r*slot, r*slot + lengths[r]))
+struct RowRanges {
+    const uint64_t* offsets;
+    const uint64_t* lengths;
+    uint64_t slot;
+};
 // single pass, one wave per row (rows are independent messages with known byte ranges); pays off with >= ~1000 rows
-hipError_t launch_varint_stream_decode(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t rows,
+hipError_t launch_varint_stream_decode(const uint8_t* d_bytes, size_t n_bytes, const RowRanges& rr, size_t rows,
                                        size_t len, size_t row_stride, int64_t* d_out, uint32_t* d_status, hipStream_t s);
+// single-pass encode into slots: row r -> d_out + r*slot_bytes (16-byte aligned), its length -> d_row_bytes[r]
+hipError_t launch_varint_stream_encode(const VarintRows& R, uint8_t* d_out, size_t slot_bytes, uint64_t* d_row_bytes,
+                                       hipStream_t s);
 // wire format -> 128-bit clerk accumulators directly: rows = jobs x rows_per_job encoded vectors (job-major), 16 rows
 // of a job per workgroup through a sliding LDS column window; acc layout [jobs][len]
-hipError_t launch_varint_stream_combine(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t jobs,
+hipError_t launch_varint_stream_combine(const uint8_t* d_bytes, size_t n_bytes, const RowRanges& rr, size_t jobs,
                                         size_t rows_per_job, size_t len, uint64_t* d_acc_lo, int64_t* d_acc_hi,
                                         uint32_t* d_status, hipStream_t s);
 hipError_t launch_varint_rowcheck(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t rows,

@@ -1208,7 +1208,8 @@ extern "C" int sda_varint_decode_dev(sda_varint_codec_t* c, const uint8_t* d_byt
     hipStream_t s = c->ctx.pick(stream);
     if (n_bytes > 0 && (!d_bytes || !d_values)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
     if (varint_use_stream(rows)) {       // many rows: one wave streams each row, the bytes are read once
-        HIP_TRY(launch_varint_stream_decode(d_bytes, n_bytes, d_row_offsets, rows, len, row_stride, d_values, d_status, s));
+        HIP_TRY(launch_varint_stream_decode(d_bytes, n_bytes, RowRanges{d_row_offsets, nullptr, 0}, rows, len, row_stride, d_values,
+                                            d_status, s));
         return SDA_OK;
     }
     SDA_TRY(varint_count_scan(c, d_bytes, n_bytes, s));
@@ -1280,15 +1281,70 @@ extern "C" int sda_share_combiner_update_varint_dev(sda_share_combiner_t* c, sda
     SDA_TRY(c->ctx.use());
     if (varint_use_stream(rows)) {
         // many rows: 16 rows of a job per workgroup, decoded values summed in an LDS column window - no decoded tile
-        HIP_TRY(launch_varint_stream_combine(d_bytes, n_bytes, d_row_offsets, c->jobs, rows_per_job, L, c->acc.lo.as<uint64_t>(),
+        const RowRanges rr{d_row_offsets, nullptr, 0};
+        HIP_TRY(launch_varint_stream_combine(d_bytes, n_bytes, rr, c->jobs, rows_per_job, L, c->acc.lo.as<uint64_t>(),
                                              c->acc.hi.as<int64_t>(), d_status, c->ctx.pick(stream)));
-        if (L == 0) HIP_TRY(launch_varint_stream_decode(d_bytes, n_bytes, d_row_offsets, rows, 0, 0, nullptr, d_status, c->ctx.pick(stream)));
+        if (L == 0) HIP_TRY(launch_varint_stream_decode(d_bytes, n_bytes, rr, rows, 0, 0, nullptr, d_status, c->ctx.pick(stream)));
         return SDA_OK;
     }
     SDA_TRY(c->tile.reserve((rows * stride ? rows * stride : 1) * 8));
     SDA_TRY(sda_varint_decode_dev(codec, d_bytes, n_bytes, d_row_offsets, rows, L, c->tile.as<int64_t>(), stride, d_status, stream));
     if (L == 0) return SDA_OK;
     return sda_share_combiner_update_dev(c, c->tile.as<int64_t>(), rows_per_job * stride, rows_per_job, stride, stream);
+}
+
+// ---- slotted rows: row r at d_bytes + r*slot_bytes, d_row_bytes[r] bytes long (single-pass kernels only) ----------
+extern "C" size_t sda_varint_slot_size(size_t len) { return (len * 10 + 15) / 16 * 16; }
+
+static int check_slots(const void* d_bytes, size_t slot_bytes, size_t len) {
+    if (slot_bytes % 16 || ((uintptr_t)d_bytes & 15u)) return fail(SDA_ERR_INVALID_ARGUMENT, "slots must be 16-byte aligned (buffer and slot_bytes)");
+    if (slot_bytes < len * 10) return fail(SDA_ERR_INVALID_ARGUMENT, "slot_bytes < 10 * len (sda_varint_slot_size)");
+    return SDA_OK;
+}
+
+extern "C" int sda_varint_encode_rows_dev(sda_varint_codec_t* c, const int64_t* d_values, size_t rows, size_t len,
+                                          size_t row_stride, uint8_t* d_out, size_t slot_bytes, uint64_t* d_row_bytes,
+                                          void* stream) {
+    if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (rows == 0) return SDA_OK;
+    if (!d_out || !d_row_bytes || (len > 0 && !d_values)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (row_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "row_stride < len");
+    SDA_TRY(check_slots(d_out, slot_bytes, len));
+    SDA_TRY(c->ctx.use());
+    HIP_TRY(launch_varint_stream_encode(VarintRows{d_values, rows, len, row_stride}, d_out, slot_bytes, d_row_bytes, c->ctx.pick(stream)));
+    return SDA_OK;
+}
+
+extern "C" int sda_varint_decode_rows_dev(sda_varint_codec_t* c, const uint8_t* d_bytes, size_t slot_bytes,
+                                          const uint64_t* d_row_bytes, size_t rows, size_t len, int64_t* d_values,
+                                          size_t row_stride, uint32_t* d_status, void* stream) {
+    if (!c || !d_status) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (rows == 0) return SDA_OK;
+    if (!d_bytes || !d_row_bytes || (len > 0 && !d_values)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (row_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "row_stride < len");
+    if (slot_bytes % 16 || ((uintptr_t)d_bytes & 15u)) return fail(SDA_ERR_INVALID_ARGUMENT, "slots must be 16-byte aligned (buffer and slot_bytes)");
+    SDA_TRY(c->ctx.use());
+    HIP_TRY(launch_varint_stream_decode(d_bytes, rows * slot_bytes, RowRanges{nullptr, d_row_bytes, slot_bytes}, rows, len, row_stride,
+                                        d_values, d_status, c->ctx.pick(stream)));
+    return SDA_OK;
+}
+
+extern "C" int sda_share_combiner_update_varint_rows_dev(sda_share_combiner_t* c, sda_varint_codec_t* codec,
+                                                         const uint8_t* d_bytes, size_t slot_bytes, const uint64_t* d_row_bytes,
+                                                         size_t rows, uint32_t* d_status, void* stream) {
+    if (!c || !codec) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (rows == 0 || c->jobs == 0) return SDA_OK;
+    if (rows % c->jobs) return fail(SDA_ERR_INVALID_ARGUMENT, "rows (%zu) must be a multiple of the combiner's jobs (%zu): job-major rows", rows, c->jobs);
+    if (!d_status || !d_bytes || !d_row_bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (slot_bytes % 16 || ((uintptr_t)d_bytes & 15u)) return fail(SDA_ERR_INVALID_ARGUMENT, "slots must be 16-byte aligned (buffer and slot_bytes)");
+    SDA_TRY(c->ctx.use());
+    const RowRanges rr{nullptr, d_row_bytes, slot_bytes};
+    const size_t L = c->dimension;
+    HIP_TRY(launch_varint_stream_combine(d_bytes, rows * slot_bytes, rr, c->jobs, rows / c->jobs, L, c->acc.lo.as<uint64_t>(),
+                                         c->acc.hi.as<int64_t>(), d_status, c->ctx.pick(stream)));
+    if (L == 0) HIP_TRY(launch_varint_stream_decode(d_bytes, rows * slot_bytes, rr, rows, 0, 0, nullptr, d_status, c->ctx.pick(stream)));
+    return SDA_OK;
 }
 
 extern "C" int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* bytes,

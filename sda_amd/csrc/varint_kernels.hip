@@ -510,10 +510,11 @@ struct StoreSink {
 
 // row checks shared by the streaming kernels; true = stream the row
 __device__ __forceinline__ bool stream_row_range(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
-                                                 const uint64_t* __restrict__ offsets, uint64_t r, uint64_t len,
+                                                 const RowRanges& rr, uint64_t r, uint64_t len,
                                                  uint32_t* __restrict__ status, uint64_t& a, uint64_t& b) {
     const bool lead = (threadIdx.x & 63) == 0;
-    a = offsets ? offsets[r] : 0; b = offsets ? offsets[r + 1] : n_bytes;
+    if (rr.lengths) { a = r * rr.slot; b = a + rr.lengths[r]; }
+    else { a = rr.offsets ? rr.offsets[r] : 0; b = rr.offsets ? rr.offsets[r + 1] : n_bytes; }
     if (b < a || b > n_bytes) { if (lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return false; }
     if (len == 0) { if (a != b && lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return false; }
     if (a == b || (bytes[b - 1] & 0x80u)) { if (lead) atomicOr(status, SDA_VARINT_UNTERMINATED); return false; }
@@ -521,8 +522,7 @@ __device__ __forceinline__ bool stream_row_range(const uint8_t* __restrict__ byt
 }
 
 __global__ __launch_bounds__(kStreamWaves * 64) void varint_stream_decode_kernel(const uint8_t* __restrict__ bytes,
-                                                                                 uint64_t n_bytes,
-                                                                                 const uint64_t* __restrict__ offsets,
+                                                                                 uint64_t n_bytes, RowRanges offsets,
                                                                                  uint64_t rows, uint64_t len,
                                                                                  uint64_t row_stride,
                                                                                  int64_t* __restrict__ out,
@@ -538,6 +538,128 @@ __global__ __launch_bounds__(kStreamWaves * 64) void varint_stream_decode_kernel
     const StoreSink sink{out + r * row_stride};
     while (!rs.done()) rs.next_group(sink);
     rs.close(status);
+}
+
+// ---- single-pass encode into slots ------------------------------------------------------------------------------
+// The mirror image: one wave encodes one row, 128 values (2 per lane, one 16-byte load) per step, four steps
+// prefetched.  Byte positions inside a step come from a wave scan of the lengths; each value's <= 10 bytes are
+// shifted to their byte phase and OR-ed into the wave's zeroed LDS tile (neighbours share boundary dwords), and the
+// tile leaves as aligned 16-byte stores.  The up to 15 bytes that do not fill a 16-byte unit are carried into
+// the next step's tile, so every global store but the row's last few bytes is a full aligned unit.  The row's byte
+// count is only known at the end, hence the slotted output (row r at r * slot): each vector is sealed on its own
+// anyway (sodium.rs:36-43), so contiguity of the rows has no meaning on the wire.
+static constexpr int kEncVals = 128;
+static constexpr int kEncTile = 16 + kEncVals * 10 + 32;      // carry | bytes | slack for the last value's dwords
+
+__device__ __forceinline__ void value_bytes(uint64_t zz, uint32_t len, uint32_t& b0, uint32_t& b1, uint32_t& b2) {
+    uint32_t d0 = (uint32_t)zz & 0x0FFFFFFFu, d1 = (uint32_t)(zz >> 28) & 0x0FFFFFFFu;   // 2 x 28 bits -> 2 x 4 bytes
+    d0 = (d0 & 0x00003FFFu) | ((d0 & 0x0FFFC000u) << 2);
+    d1 = (d1 & 0x00003FFFu) | ((d1 & 0x0FFFC000u) << 2);
+    d0 = (d0 & 0x007F007Fu) | ((d0 & 0x3F803F80u) << 1);
+    d1 = (d1 & 0x007F007Fu) | ((d1 & 0x3F803F80u) << 1);
+    const uint32_t d2 = ((uint32_t)(zz >> 56) & 0x7Fu) | ((uint32_t)(zz >> 63) << 8);     // bytes 8 and 9
+    // continuation bit on every byte but the last one
+    const uint64_t cont = len >= 9 ? 0x8080808080808080ull : (0x0080808080808080ull >> (8 * ((8 - len) & 7)));   // len 0: unused
+    b0 = d0 | (uint32_t)cont;
+    b1 = d1 | (uint32_t)(cont >> 32);
+    b2 = d2 | (len > 9 ? 0x80u : 0u);
+    if (len == 0) { b0 = 0; b1 = 0; b2 = 0; }
+}
+
+__device__ __forceinline__ void tile_or(uint32_t* tile32, uint32_t pos, uint32_t b0, uint32_t b1, uint32_t b2) {
+    const uint32_t sh = 8u * (pos & 3u);
+    const uint64_t lo = ((uint64_t)b1 << 32 | b0) << sh;                 // bytes 0..7 at their phase (low part)
+    const uint64_t hi = (((uint64_t)b2 << 32) | b1) << sh;               // high dword: b2 and what left b1
+    uint32_t* t = tile32 + (pos >> 2);
+    atomicOr(t + 0, (uint32_t)lo);
+    atomicOr(t + 1, (uint32_t)(lo >> 32));
+    atomicOr(t + 2, (uint32_t)(hi >> 32));
+    if (sh) atomicOr(t + 3, (uint32_t)(((uint64_t)b2 << sh) >> 32));
+}
+
+__device__ __forceinline__ void enc_load2(const int64_t* __restrict__ src, uint64_t len, bool vec, uint64_t i, int64_t& x,
+                                          int64_t& y) {
+    x = 0; y = 0;
+    if (i + 1 < len && vec) {
+        typedef long long ll2v __attribute__((ext_vector_type(2)));
+        const ll2v v = __builtin_nontemporal_load(reinterpret_cast<const ll2v*>(src + i));
+        x = v.x; y = v.y;
+    } else {
+        if (i < len) x = src[i];
+        if (i + 1 < len) y = src[i + 1];
+    }
+}
+
+__global__ __launch_bounds__(kStreamWaves * 64) void varint_stream_encode_kernel(VarintRows R, uint8_t* __restrict__ out,
+                                                                                 uint64_t slot,
+                                                                                 uint64_t* __restrict__ row_bytes) {
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[kStreamWaves][kEncTile];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * kStreamWaves + wave;
+    if (r >= R.rows) return;
+    const int64_t* __restrict__ src = R.values + r * R.row_stride;
+    uint8_t* __restrict__ dst = out + r * slot;
+    uint32_t* tile32 = reinterpret_cast<uint32_t*>(tiles[wave]);
+    uint4* tile128 = reinterpret_cast<uint4*>(tiles[wave]);
+    const bool vec = (((uintptr_t)src) & 15u) == 0;
+    const uint64_t n_steps = (R.len + kEncVals - 1) / kEncVals;
+    const uint64_t len = R.len;
+    int64_t wx[kStreamDepth], wy[kStreamDepth];
+#pragma unroll
+    for (int d = 0; d < kStreamDepth; ++d) enc_load2(src, len, vec, (uint64_t)d * kEncVals + 2 * (uint64_t)lane, wx[d], wy[d]);
+    uint64_t cur = 0;                 // bytes of this row already in global memory (multiple of 16)
+    uint32_t cb = 0;                  // carried bytes (< 16), held by lane 0 in `carry`
+    uint4 carry = make_uint4(0, 0, 0, 0);
+    for (uint64_t j0 = 0; j0 < n_steps; j0 += kStreamDepth) {
+#pragma unroll
+        for (int d = 0; d < kStreamDepth; ++d) {
+            const uint64_t j = j0 + d;
+            if (j >= n_steps) continue;
+            int64_t x = wx[d], y = wy[d];
+            asm volatile("" : "+v"(x), "+v"(y));
+            __builtin_amdgcn_sched_barrier(0);
+            enc_load2(src, len, vec, (j + kStreamDepth) * kEncVals + 2 * (uint64_t)lane, wx[d], wy[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint64_t i = j * kEncVals + 2 * (uint64_t)lane;
+            const uint64_t zx = zigzag(x), zy = zigzag(y);
+            const uint32_t lx = i < len ? varint_len(zx) : 0u, ly = i + 1 < len ? varint_len(zy) : 0u;
+            const uint32_t cnt = lx + ly;
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t T = __builtin_amdgcn_readlane(incl, 63);
+            const uint32_t pos = cb + incl - cnt;
+            // zero the tile, put the carried bytes in front
+            const bool first = lane == 0;
+            tile128[lane] = make_uint4(first ? carry.x : 0u, first ? carry.y : 0u, first ? carry.z : 0u, first ? carry.w : 0u);
+            if (lane + 64 < kEncTile / 16) tile128[lane + 64] = make_uint4(0, 0, 0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t b0, b1, b2;
+            value_bytes(zx, lx, b0, b1, b2);
+            tile_or(tile32, pos, b0, b1, b2);
+            value_bytes(zy, ly, b0, b1, b2);
+            tile_or(tile32, pos + lx, b0, b1, b2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t have = cb + T, units = have >> 4;              // <= 81 units
+            uint4* g = reinterpret_cast<uint4*>(dst + cur);
+            if ((uint32_t)lane < units) g[lane] = tile128[lane];
+            if ((uint32_t)lane + 64 < units) g[lane + 64] = tile128[lane + 64];
+            const uint4 next = tile128[units];                            // bytes past `have` are zero
+            carry = make_uint4(__builtin_amdgcn_readfirstlane(next.x), __builtin_amdgcn_readfirstlane(next.y),
+                               __builtin_amdgcn_readfirstlane(next.z), __builtin_amdgcn_readfirstlane(next.w));
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cur += (uint64_t)units * 16;
+            cb = have & 15u;
+        }
+    }
+    // the last bytes of the row
+    if ((uint32_t)lane < cb) {
+        const uint32_t wsel = lane >> 2;
+        const uint32_t word = wsel == 0 ? carry.x : wsel == 1 ? carry.y : wsel == 2 ? carry.z : carry.w;
+        dst[cur + lane] = (uint8_t)(word >> (8 * (lane & 3)));
+    }
+    if (lane == 0) row_bytes[r] = cur + cb;
 }
 
 // ---- wire format -> clerk sums without the decoded tile ---------------------------------
@@ -567,7 +689,7 @@ struct WindowSink {
 
 template <int kCombWaves>       // rows per workgroup: 16 (one pair of global atomics per column and 16 rows), 8 when rows are few
 __global__ __launch_bounds__(kCombWaves * 64) void varint_stream_combine_kernel(
-    const uint8_t* __restrict__ bytes, uint64_t n_bytes, const uint64_t* __restrict__ offsets, uint64_t rows_per_job,
+    const uint8_t* __restrict__ bytes, uint64_t n_bytes, RowRanges offsets, uint64_t rows_per_job,
     uint64_t groups_per_job, uint64_t len, uint64_t* __restrict__ acc_lo, int64_t* __restrict__ acc_hi,
     uint32_t* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[kCombWaves][kStreamTile];
@@ -666,7 +788,7 @@ hipError_t launch_varint_decode(const uint8_t* d_bytes, size_t n_bytes, const ui
     return hipGetLastError();
 }
 
-hipError_t launch_varint_stream_decode(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t rows,
+hipError_t launch_varint_stream_decode(const uint8_t* d_bytes, size_t n_bytes, const RowRanges& d_offsets, size_t rows,
                                        size_t len, size_t row_stride, int64_t* d_out, uint32_t* d_status, hipStream_t s) {
     if (rows == 0) return hipSuccess;
     varint_stream_decode_kernel<<<dim3((unsigned)vceil(rows, kStreamWaves)), dim3(kStreamWaves * 64), 0, s>>>(
@@ -674,7 +796,15 @@ hipError_t launch_varint_stream_decode(const uint8_t* d_bytes, size_t n_bytes, c
     return hipGetLastError();
 }
 
-hipError_t launch_varint_stream_combine(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t jobs,
+hipError_t launch_varint_stream_encode(const VarintRows& R, uint8_t* d_out, size_t slot_bytes, uint64_t* d_row_bytes,
+                                       hipStream_t s) {
+    if (R.rows == 0) return hipSuccess;
+    varint_stream_encode_kernel<<<dim3((unsigned)vceil(R.rows, kStreamWaves)), dim3(kStreamWaves * 64), 0, s>>>(
+        R, d_out, slot_bytes, d_row_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_varint_stream_combine(const uint8_t* d_bytes, size_t n_bytes, const RowRanges& d_offsets, size_t jobs,
                                         size_t rows_per_job, size_t len, uint64_t* d_acc_lo, int64_t* d_acc_hi,
                                         uint32_t* d_status, hipStream_t s) {
     if (jobs == 0 || rows_per_job == 0 || len == 0) return hipSuccess;

@@ -294,3 +294,65 @@ def test_wire_format_clerk_sums(gpu, monkeypatch, jobs, rpj, L, kind):
             comb.begin_dev(jobs, L)
             comb.update_encoded_dev(codec, db.ptr, len(raw), d_off.ptr, rows, st.ptr)
             assert st.to_numpy()[0] != 0, path
+
+
+@pytest.mark.parametrize("rows,L,kind,stride_pad", [(1, 1, "mixed", 0), (5, 127, "mixed", 1), (9, 128, "mixed", 0), (7, 129, "mixed", 3),
+                                                    (33, 5001, "shares", 0), (6, 3000, "tiny", 2), (4, 2500, "huge", 0),
+                                                    (40, 4096, "signed", 1), (3, 0, "mixed", 0), (2100, 61, "mixed", 0)])
+def test_slotted_rows_encode_decode_combine(gpu, rows, L, kind, stride_pad):
+    """single-pass slotted encode: the bytes of every row equal the oracle's encoding of that vector (all value
+    lengths, odd strides -> unaligned rows take the scalar loads); decoded back bit-exactly; summed straight from
+    the slots == the oracle's combine."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(rows * 7919 + L)
+    if kind == "mixed":
+        v = _mixed(rng, rows * L).reshape(rows, L)
+    elif kind == "shares":
+        v = rng.integers(0, P62, size=(rows, L), dtype=np.int64)
+    elif kind == "signed":
+        v = rng.integers(-(P62 - 1), P62, size=(rows, L), dtype=np.int64)
+    elif kind == "tiny":
+        v = rng.integers(-64, 64, size=(rows, L), dtype=np.int64)
+    else:
+        v = rng.integers(2 ** 62, 2 ** 63 - 1, size=(rows, L), dtype=np.int64) * rng.choice([-1, 1], size=(rows, L))
+    if L:
+        v[0, :min(L, 20)] = _edge_values()[:min(L, 20)]
+    stride = L + stride_pad
+    vals = np.zeros((rows, max(stride, 1)), dtype=np.int64)
+    vals[:, :L] = v
+    d_vals = DeviceBuffer.from_numpy(vals)
+    codec = crypto.VarintCodec()
+    slot = codec.slot_size(L) + 16
+    assert slot % 16 == 0 and slot >= 10 * L
+    d_bytes = DeviceBuffer(rows * slot // 8 + 2)
+    d_len = DeviceBuffer(rows).zero()
+    codec.encode_rows_dev(d_vals.ptr, rows, L, max(stride, 1) if L == 0 else stride, d_bytes.ptr, slot, d_len.ptr)
+    lens = d_len.to_numpy().astype(np.uint64)
+    raw = d_bytes.to_numpy().view(np.uint8)
+    for r in range(rows):
+        want = coracle.varint_encode(v[r]) if L else b""
+        assert int(lens[r]) == len(want), (r, int(lens[r]), len(want))
+        assert raw[r * slot:r * slot + len(want)].tobytes() == want, r
+    if L == 0:
+        return
+    stride2 = L + 2
+    d_dec = DeviceBuffer(rows * stride2).zero()
+    st = DeviceBuffer(1).zero()
+    codec.decode_rows_dev(d_bytes.ptr, slot, d_len.ptr, rows, L, d_dec.ptr, stride2, st.ptr)
+    assert st.to_numpy()[0] == 0
+    assert np.array_equal(d_dec.to_numpy().reshape(rows, stride2)[:, :L], v)
+    comb = crypto.ShareCombiner(crypto.Additive(3, P62))
+    out = DeviceBuffer(L)
+    comb.begin_dev(1, L)
+    comb.update_encoded_rows_dev(codec, d_bytes.ptr, slot, d_len.ptr, rows, st.ptr)
+    comb.finish_dev(out.ptr)
+    assert st.to_numpy()[0] == 0
+    assert np.array_equal(out.to_numpy(), coracle.combine(P62, v))
+    # a length that cuts a row short is reported
+    bad = lens.astype(np.int64).copy(); bad[rows // 2] -= 1
+    d_bad = DeviceBuffer.from_numpy(bad)
+    st.zero()
+    codec.decode_rows_dev(d_bytes.ptr, slot, d_bad.ptr, rows, L, d_dec.ptr, stride2, st.ptr)
+    assert st.to_numpy()[0] != 0

@@ -69,5 +69,27 @@ for rows in [int(x) for x in os.environ.get("ROWS", "2000,16000").split(",")]:
         out[f"wire_clerk_sum_{path}_{rows}x{L}"] = {"ms": dt2 * 1e3, "values_per_s": nv / dt2,
                                                    "GBps_wire_bytes": total[0] / dt2 / 1e9, "sums_equal_first_form": same}
     os.environ.pop("SDA_VARINT_PATH", None)
-    del vals, d_bytes, dec
+    # slotted rows: single pass on both sides
+    del d_bytes
+    slot = codec.slot_size(L)
+    d_slots = DeviceBuffer(rows * slot // 8 + 2)
+    d_len = DeviceBuffer(rows)
+    dt = timed(lambda: codec.encode_rows_dev(vals.ptr, rows, L, stride, d_slots.ptr, slot, d_len.ptr), reps=3)
+    wire = int(d_len.to_numpy().sum())
+    assert wire == total[0]
+    out[f"encode_slotted_{rows}x{L}"] = {"ms": dt * 1e3, "values_per_s": nv / dt, "wire_bytes": wire,
+                                         "GBps_algorithmic": (nv * 8 + wire) / dt / 1e9}
+    dt = timed(lambda: codec.decode_rows_dev(d_slots.ptr, slot, d_len.ptr, rows, L, dec.ptr, stride, st.ptr), reps=3)
+    assert st.to_numpy()[0] == 0
+    out[f"decode_slotted_{rows}x{L}"] = {"ms": dt * 1e3, "values_per_s": nv / dt, "GBps_algorithmic": (nv * 8 + wire) / dt / 1e9}
+
+    def rows_comb():
+        comb.begin_dev(1, L)
+        comb.update_encoded_rows_dev(codec, d_slots.ptr, slot, d_len.ptr, rows, st.ptr)
+        comb.finish_dev(o2.ptr)
+    dt = timed(rows_comb, reps=3)
+    assert st.to_numpy()[0] == 0
+    out[f"wire_clerk_sum_slotted_{rows}x{L}"] = {"ms": dt * 1e3, "values_per_s": nv / dt, "GBps_wire_bytes": wire / dt / 1e9,
+                                                 "sums_equal_first_form": bool((o2.to_numpy() == ref).all())}
+    del vals, d_slots, dec
 print(json.dumps(out, indent=1))
