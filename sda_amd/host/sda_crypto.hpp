@@ -128,6 +128,46 @@ struct ShareCombiner {
     }
 };
 
+// ---- share-vector wire codec (sodium.rs:36-41 `share.encode_var`, :83-89 `Share::decode_var` until EOF) ----------
+struct ShareCodec {
+    sda_varint_codec_t* h = nullptr;
+    ShareCodec() { detail::check(sda_varint_codec_new(&h)); }
+    ~ShareCodec() { sda_varint_codec_free(h); }
+    ShareCodec(const ShareCodec&) = delete;
+    std::vector<uint8_t> encode(const std::vector<Share>& shares) const {
+        std::vector<uint8_t> out(sda_varint_max_encoded_size(shares.size()) + 1);
+        size_t n = 0;
+        detail::check(sda_varint_encode(h, shares.data(), shares.size(), out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+    std::vector<Share> decode(const std::vector<uint8_t>& raw) const {
+        std::vector<Share> out(raw.size() + 1);
+        size_t n = 0;
+        detail::check(sda_varint_decode(h, raw.data(), raw.size(), out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+};
+
+/// clerk.rs:78-86 as a stream (the FIXME at :71-72): begin(dimension); add(payload) per opened sealed box; finish()
+struct StreamingShareCombiner {
+    sda_share_combiner_t* h = nullptr;
+    size_t dimension = 0;
+    explicit StreamingShareCombiner(const LinearSecretSharingScheme& s) { detail::check(sda_share_combiner_new(&s.c, &h)); }
+    ~StreamingShareCombiner() { sda_share_combiner_free(h); }
+    StreamingShareCombiner(const StreamingShareCombiner&) = delete;
+    void begin(size_t dim) { dimension = dim; detail::check(sda_share_combiner_begin(h, dim)); }
+    void add(const ShareCodec& codec, const std::vector<uint8_t>& payload) {
+        detail::check(sda_share_combiner_update_varint(h, codec.h, payload.data(), payload.size()));
+    }
+    std::vector<Share> finish() {
+        std::vector<Share> out(dimension);
+        detail::check(sda_share_combiner_finish(h, out.data()));
+        return out;
+    }
+};
+
 struct SecretReconstructor {
     sda_secret_reconstructor_t* h = nullptr;
     size_t dimension;

@@ -65,6 +65,34 @@ int main() {
     const std::vector<std::vector<int64_t>> readme = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}};
     EXPECT(run({10, 433, LinearMaskingScheme::None(), add}, readme) == (std::vector<int64_t>{0, 2, 2, 4, 4, 6, 6, 8, 8, 10}),
            "README walkthrough (README.md:157)");
+    // the same loop over the wire format: every share vector varint-encoded (sodium.rs:36-41), each clerk streaming
+    // the opened payloads into its running sum (clerk.rs:78-86 without materialising them)
+    {
+        ShareCodec codec;
+        ShareGenerator gen(pss);
+        std::vector<std::vector<std::vector<uint8_t>>> wire(8);           // [clerk][participant] payload
+        for (const auto& secrets : two) {
+            const auto shares = gen.generate(secrets);
+            for (size_t c = 0; c < 8; ++c) {
+                wire[c].push_back(codec.encode(shares[c]));
+                EXPECT(codec.decode(wire[c].back()) == shares[c], "codec round trip");
+            }
+        }
+        std::vector<std::pair<size_t, std::vector<int64_t>>> sums;
+        StreamingShareCombiner clerk(pss);
+        for (size_t c = 0; c < 8; ++c) {
+            clerk.begin(wire[c][0].empty() ? 0 : codec.decode(wire[c][0]).size());
+            for (const auto& payload : wire[c]) clerk.add(codec, payload);
+            sums.push_back({c, clerk.finish()});
+        }
+        auto out = SecretReconstructor(pss, 4).reconstruct(sums);
+        EXPECT((RecipientOutput{433, out}.positive().values) == want, "packed shamir over the wire format, streaming clerks");
+        try {
+            clerk.begin(2);
+            clerk.add(codec, codec.encode({1, 2, 3}));
+            EXPECT(false, "a payload of the wrong length must fail");
+        } catch (const SdaClientError& e) { EXPECT(std::string(e.what()) == "Wrong dimension", "combiner.rs:21 on the wire form"); }
+    }
     // error behaviour mirrors the reference's strings
     try {
         ShareCombiner(add).combine({{1, 2, 3}, {1, 2}});
