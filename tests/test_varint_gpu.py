@@ -356,3 +356,56 @@ def test_slotted_rows_encode_decode_combine(gpu, rows, L, kind, stride_pad):
     st.zero()
     codec.decode_rows_dev(d_bytes.ptr, slot, d_bad.ptr, rows, L, d_dec.ptr, stride2, st.ptr)
     assert st.to_numpy()[0] != 0
+
+
+def test_whole_pipeline_over_the_wire_format(gpu):
+    """participants -> shares -> (slotted) wire bytes -> clerks' streaming sums -> reconstruct: every stage on the
+    device, nothing decoded to a tile; the result is the sum of the secrets (participate.rs:75-76 ->
+    sodium.rs:36-41 | :83-89 -> clerk.rs:85-86 -> receive.rs:140-152), and the clerk sums equal the oracle's combine
+    of the oracle's own generated shares."""
+    from sda_amd import crypto
+    from sda_amd.capi import check
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    W8, W9 = 631229665360524489, 3451275676410824977
+    KEY = bytes(range(32))
+    k, t, n, dim, P = 3, 1, 8, 5000, 96
+    sch = crypto.PackedShamir(k, n, t, P62, W8, W9)
+    B = (dim + k - 1) // k
+    Bs = (B + 15) // 16 * 16
+    secrets = DeviceBuffer(P * dim)
+    check(gpu.sda_fill_synthetic_dev(secrets.ptr, P, dim, dim, 0, 5, P62, None))
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    shares = DeviceBuffer(n * P * Bs)                                   # job-major: [clerk][participant][Bs]
+    gen.generate_batch_dev(secrets.ptr, P, dim, dim, shares.ptr, Bs, P * Bs, first_participant=0)
+    codec = crypto.VarintCodec()
+    slot = codec.slot_size(B)
+    wire = DeviceBuffer(n * P * slot // 8 + 2)
+    lens = DeviceBuffer(n * P)
+    codec.encode_rows_dev(shares.ptr, n * P, B, Bs, wire.ptr, slot, lens.ptr)      # one message per (clerk, participant)
+    comb = crypto.ShareCombiner(sch)
+    st = DeviceBuffer(1).zero()
+    comb.begin_dev(n, B)
+    comb.update_encoded_rows_dev(codec, wire.ptr, slot, lens.ptr, n * P, st.ptr)   # all clerks' jobs in one call
+    sums = DeviceBuffer(n * B)
+    comb.finish_dev(sums.ptr)
+    assert st.to_numpy()[0] == 0
+    S = sums.to_numpy().reshape(n, B)
+    host = shares.to_numpy().reshape(n, P, Bs)[:, :, :B]
+    assert np.array_equal(S, np.stack([coracle.combine(P62, host[c]) for c in range(n)]))
+    # a participant's wire bytes are the oracle's encoding of the oracle's shares for the same draws
+    sec = secrets.to_numpy().reshape(P, dim)
+    rnd = coracle.drbg_fill(KEY, 3, B, t, P62)
+    want = coracle.packed_generate(P62, k, t, n, W8, W9, sec[3], rnd)
+    raw = wire.to_numpy().view(np.uint8)
+    ln = lens.to_numpy().astype(np.int64).reshape(n, P)
+    for c in (0, 5):
+        off = (c * P + 3) * slot
+        assert raw[off:off + ln[c, 3]].tobytes() == coracle.varint_encode(want[c])
+    rec = crypto.SecretReconstructor(sch, dim)
+    idx = [6, 0, 3, 7]                                                  # any t + k clerks
+    rows = DeviceBuffer.from_numpy(np.ascontiguousarray(S[idx]))
+    out = DeviceBuffer(dim)
+    rec.reconstruct_dev(idx, rows.ptr, B, B, out.ptr, dim)
+    assert np.array_equal(out.to_numpy(), coracle.combine(P62, sec))
