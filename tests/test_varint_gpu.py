@@ -409,3 +409,76 @@ def test_whole_pipeline_over_the_wire_format(gpu):
     out = DeviceBuffer(dim)
     rec.reconstruct_dev(idx, rows.ptr, B, B, out.ptr, dim)
     assert np.array_equal(out.to_numpy(), coracle.combine(P62, sec))
+
+
+def _row_verdict(row: bytes, L: int):
+    """(well_formed, values) of one row by the wire rules: ends on a terminator, no value longer than 10 bytes,
+    exactly L values."""
+    from oracle import coracle
+    if L == 0:
+        return len(row) == 0, np.zeros(0, dtype=np.int64)
+    if not row or row[-1] & 0x80:
+        return False, None
+    b = np.frombuffer(row, dtype=np.uint8)
+    ends = np.flatnonzero((b & 0x80) == 0)
+    sizes = np.diff(np.concatenate([[-1], ends]))
+    if sizes.max() > 10 or ends.size != L:
+        return False, None
+    return True, coracle.varint_decode(row)
+
+
+def test_decoders_on_damaged_wire_data(gpu, monkeypatch):
+    """the decoders parse bytes that untrusted participants produced: for mutated streams (bit flips, truncation,
+    extra bytes, wrong row boundaries) both forms must reach the oracle's verdict, decode the sound ones exactly,
+    and never write outside the rows they were given."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(2024)
+    codec = crypto.VarintCodec()
+    for case in range(120):
+        rows, L = int(rng.integers(1, 6)), int(rng.integers(1, 260))
+        v = _mixed(rng, rows * L).reshape(rows, L) if case % 3 else rng.integers(0, P62, size=(rows, L), dtype=np.int64)
+        enc = [bytearray(coracle.varint_encode(r)) for r in v]
+        kind = case % 6
+        for _ in range(int(rng.integers(0, 4)) if kind else 0):
+            e = enc[int(rng.integers(0, rows))]
+            if kind == 1 and len(e):
+                e[int(rng.integers(0, len(e)))] ^= 1 << int(rng.integers(0, 8))          # bit flip
+            elif kind == 2 and len(e) > 1:
+                del e[int(rng.integers(0, len(e))):]                                      # truncation
+            elif kind == 3:
+                e += bytes(rng.integers(0, 256, size=int(rng.integers(1, 14)), dtype=np.uint8))   # trailing bytes
+            elif kind == 4 and len(e):
+                pos = int(rng.integers(0, len(e)))
+                e[pos:pos] = b"\x80" * int(rng.integers(1, 13))                           # a run of continuation bytes
+            elif kind == 5 and len(e) > 2:
+                e[int(rng.integers(0, len(e)))] = 0x00                                    # a spurious terminator
+        raw = b"".join(bytes(e) for e in enc)
+        offs = np.cumsum([0] + [len(e) for e in enc]).astype(np.int64)
+        verdicts = [_row_verdict(bytes(e), L) for e in enc]
+        sound = all(ok for ok, _ in verdicts)
+        d_bytes = DeviceBuffer.from_numpy(np.frombuffer(raw + b"\0" * (-len(raw) % 8 or 8), dtype=np.int64))
+        d_off = DeviceBuffer.from_numpy(offs)
+        stride = L + 4
+        for path in ("scan", "stream"):
+            monkeypatch.setenv("SDA_VARINT_PATH", path)
+            guard = np.full((rows + 2, stride), -7, dtype=np.int64)                      # a guard row above and below
+            d_out = DeviceBuffer.from_numpy(guard)
+            st = DeviceBuffer(1).zero()
+            codec.decode_dev(d_bytes.ptr, len(raw), d_off.ptr, rows, L, d_out.ptr + 8 * stride, stride, st.ptr)
+            got = d_out.to_numpy().reshape(rows + 2, stride)
+            assert (int(st.to_numpy()[0]) == 0) == sound, (case, path, int(st.to_numpy()[0]), sound)
+            assert (got[0] == -7).all() and (got[-1] == -7).all() and (got[1:-1, L:] == -7).all(), (case, path)
+            if sound:
+                assert np.array_equal(got[1:-1, :L], np.stack([vals for _, vals in verdicts])), (case, path)
+            # the clerk form on the same bytes: same verdict, and the exact sums when sound
+            comb = crypto.ShareCombiner(crypto.Additive(3, P62))
+            st.zero()
+            out = DeviceBuffer(L)
+            comb.begin_dev(1, L)
+            comb.update_encoded_dev(codec, d_bytes.ptr, len(raw), d_off.ptr, rows, st.ptr)
+            comb.finish_dev(out.ptr)
+            assert (int(st.to_numpy()[0]) == 0) == sound, (case, path, "clerk")
+            if sound:
+                assert np.array_equal(out.to_numpy(), coracle.combine(P62, np.stack([vals for _, vals in verdicts])))
