@@ -293,6 +293,16 @@ int sda_secret_masker_mask(sda_secret_masker_t* m,
                            int64_t* mask_out, size_t mask_cap, size_t* mask_len,
                            int64_t* masked_out);
 
+/* device-resident batch: participate.rs:52-54 for a whole tile of participants.  Full: masks[p][i] uniform from the
+ * on-device CSPRNG (stream first_participant + p; reproducible with sda_secret_masker_set_drbg_key),
+ * masked[p][i] = (secrets[p][i] + masks[p][i]) mod q.  None: masked = secrets, d_masks untouched.  ChaCha draws an
+ * OS-entropy seed per participant (chacha.rs:29-33) -> SDA_ERR_UNSUPPORTED, use sda_secret_masker_mask.  The P mask
+ * vectors are combined on the recipient side exactly like shares (full.rs:37-52 == combiner.rs:15-29): feed them to
+ * an sda_share_combiner begun with jobs == 1. */
+int sda_secret_masker_mask_batch_dev(sda_secret_masker_t* m, const int64_t* d_secrets, size_t participants, size_t len,
+                                     size_t secrets_stride, uint64_t first_participant, int64_t* d_masks,
+                                     size_t mask_stride, int64_t* d_masked, size_t masked_stride, void* stream);
+
 /* new_mask_combiner(&scheme) - masking/mod.rs:55-75 */
 int  sda_mask_combiner_new(const sda_masking_scheme_t* scheme, sda_mask_combiner_t** out);
 void sda_mask_combiner_free(sda_mask_combiner_t* c);
@@ -318,6 +328,11 @@ int sda_secret_unmasker_unmask(sda_secret_unmasker_t* u,
                                const int64_t* mask, size_t mask_len,
                                const int64_t* masked, size_t masked_len,
                                int64_t* out);
+
+/* the same on device-resident vectors (receive.rs:149-152 once the masks are combined): out = (masked - mask) mod q;
+ * None: out = masked */
+int sda_secret_unmasker_unmask_dev(sda_secret_unmasker_t* u, const int64_t* d_mask, const int64_t* d_masked, size_t len,
+                                   int64_t* d_out, void* stream);
 
 /* RecipientOutput::positive - client/src/receive.rs:13-21: v < 0 ? v + modulus : v.  Host-side,
  * element-wise; the identity on this library's canonical outputs. */

@@ -126,6 +126,9 @@ SIGNATURES = {
     "sda_share_combiner_update_varint_dev": (C.c_int, [_H, _H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                                        C.c_void_p]),
     "sda_share_combiner_update_varint": (C.c_int, [_H, _H, c_u8p, C.c_size_t]),
+    "sda_secret_masker_mask_batch_dev": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64,
+                                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sda_secret_unmasker_unmask_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "sda_varint_slot_size": (C.c_size_t, [C.c_size_t]),
     "sda_varint_encode_rows_dev": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                              C.c_void_p, C.c_void_p]),

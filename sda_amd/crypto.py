@@ -307,6 +307,14 @@ class SecretMasker(_Handle):
                                                      C.byref(n_mask), _ptr(masked)))
         return mask[:n_mask.value].copy(), masked[:s.size].copy()
 
+    def mask_batch_dev(self, d_secrets: int, participants: int, length: int, secrets_stride: int, d_masks: int,
+                       mask_stride: int, d_masked: int, masked_stride: int, first_participant: int = 0,
+                       stream: int = 0) -> None:
+        """participate.rs:52-54 for a device-resident tile (Full / None schemes)"""
+        check(self._lib.sda_secret_masker_mask_batch_dev(self._h, d_secrets, participants, length, secrets_stride,
+                                                         first_participant, d_masks or None, mask_stride, d_masked,
+                                                         masked_stride, stream or None))
+
 
 class MaskCombiner(_Handle):
     """masking/mod.rs:21-23; impl none.rs:21-26, full.rs:37-52, chacha.rs:56-77."""
@@ -346,6 +354,9 @@ class SecretUnmasker(_Handle):
         _check_mask(self._lib.sda_secret_unmasker_unmask(self._h, _ptr(mask), mask.size, _ptr(masked), masked.size,
                                                          _ptr(out)))
         return out[:masked.size].copy()
+
+    def unmask_dev(self, d_mask: int, d_masked: int, length: int, d_out: int, stream: int = 0) -> None:
+        check(self._lib.sda_secret_unmasker_unmask_dev(self._h, d_mask or None, d_masked, length, d_out, stream or None))
 
 
 # ---- factory (client/src/crypto/mod.rs:58-66) ---------------------------------------------------------------

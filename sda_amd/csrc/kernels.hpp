@@ -111,10 +111,11 @@ hipError_t launch_packed_reconstruct(const int64_t* d_shares, size_t row_stride,
 // out = (a + b) mod m   or   (a - b) mod m, any i64 inputs
 hipError_t launch_addsub_mod(const int64_t* d_a, const int64_t* d_b, size_t len, bool subtract,
                              const ModParams& mod, int64_t* d_out, hipStream_t s);
-// full.rs:21-35 with the on-device CSPRNG: mask[i] uniform, masked[i] = (s[i] + mask[i]) mod m
-hipError_t launch_full_mask_drbg(const int64_t* d_secrets, size_t len, uint64_t stream_id,
-                                 const ModParams& mod, const DrbgKey& key, int rounds,
-                                 int64_t* d_mask, int64_t* d_masked, hipStream_t s);
+// full.rs:21-35 with the on-device CSPRNG, `participants` vectors at once: mask[p][i] uniform (DRBG stream
+// first_stream + p), masked[p][i] = (s[p][i] + mask[p][i]) mod m
+hipError_t launch_full_mask_drbg(const int64_t* d_secrets, size_t secrets_stride, size_t participants, size_t len,
+                                 uint64_t first_stream, const ModParams& mod, const DrbgKey& key, int rounds,
+                                 int64_t* d_mask, size_t mask_stride, int64_t* d_masked, size_t masked_stride, hipStream_t s);
 
 // ---- rand-0.3 ChaChaRng mask expansion (chacha.rs:36-39, :60-73) ----------------------------------
 // Adds the `dimension` masks of each of the n_seeds seeds into the 128-bit accumulators.

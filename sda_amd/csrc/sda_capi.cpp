@@ -996,8 +996,8 @@ extern "C" int sda_secret_masker_mask(sda_secret_masker_t* m, const int64_t* sec
             HIP_TRY(launch_addsub_mod(c.d_b.as<int64_t>(), c.d_a.as<int64_t>(), len, false, c.mod, c.tile.as<int64_t>(), s));
             HIP_TRY(hipMemcpyAsync(c.d_b.p, c.tile.p, len * 8, hipMemcpyDeviceToDevice, s));
         } else {
-            HIP_TRY(launch_full_mask_drbg(c.d_a.as<int64_t>(), len, c.drbg.next_stream++, c.mod, c.drbg.key, c.drbg.rounds,
-                                          c.d_b.as<int64_t>(), c.d_out.as<int64_t>(), s));
+            HIP_TRY(launch_full_mask_drbg(c.d_a.as<int64_t>(), len, 1, len, c.drbg.next_stream++, c.mod, c.drbg.key, c.drbg.rounds,
+                                          c.d_b.as<int64_t>(), len, c.d_out.as<int64_t>(), len, s));
         }
         HIP_TRY(hipMemcpyAsync(mask_out, c.d_b.p, len * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(masked_out, c.d_out.p, len * 8, hipMemcpyDeviceToHost, s));
@@ -1032,6 +1032,31 @@ extern "C" int sda_secret_masker_mask(sda_secret_masker_t* m, const int64_t* sec
     }
     for (size_t i = 0; i < nw; ++i) mask_out[i] = seed[i];                    // chacha.rs:48-50
     *mask_len = nw;
+    return SDA_OK;
+}
+
+// device-resident batch of participants (participate.rs:52-54 for a whole tile): Full and None schemes
+extern "C" int sda_secret_masker_mask_batch_dev(sda_secret_masker_t* m, const int64_t* d_secrets, size_t participants,
+                                                size_t len, size_t secrets_stride, uint64_t first_participant,
+                                                int64_t* d_masks, size_t mask_stride, int64_t* d_masked,
+                                                size_t masked_stride, void* stream) {
+    if (!m) return fail(SDA_ERR_INVALID_ARGUMENT, "masker is NULL");
+    MaskCore& c = m->core;
+    if (participants == 0 || len == 0) return SDA_OK;
+    if (!d_secrets || !d_masked) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (secrets_stride < len || masked_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "stride < len");
+    if (c.scheme.kind == SDA_MASKING_CHACHA)
+        return fail(SDA_ERR_UNSUPPORTED, "ChaCha masking draws one OS-entropy seed per participant (chacha.rs:29-33): use sda_secret_masker_mask");
+    if (c.scheme.kind == SDA_MASKING_NONE) {                                  // none.rs:13-19: identity, no mask
+        HIP_TRY(hipMemcpy2DAsync(d_masked, masked_stride * 8, d_secrets, secrets_stride * 8, len * 8, participants,
+                                 hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
+        return SDA_OK;
+    }
+    if (!d_masks) return fail(SDA_ERR_INVALID_ARGUMENT, "d_masks is NULL");
+    if (mask_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "stride < len");
+    SDA_TRY(c.ctx.use());
+    HIP_TRY(launch_full_mask_drbg(d_secrets, secrets_stride, participants, len, first_participant, c.mod, c.drbg.key,
+                                  c.drbg.rounds, d_masks, mask_stride, d_masked, masked_stride, c.ctx.pick(stream)));
     return SDA_OK;
 }
 
@@ -1103,6 +1128,23 @@ extern "C" int sda_secret_unmasker_unmask(sda_secret_unmasker_t* u, const int64_
     HIP_TRY(launch_addsub_mod(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), masked_len, true, c.mod, c.d_out.as<int64_t>(), s));   // (ms - m) % q
     HIP_TRY(hipMemcpyAsync(out, c.d_out.p, masked_len * 8, hipMemcpyDeviceToHost, s));
     return c.ctx.sync();
+}
+
+// (masked - mask) mod q on device-resident vectors (full.rs:54-67, chacha.rs:79-93 once the masks are combined)
+extern "C" int sda_secret_unmasker_unmask_dev(sda_secret_unmasker_t* u, const int64_t* d_mask, const int64_t* d_masked,
+                                              size_t len, int64_t* d_out, void* stream) {
+    if (!u) return fail(SDA_ERR_INVALID_ARGUMENT, "unmasker is NULL");
+    MaskCore& c = u->core;
+    if (len == 0) return SDA_OK;
+    if (!d_masked || !d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (c.scheme.kind == SDA_MASKING_NONE) {                                  // none.rs:28-33
+        if (d_out != d_masked) HIP_TRY(hipMemcpyAsync(d_out, d_masked, len * 8, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
+        return SDA_OK;
+    }
+    if (!d_mask) return fail(SDA_ERR_INVALID_ARGUMENT, "d_mask is NULL");
+    SDA_TRY(c.ctx.use());
+    HIP_TRY(launch_addsub_mod(d_masked, d_mask, len, true, c.mod, d_out, c.ctx.pick(stream)));
+    return SDA_OK;
 }
 
 extern "C" int sda_positive(const int64_t* values, size_t len, int64_t modulus, int64_t* out) {

@@ -643,15 +643,29 @@ __global__ __launch_bounds__(kThreads) void addsub_mod_kernel(const int64_t* __r
     out[i] = (int64_t)(subtract ? submod(x, y, mod.m) : addmod(x, y, mod.m));
 }
 
+// participant p = blockIdx.y of the launch's slice: stream = first stream + p, rows at p * stride; one lane = two
+// adjacent elements (16-byte accesses when the rows allow it)
 template <int ROUNDS>
-__global__ __launch_bounds__(kThreads) void full_mask_drbg_kernel(const int64_t* __restrict__ secrets, size_t len,
-                                                                  uint64_t stream, ModParams mod, DrbgKey key,
-                                                                  int64_t* __restrict__ mask,
-                                                                  int64_t* __restrict__ masked) {
+__global__ __launch_bounds__(kThreads) void full_mask_drbg_kernel(const int64_t* __restrict__ secrets, size_t secrets_stride,
+                                                                  size_t len, uint64_t stream, ModParams mod, DrbgKey key,
+                                                                  int64_t* __restrict__ mask, size_t mask_stride,
+                                                                  int64_t* __restrict__ masked, size_t masked_stride,
+                                                                  bool vec) {
     const uint64_t pair = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    const uint64_t b0 = 2 * pair;
+    const uint64_t b0 = 2 * pair, p = blockIdx.y;
     uint64_t r0, r1;
-    drbg_pair<ROUNDS>(key, quad_col(key), stream, pair, 1, 0, mod, r0, r1);
+    drbg_pair<ROUNDS>(key, quad_col(key), stream + p, pair, 1, 0, mod, r0, r1);
+    secrets += p * secrets_stride; mask += p * mask_stride; masked += p * masked_stride;
+    if (vec && b0 + 1 < len) {
+        const ll2 sv = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(secrets + b0));
+        ll2 mk, ms;
+        mk.x = (int64_t)r0; mk.y = (int64_t)r1;
+        ms.x = (int64_t)addmod(canon_i64(sv.x, mod.m, mod.mu), r0, mod.m);
+        ms.y = (int64_t)addmod(canon_i64(sv.y, mod.m, mod.mu), r1, mod.m);
+        __builtin_nontemporal_store(mk, reinterpret_cast<ll2*>(mask + b0));
+        __builtin_nontemporal_store(ms, reinterpret_cast<ll2*>(masked + b0));
+        return;
+    }
     if (b0 < len) {
         mask[b0] = (int64_t)r0;
         masked[b0] = (int64_t)addmod(canon_i64(secrets[b0], mod.m, mod.mu), r0, mod.m);
@@ -1144,16 +1158,30 @@ hipError_t launch_addsub_mod(const int64_t* d_a, const int64_t* d_b, size_t len,
     return hipGetLastError();
 }
 
-hipError_t launch_full_mask_drbg(const int64_t* d_secrets, size_t len, uint64_t stream_id, const ModParams& mod,
-                                 const DrbgKey& key, int rounds, int64_t* d_mask, int64_t* d_masked, hipStream_t s) {
-    if (len == 0) return hipSuccess;
+hipError_t launch_full_mask_drbg(const int64_t* d_secrets, size_t secrets_stride, size_t participants, size_t len,
+                                 uint64_t first_stream, const ModParams& mod, const DrbgKey& key, int rounds,
+                                 int64_t* d_mask, size_t mask_stride, int64_t* d_masked, size_t masked_stride, hipStream_t s) {
+    if (len == 0 || participants == 0) return hipSuccess;
     const uint64_t blocks = ceil_div(ceil_div(len, 2), kThreads);
     if (hipError_t e = grid_check(blocks)) return e;
-    switch (rounds) {
-        case 20: full_mask_drbg_kernel<20><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_secrets, len, stream_id, mod, key, d_mask, d_masked); break;
-        case 12: full_mask_drbg_kernel<12><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_secrets, len, stream_id, mod, key, d_mask, d_masked); break;
-        case 8: full_mask_drbg_kernel<8><<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_secrets, len, stream_id, mod, key, d_mask, d_masked); break;
-        default: return hipErrorInvalidValue;
+    const bool vec = aligned16(d_secrets) && aligned16(d_mask) && aligned16(d_masked) && secrets_stride % 2 == 0 &&
+                     mask_stride % 2 == 0 && masked_stride % 2 == 0;
+    // < 2^32 work-items per launch and <= 65535 in y: slices of participants
+    uint64_t per = 0xFFFFFFFFull / (blocks * kThreads);
+    if (per > 65535) per = 65535;
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (size_t p0 = 0; p0 < participants; p0 += per) {
+        const unsigned np = (unsigned)(participants - p0 < per ? participants - p0 : per);
+        const dim3 grid((unsigned)blocks, np);
+        const int64_t* sp = d_secrets + p0 * secrets_stride;
+        int64_t* mp = d_mask + p0 * mask_stride;
+        int64_t* xp = d_masked + p0 * masked_stride;
+        switch (rounds) {
+            case 20: full_mask_drbg_kernel<20><<<grid, dim3(kThreads), 0, s>>>(sp, secrets_stride, len, first_stream + p0, mod, key, mp, mask_stride, xp, masked_stride, vec); break;
+            case 12: full_mask_drbg_kernel<12><<<grid, dim3(kThreads), 0, s>>>(sp, secrets_stride, len, first_stream + p0, mod, key, mp, mask_stride, xp, masked_stride, vec); break;
+            case 8: full_mask_drbg_kernel<8><<<grid, dim3(kThreads), 0, s>>>(sp, secrets_stride, len, first_stream + p0, mod, key, mp, mask_stride, xp, masked_stride, vec); break;
+            default: return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }

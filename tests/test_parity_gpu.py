@@ -385,6 +385,67 @@ def test_full_and_none_masking(gpu):
     assert list(crypto.SecretUnmasker(none).unmask(([], [3, -4]))) == [3, -4]
 
 
+@pytest.mark.parametrize("P,dim,pad", [(1, 1, 0), (5, 1001, 3), (40, 4096, 0), (7, 777, 1)])
+def test_masked_participation_on_device(gpu, P, dim, pad):
+    """participate.rs:52-76 for a device-resident tile: full masking (masks from the device CSPRNG, stream = participant)
+    then additive share generation of the MASKED secrets; recipient side receive.rs:113-152: combine masks, combine
+    clerk sums, reconstruct, unmask == sum of the secrets.  Every stage against the oracle."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    q = P62
+    rng = np.random.default_rng(P * 31 + dim)
+    stride = dim + pad
+    sec = np.zeros((P, stride), dtype=np.int64)
+    sec[:, :dim] = rng.integers(-(1 << 62), 1 << 62, size=(P, dim), dtype=np.int64)       # any i64 is accepted
+    d_sec = DeviceBuffer.from_numpy(sec)
+    masker = crypto.SecretMasker(crypto.Full(q))
+    masker.set_drbg_key(KEY)
+    d_mask, d_masked = DeviceBuffer(P * stride).zero(), DeviceBuffer(P * stride).zero()
+    masker.mask_batch_dev(d_sec.ptr, P, dim, stride, d_mask.ptr, stride, d_masked.ptr, stride, first_participant=100)
+    masks = d_mask.to_numpy().reshape(P, stride)
+    masked = d_masked.to_numpy().reshape(P, stride)
+    for p in (0, P // 2, P - 1):
+        want = coracle.drbg_fill(KEY, 100 + p, dim, 1, q)
+        assert np.array_equal(masks[p, :dim], want)
+        assert np.array_equal(masked[p, :dim], coracle.addsub(sec[p, :dim], want, q))
+    assert not masks[:, dim:].any() and not masked[:, dim:].any()
+    # shares of the masked secrets, clerk sums, reconstruction
+    sch = crypto.Additive(3, q)
+    gen = crypto.ShareGenerator(sch); gen.set_drbg_key(KEY)
+    Bs = dim + (dim & 1)
+    shares = DeviceBuffer(3 * P * Bs).zero()
+    gen.generate_batch_dev(d_masked.ptr, P, dim, stride, shares.ptr, Bs, P * Bs, first_participant=100)
+    comb = crypto.ShareCombiner(sch)
+    comb.begin_dev(3, dim)
+    comb.update_dev(shares.ptr, P * Bs, P, Bs)
+    sums = DeviceBuffer(3 * dim)
+    comb.finish_dev(sums.ptr)
+    rec = crypto.SecretReconstructor(sch, dim)
+    masked_total = DeviceBuffer(dim)
+    rec.reconstruct_dev([0, 1, 2], sums.ptr, dim, dim, masked_total.ptr, dim)
+    assert np.array_equal(masked_total.to_numpy(), coracle.combine(q, masked[:, :dim]))
+    # recipient: the P mask vectors are combined like shares (full.rs:37-52), then unmask
+    mc = crypto.ShareCombiner(sch)
+    mc.begin_dev(1, dim)
+    mc.update_dev(d_mask.ptr, 0, P, stride)
+    mask_total = DeviceBuffer(dim)
+    mc.finish_dev(mask_total.ptr)
+    assert np.array_equal(mask_total.to_numpy(), crypto.MaskCombiner(crypto.Full(q)).combine(list(masks[:, :dim])))
+    out = DeviceBuffer(dim)
+    crypto.SecretUnmasker(crypto.Full(q)).unmask_dev(mask_total.ptr, masked_total.ptr, dim, out.ptr)
+    assert np.array_equal(out.to_numpy(), coracle.combine(q, sec[:, :dim]))
+    # None: identity; ChaCha: refused with a pointer to the host form
+    none = crypto.SecretMasker(crypto.NoMask())
+    d2 = DeviceBuffer(P * stride).zero()
+    none.mask_batch_dev(d_sec.ptr, P, dim, stride, 0, 0, d2.ptr, stride)
+    assert np.array_equal(d2.to_numpy().reshape(P, stride)[:, :dim], sec[:, :dim])
+    from sda_amd import capi
+    with pytest.raises(capi.SdaError):
+        crypto.SecretMasker(crypto.ChaCha(q, dim, 128)).mask_batch_dev(d_sec.ptr, P, dim, stride, d_mask.ptr, stride,
+                                                                     d_masked.ptr, stride)
+
+
 def test_scheme_validation(gpu):
     from sda_amd import capi, crypto
     for bad in (crypto.Additive(3, 1), crypto.Additive(0, 433), crypto.Additive(3, 1 << 62),

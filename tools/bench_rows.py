@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-row measurements for the SURVEY.md 8(a) kernels that are not on bench.py's headline path:
 reconstruct (R0/R1), ChaCha mask expansion/combination (M2), full masking (M1), unmask (K6), the
-cross-GPU partial-sum reducer (X1).  Prints one JSON object; run on the GPU box."""
+cross-GPU partial-sum reducer (X1).  The wire-format rows are in tools/bench_wire.py.  Prints one JSON object; run on
+the GPU box."""
 import ctypes as C
 import json
 import os
@@ -73,32 +74,25 @@ dt = timed(lambda: capi.check(lib.sda_modsum_parts_dev(P62, d.ptr, parts, L, L, 
 out["modsum_parts_8x358MB"] = {"ms": dt * 1e3, "GBps_algorithmic": (parts + 1) * L * 8 / dt / 1e9}
 del d, o
 
-# 8f rank 1: wire codec on one clerk job tile: 2000 participants x L = 349526 canonical 62-bit shares
-rows, L, stride = 2000, 349526, 349536
-vals = DeviceBuffer(rows * stride)
-capi.check(lib.sda_fill_synthetic_dev(vals.ptr, rows, stride, stride, 0, 9, P62, None))
-codec = crypto.VarintCodec()
-cap = rows * L * 10
-d_bytes = DeviceBuffer((cap + 7) // 8)
-d_off = DeviceBuffer(rows + 1)
-total = [0]
-def enc():
-    total[0] = codec.encode_dev(vals.ptr, rows, L, stride, d_bytes.ptr, cap, d_off.ptr)
-dt = timed(enc, reps=3)
-nv = rows * L
-out["varint_encode_2000x349526"] = {"ms": dt * 1e3, "values_per_s": nv / dt, "wire_bytes": total[0],
-                                    "GBps_algorithmic": (nv * 8 + total[0]) / dt / 1e9}
-dec = DeviceBuffer(rows * stride)
-st = DeviceBuffer(1).zero()
-dt = timed(lambda: codec.decode_dev(d_bytes.ptr, total[0], d_off.ptr, rows, L, dec.ptr, stride, st.ptr), reps=3)
-assert st.to_numpy()[0] == 0
-out["varint_decode_2000x349526"] = {"ms": dt * 1e3, "values_per_s": nv / dt,
-                                    "GBps_algorithmic": (nv * 8 + total[0]) / dt / 1e9}
-comb = crypto.ShareCombiner(crypto.Additive(3, P62))
-o2 = DeviceBuffer(L)
-def dec_comb():
-    codec.decode_dev(d_bytes.ptr, total[0], d_off.ptr, rows, L, dec.ptr, stride, st.ptr)
-    comb.begin_dev(1, L); comb.update_dev(dec.ptr, 0, rows, stride); comb.finish_dev(o2.ptr)
-dt = timed(dec_comb, reps=3)
-out["varint_decode_then_clerk_sum_2000x349526"] = {"ms": dt * 1e3, "values_per_s": nv / dt}
+# M1 on device: full masking of a resident tile (participate.rs:52-54 x 2000 participants), masks from the device CSPRNG
+P, dim = 2000, 1 << 20
+sec = DeviceBuffer(P * dim)
+capi.check(lib.sda_fill_synthetic_dev(sec.ptr, P, dim, dim, 0, 11, P62, None))
+d_mask, d_masked = DeviceBuffer(P * dim), DeviceBuffer(P * dim)
+mk = crypto.SecretMasker(crypto.Full(P62))
+dt = timed(lambda: mk.mask_batch_dev(sec.ptr, P, dim, dim, d_mask.ptr, dim, d_masked.ptr, dim), reps=3)
+out["full_mask_batch_dev_2000x1Mi"] = {"ms": dt * 1e3, "elements_per_s": P * dim / dt,
+                                      "GBps_algorithmic": P * dim * 24 / dt / 1e9,
+                                      "note": "8 B read + 8 B mask + 8 B masked per element, one ChaCha20 draw per element"}
+# recipient: combine the 2000 mask vectors (full.rs:37-52 == the clerk-sum kernel), then unmask (full.rs:54-67)
+cm = crypto.ShareCombiner(crypto.Additive(3, P62))
+tot, o3 = DeviceBuffer(dim), DeviceBuffer(dim)
+def comb_masks():
+    cm.begin_dev(1, dim); cm.update_dev(d_mask.ptr, 0, P, dim); cm.finish_dev(tot.ptr)
+dt = timed(comb_masks, reps=3)
+out["full_mask_combine_dev_2000x1Mi"] = {"ms": dt * 1e3, "elements_per_s": P * dim / dt, "GBps_algorithmic": P * dim * 8 / dt / 1e9}
+um = crypto.SecretUnmasker(crypto.Full(P62))
+dt = timed(lambda: um.unmask_dev(tot.ptr, d_masked.ptr, dim, o3.ptr), reps=5)
+out["unmask_dev_1Mi"] = {"ms": dt * 1e3, "elements_per_s": dim / dt}
+del sec, d_mask, d_masked
 print(json.dumps(out, indent=1))
