@@ -102,10 +102,28 @@ def _ptr(a: np.ndarray):
 
 
 def _rows(vectors: Sequence) -> Tuple[List[np.ndarray], C.Array, C.Array]:
+    if isinstance(vectors, np.ndarray) and vectors.ndim == 2 and vectors.dtype == np.int64 and vectors.shape[0] > 0 \
+            and vectors.strides[1] == 8:
+        # a matrix: row pointers by arithmetic instead of one ctypes object per row (thousands of seeds / vectors)
+        n = vectors.shape[0]
+        addr = (vectors.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(vectors.strides[0])).astype(np.uint64)
+        lens_np = np.full(n, vectors.shape[1], dtype=np.uint64)
+        ptrs = C.cast(addr.ctypes.data_as(C.POINTER(C.c_uint64)), C.POINTER(capi.c_i64p))
+        lens = C.cast(lens_np.ctypes.data_as(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t))
+        rows = _MatrixRows(vectors, addr, lens_np)
+        return rows, ptrs, lens
     arrs = [_vec(v) for v in vectors]
     ptrs = (capi.c_i64p * max(len(arrs), 1))(*[_ptr(a) for a in arrs])
     lens = (C.c_size_t * max(len(arrs), 1))(*[a.size for a in arrs])
     return arrs, ptrs, lens
+
+
+class _MatrixRows(list):
+    """keeps the matrix and the pointer/length arrays alive; len() = rows, [0].size = columns"""
+
+    def __init__(self, matrix, addr, lens):
+        super().__init__(matrix)
+        self._keep = (matrix, addr, lens)
 
 
 def _check_mask(status: int) -> None:

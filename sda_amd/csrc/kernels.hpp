@@ -121,11 +121,23 @@ hipError_t launch_full_mask_drbg(const int64_t* d_secrets, size_t secrets_stride
 // Adds the `dimension` masks of each of the n_seeds seeds into the 128-bit accumulators.
 // d_seeds: n_seeds x 8 u32 key words (seed words beyond the given ones are 0).
 // Fast path: candidate i of every seed is added at position i (correct unless the seed's stream
-// contains a rejected candidate).  d_reject_flags[s] is set to 1 when seed s hit a rejection (zone
-// test); those seeds must then be corrected by launch_chacha_mask_slow(subtract_naive = true).
+// contains a rejected candidate).  d_rejects[s] (zeroed by the caller) counts the rejected candidates of
+// seed s among its first `dimension` and keeps the index of up to three of them; such seeds must then be
+// corrected by launch_chacha_mask_shift (count <= 3) or launch_chacha_mask_slow(subtract_naive = true).
+struct RejectRecord {
+    uint32_t count;
+    uint32_t pos[3];
+};
 hipError_t launch_chacha_mask_accumulate(const uint32_t* d_seeds, size_t n_seeds, size_t dimension,
                                          const ModParams& mod, uint64_t zone, uint64_t* d_acc_lo,
-                                         int64_t* d_acc_hi, uint32_t* d_reject_flags, hipStream_t s);
+                                         int64_t* d_acc_hi, RejectRecord* d_rejects, hipStream_t s);
+// Parallel correction of the seeds in d_list whose rejected candidates are all recorded (count 1..3): removing
+// candidate x shifts every later mask by one, so position i >= x takes candidate i + (rejections so far) instead of
+// candidate i - each lane recomputes two ChaCha blocks and adds the difference.  The last few positions reach
+// past candidate `dimension`, which the fast kernel never tested: those lanes walk on until they have their mask.
+hipError_t launch_chacha_mask_shift(const uint32_t* d_seeds, const uint32_t* d_list, size_t n_list,
+                                    const RejectRecord* d_rejects, size_t dimension, const ModParams& mod,
+                                    uint64_t zone, uint64_t* d_acc_lo, int64_t* d_acc_hi, hipStream_t s);
 // exact sequential-order expansion (handles rejections) of the seeds named by d_list (n_list indices
 // into d_seeds; d_list == nullptr -> seeds 0..n_list-1), added into the accumulators.  With
 // subtract_naive the fast kernel's contribution for those seeds is taken back first.

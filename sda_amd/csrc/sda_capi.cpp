@@ -264,9 +264,10 @@ int chacha_accumulate(const Ctx& ctx, const std::vector<uint32_t>& seeds8, size_
                       const ModParams& mod, AccState& acc, DevBuf& d_seeds, DevBuf& d_flags, DevBuf& d_list) {
     if (n_seeds == 0 || dimension == 0) return SDA_OK;
     const uint64_t zone = rand03_zone(mod.m);
-    // expected rejected candidates per seed; above ~1/4 the naive fast path is wasted work
+    // expected rejected candidates per seed: up to about one, nearly every seed is either clean or repaired by the
+    // parallel shift pass (<= 3 rejections); beyond that the exact-order kernel does everything
     const double p_rej = (double)(UINT64_MAX - zone + 1) / 18446744073709551616.0;
-    const bool all_slow = p_rej * (double)dimension > 0.25;
+    const bool all_slow = p_rej * (double)dimension > 1.0 || dimension >= 0xFFFFFFF0ull;
     const size_t chunk = (size_t)1 << 20;                  // seeds per launch
     for (size_t s0 = 0; s0 < n_seeds; s0 += chunk) {
         const size_t ns = std::min(chunk, n_seeds - s0);
@@ -278,21 +279,29 @@ int chacha_accumulate(const Ctx& ctx, const std::vector<uint32_t>& seeds8, size_
             HIP_TRY(hipStreamSynchronize(ctx.stream));
             continue;
         }
-        SDA_TRY(d_flags.reserve(ns * 4));
-        HIP_TRY(hipMemsetAsync(d_flags.p, 0, ns * 4, ctx.stream));
+        SDA_TRY(d_flags.reserve(ns * sizeof(RejectRecord)));
+        HIP_TRY(hipMemsetAsync(d_flags.p, 0, ns * sizeof(RejectRecord), ctx.stream));
         HIP_TRY(launch_chacha_mask_accumulate(d_seeds.as<uint32_t>(), ns, dimension, mod, zone, acc.lo.as<uint64_t>(),
-                                              acc.hi.as<int64_t>(), d_flags.as<uint32_t>(), ctx.stream));
-        std::vector<uint32_t> flags(ns);
-        HIP_TRY(hipMemcpyAsync(flags.data(), d_flags.p, ns * 4, hipMemcpyDeviceToHost, ctx.stream));
+                                              acc.hi.as<int64_t>(), d_flags.as<RejectRecord>(), ctx.stream));
+        std::vector<RejectRecord> rec(ns);
+        HIP_TRY(hipMemcpyAsync(rec.data(), d_flags.p, ns * sizeof(RejectRecord), hipMemcpyDeviceToHost, ctx.stream));
         HIP_TRY(hipStreamSynchronize(ctx.stream));
-        std::vector<uint32_t> list;
+        std::vector<uint32_t> shift, exact;                 // seeds repaired in parallel / walked in stream order
         for (size_t i = 0; i < ns; ++i)
-            if (flags[i]) list.push_back((uint32_t)i);
-        if (!list.empty()) {
-            SDA_TRY(d_list.reserve(list.size() * 4));
-            HIP_TRY(hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx.stream));
-            HIP_TRY(launch_chacha_mask_slow(d_seeds.as<uint32_t>(), d_list.as<uint32_t>(), list.size(), dimension, mod, zone,
-                                            acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), true, ctx.stream));
+            if (rec[i].count) (rec[i].count <= 3 ? shift : exact).push_back((uint32_t)i);
+        if (!shift.empty() || !exact.empty()) {
+            SDA_TRY(d_list.reserve((shift.size() + exact.size()) * 4));
+            uint32_t* dl = d_list.as<uint32_t>();
+            if (!shift.empty()) {
+                HIP_TRY(hipMemcpyAsync(dl, shift.data(), shift.size() * 4, hipMemcpyHostToDevice, ctx.stream));
+                HIP_TRY(launch_chacha_mask_shift(d_seeds.as<uint32_t>(), dl, shift.size(), d_flags.as<RejectRecord>(), dimension, mod,
+                                                 zone, acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), ctx.stream));
+            }
+            if (!exact.empty()) {
+                HIP_TRY(hipMemcpyAsync(dl + shift.size(), exact.data(), exact.size() * 4, hipMemcpyHostToDevice, ctx.stream));
+                HIP_TRY(launch_chacha_mask_slow(d_seeds.as<uint32_t>(), dl + shift.size(), exact.size(), dimension, mod, zone,
+                                                acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), true, ctx.stream));
+            }
             HIP_TRY(hipStreamSynchronize(ctx.stream));
         }
     }

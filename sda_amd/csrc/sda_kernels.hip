@@ -688,7 +688,7 @@ __global__ __launch_bounds__(kThreads) void chacha_mask_fast_kernel(const uint32
                                                                     size_t n_seeds, size_t dimension, ModParams mod,
                                                                     uint64_t zone, uint64_t* __restrict__ acc_lo,
                                                                     int64_t* __restrict__ acc_hi,
-                                                                    uint32_t* __restrict__ flags,
+                                                                    RejectRecord* __restrict__ rejects,
                                                                     size_t seeds_per_split) {
     const uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x;   // ChaCha block index
     const size_t pos0 = j * 8;
@@ -708,21 +708,90 @@ __global__ __launch_bounds__(kThreads) void chacha_mask_fast_kernel(const uint32
         for (int w = 0; w < 8; ++w) key[w] = seeds[s * 8 + w];          // wave-uniform -> SGPRs
         uint32_t o[16];
         chacha_block_lane<20>(key, (uint32_t)j, (uint32_t)(j >> 32), 0u, 0u, o);
-        bool rejected = false;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const uint64_t v = ((uint64_t)o[2 * m] << 32) | o[2 * m + 1];
-            if (pos0 + m < dimension && v >= zone) rejected = true;
-            const uint64_t r = barrett_mod64(v, mod.m, mod.mu);
-            const uint64_t nl = lo[m] + r;
+            if (pos0 + m < dimension && v >= zone) {                       // rare: record where, for the correction pass
+                const uint32_t k = atomicAdd(&rejects[s].count, 1u);
+                if (k < 3) rejects[s].pos[k] = (uint32_t)(pos0 + m);
+            }
+            // the candidate itself is added, not v % m: the sums are only ever read modulo m (combine_finish), and
+            // v == v % m there - one Barrett reduction per column at the end instead of one per mask
+            const uint64_t nl = lo[m] + v;
             hi[m] += nl < lo[m] ? 1u : 0u;
             lo[m] = nl;
         }
-        if (rejected) flags[s] = 1u;
     }
 #pragma unroll
     for (int m = 0; m < 8; ++m)
         if (pos0 + m < dimension) acc_atomic_add(acc_lo + pos0 + m, acc_hi + pos0 + m, lo[m], (int64_t)hi[m]);
+}
+
+// candidate m (0..7) of a ChaCha block, rand 0.3 next_u64 = (word 2m << 32) | word 2m+1
+__device__ __forceinline__ uint64_t block_candidate(const uint32_t (&o)[16], uint32_t m) {
+    uint32_t hi = 0, lo = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t)
+        if (t == m) { hi = o[2 * t]; lo = o[2 * t + 1]; }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Shift correction for seeds whose <= 3 rejected candidates (all below `dimension`) are recorded: the mask of
+// position i is candidate f(i) = i + #{rejected <= f(i)} instead of candidate i.
+__global__ __launch_bounds__(kThreads) void chacha_mask_shift_kernel(const uint32_t* __restrict__ seeds,
+                                                                     const uint32_t* __restrict__ list,
+                                                                     const RejectRecord* __restrict__ rejects,
+                                                                     size_t dimension, uint64_t zone,
+                                                                     uint64_t* __restrict__ acc_lo,
+                                                                     int64_t* __restrict__ acc_hi) {
+    const uint32_t s = list[blockIdx.y];
+    const uint32_t R = rejects[s].count;                                  // 1..3 by construction of the list
+    uint32_t x0 = rejects[s].pos[0], x1 = R > 1 ? rejects[s].pos[1] : 0xFFFFFFFFu, x2 = R > 2 ? rejects[s].pos[2] : 0xFFFFFFFFu;
+    if (x0 > x1) { const uint32_t t = x0; x0 = x1; x1 = t; }
+    if (x1 > x2) { const uint32_t t = x1; x1 = x2; x2 = t; }
+    if (x0 > x1) { const uint32_t t = x0; x0 = x1; x1 = t; }
+    const uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t i0 = j * 8;
+    if (i0 >= dimension || i0 + 7 < x0) return;                           // nothing moves before the first rejection
+    uint32_t key[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) key[w] = seeds[(size_t)s * 8 + w];
+    uint32_t o0[16], o1[16], oc[16];
+    chacha_block_lane<20>(key, (uint32_t)j, (uint32_t)(j >> 32), 0u, 0u, o0);
+    chacha_block_lane<20>(key, (uint32_t)(j + 1), (uint32_t)((j + 1) >> 32), 0u, 0u, o1);
+    uint64_t cached = ~0ull;                                              // block index held in oc
+    for (uint32_t m = 0; m < 8; ++m) {
+        const uint64_t i = i0 + m;
+        if (i >= dimension) break;
+        if (i < x0) continue;
+        uint64_t f = i;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) f = i + (x0 <= f ? 1u : 0u) + (x1 <= f ? 1u : 0u) + (x2 <= f ? 1u : 0u);
+        uint64_t nv;
+        if (f < dimension) {
+            const uint32_t d = (uint32_t)(f - i0);                       // 1 .. 10
+            nv = d < 8 ? block_candidate(o0, d) : block_candidate(o1, d - 8);
+        } else {
+            // dimension - R candidates below `dimension` are accepted; this position is the (t+1)-th accepted one
+            // from candidate `dimension` on, and nobody has tested those yet
+            uint64_t need = i - (dimension - R) + 1;
+            uint64_t idx = dimension;
+            for (;;) {
+                const uint64_t b = idx >> 3;
+                uint64_t v;
+                if (b == j) v = block_candidate(o0, (uint32_t)idx & 7u);
+                else if (b == j + 1) v = block_candidate(o1, (uint32_t)idx & 7u);
+                else {
+                    if (b != cached) { chacha_block_lane<20>(key, (uint32_t)b, (uint32_t)(b >> 32), 0u, 0u, oc); cached = b; }
+                    v = block_candidate(oc, (uint32_t)idx & 7u);
+                }
+                if (v < zone && --need == 0) { nv = v; break; }
+                ++idx;
+            }
+        }
+        const uint64_t ov = block_candidate(o0, m);                       // what the fast kernel added here
+        acc_atomic_add(acc_lo + i, acc_hi + i, nv - ov, nv < ov ? -1 : 0);
+    }
 }
 
 // exact expansion for the listed seeds; one workgroup per seed walks the candidate stream in order.
@@ -1188,7 +1257,7 @@ hipError_t launch_full_mask_drbg(const int64_t* d_secrets, size_t secrets_stride
 
 hipError_t launch_chacha_mask_accumulate(const uint32_t* d_seeds, size_t n_seeds, size_t dimension,
                                          const ModParams& mod, uint64_t zone, uint64_t* d_acc_lo, int64_t* d_acc_hi,
-                                         uint32_t* d_reject_flags, hipStream_t s) {
+                                         RejectRecord* d_rejects, hipStream_t s) {
     if (n_seeds == 0 || dimension == 0) return hipSuccess;
     const uint64_t pos_blocks = ceil_div(ceil_div(dimension, 8), kThreads);
     if (hipError_t e = grid_check(pos_blocks)) return e;
@@ -1200,7 +1269,22 @@ hipError_t launch_chacha_mask_accumulate(const uint32_t* d_seeds, size_t n_seeds
     const size_t per = ceil_div(n_seeds, split);
     split = ceil_div(n_seeds, per);
     chacha_mask_fast_kernel<<<dim3((unsigned)pos_blocks, (unsigned)split), dim3(kThreads), 0, s>>>(
-        d_seeds, n_seeds, dimension, mod, zone, d_acc_lo, d_acc_hi, d_reject_flags, per);
+        d_seeds, n_seeds, dimension, mod, zone, d_acc_lo, d_acc_hi, d_rejects, per);
+    return hipGetLastError();
+}
+
+hipError_t launch_chacha_mask_shift(const uint32_t* d_seeds, const uint32_t* d_list, size_t n_list,
+                                    const RejectRecord* d_rejects, size_t dimension, const ModParams& mod, uint64_t zone,
+                                    uint64_t* d_acc_lo, int64_t* d_acc_hi, hipStream_t s) {
+    (void)mod;
+    if (n_list == 0 || dimension == 0) return hipSuccess;
+    const uint64_t pos_blocks = ceil_div(ceil_div(dimension, 8), kThreads);
+    if (hipError_t e = grid_check(pos_blocks)) return e;
+    for (size_t l0 = 0; l0 < n_list; l0 += 65535) {
+        const unsigned nl = (unsigned)(n_list - l0 < 65535 ? n_list - l0 : 65535);
+        chacha_mask_shift_kernel<<<dim3((unsigned)pos_blocks, nl), dim3(kThreads), 0, s>>>(d_seeds, d_list + l0, d_rejects,
+                                                                                           dimension, zone, d_acc_lo, d_acc_hi);
+    }
     return hipGetLastError();
 }
 

@@ -319,7 +319,10 @@ def test_chacha_masks_kats(gpu):
 
 @pytest.mark.parametrize("q,dim,seeds", [(433, 1000, 5), (P62, 4099, 9), (P62, 8, 1), (97, 3, 300),
                                          ((1 << 61) + 1, 3000, 6),            # ~12% rejection: exact-order path for all
-                                         ((1 << 62) - (1 << 49), 2000, 60)])  # 2^-13 rejection: fast path + fix-ups
+                                         ((1 << 62) - (1 << 49), 2000, 60),   # 2^-13 rejection: fast path + fix-ups
+                                         ((1 << 62) - (1 << 51), 1500, 300),  # ~0.7 rejections per seed: shift pass (<= 3) and exact-order kernel (> 3)
+                                         ((1 << 62) - (1 << 51), 40, 3000),   # rejections near the end of short streams: the tail walk
+                                         ((1 << 61) + 1, 8, 500)])            # 12% rejection on 8 candidates: tails that meet further rejections
 def test_chacha_combine_vs_oracle(gpu, q, dim, seeds):
     from sda_amd import crypto
     from oracle import coracle

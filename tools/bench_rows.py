@@ -54,7 +54,7 @@ dim = 1 << 20
 for P in (256, 4096):
     seeds = np.random.default_rng(1).integers(0, 1 << 32, size=(P, 4), dtype=np.int64)
     mc = crypto.MaskCombiner(crypto.ChaCha(P62, dim, 128))
-    dt = timed(lambda: mc.combine(list(seeds)), reps=3)
+    dt = timed(lambda: mc.combine(seeds), reps=3)
     out[f"chacha_mask_combine_P{P}_dim1Mi"] = {"ms": dt * 1e3, "masks_per_s": P * dim / dt,
                                                "note": "host call: includes seed upload, flag readback, 8 MB result download"}
 
