@@ -102,7 +102,8 @@ __device__ __forceinline__ void drbg_pair(const DrbgKey& key, const QuadCol& qc,
 
 // ---- small load/store helpers --------------------------------------------------------------------
 // Cache policies, each measured on config 3 (interleaved A/B of builds): secrets with the default policy (nt loads
-// cost the dual-role launch 12 %), share stores nt (plain: -1 %), clerk-sum loads nt (plain: 7.8 vs 7.2 ms).
+// cost the dual-role launch 12 %), share stores nt (plain: -1 %; sc1 / sc0 sc1 / sc1 nt write-through forms: equal within
+// noise), clerk-sum loads nt (plain: 7.8 vs 7.2 ms).
 __device__ __forceinline__ ll2 load2(const int64_t* p) { return *reinterpret_cast<const ll2*>(p); }
 __device__ __forceinline__ void store2(int64_t* p, uint64_t a, uint64_t b) {
     ll2 v; v.x = (long long)a; v.y = (long long)b;
