@@ -301,3 +301,16 @@ def test_varint_roundtrip_property(values):
     assert po.varint_decode(enc) == values
     assert coracle.varint_encode(values) == enc
     assert len(enc) == sum(max(1, ((((v << 1) ^ (v >> 63)) & po.MASK64).bit_length() + 6) // 7) for v in values)
+
+
+def test_c_oracle_under_sanitizers():
+    """the host oracle is built with -fsanitize=address,undefined and run over the reference's end-to-end
+    vectors, the mask paths, the DRBG and the wire codec with exact-size buffers (oracle/selftest.c)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "-s", "check-sanitize"], capture_output=True, text=True,
+                       timeout=300)
+    if r.returncode != 0 and ("cannot find -lasan" in r.stderr or "libasan" in r.stderr or "cannot find -lubsan" in r.stderr):
+        pytest.skip("sanitizer runtimes not installed")
+    assert r.returncode == 0 and "oracle selftest: OK" in r.stdout, r.stdout + r.stderr
