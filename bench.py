@@ -226,7 +226,7 @@ def measure_fused(env, name, dim, P, steps, warmup, row_align=16, verify=True):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": w["desc"], "name": name, "dim": dim, "tile_participants": P,
                    "participants_total": world * steps * P, "share_count": n, "secret_count": k,
-                   "privacy_threshold": t, "modulus": P62, "randomness": "on-device ChaCha20 (sda-drbg-v1)",
+                   "privacy_threshold": t, "modulus": P62, "randomness": f"on-device ChaCha{os.environ.get('SDA_DRBG_ROUNDS', '20')} (sda-drbg-v1)",
                    "row_stride_elements": Bs,
                    "schedule": "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid "
                                "(shares materialised in HBM by one launch, read back by the next); K+1 launches for K tiles",
@@ -406,7 +406,7 @@ def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=Tr
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": w["desc"], "name": name, "dim": dim, "tile_participants": P,
                    "participants_total": world * steps * P, "share_count": n, "secret_count": k,
-                   "privacy_threshold": t, "modulus": P62, "randomness": "on-device ChaCha20 (sda-drbg-v1)",
+                   "privacy_threshold": t, "modulus": P62, "randomness": f"on-device ChaCha{os.environ.get('SDA_DRBG_ROUNDS', '20')} (sda-drbg-v1)",
                    "row_stride_elements": Bs,
                    "schedule": ("share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares"
                                 if overlap else "one stream, serial"),

@@ -1176,12 +1176,18 @@ hipError_t launch_fused_packed_l31(const GenLayout& L, uint32_t n, uint32_t k, u
                                    int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs, size_t dimension,
                                    hipStream_t s, bool* fused) {
     *fused = false;
-    if (rounds != 20 || L.rand) return hipSuccess;
+    if ((rounds != 20 && rounds != 12 && rounds != 8) || L.rand) return hipSuccess;
     const uint64_t batches = ceil_div(L.len, k);
     const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
     FuseArgs F;
     if (!fuse_plan(L, chunks, acc_lo, acc_hi, d_prev, prev_rows, jobs, dimension, F)) return hipSuccess;
-#define X(K_, T_) if (k == K_ && t == T_) { *fused = true; return fused_l31_kt<K_, T_, 20>(L, n, mod, lp, M, key, F, chunks, batches, s); }
+#define X(K_, T_)                                                                                                        \
+    if (k == K_ && t == T_) {                                                                                            \
+        *fused = true;                                                                                                   \
+        return rounds == 20 ? fused_l31_kt<K_, T_, 20>(L, n, mod, lp, M, key, F, chunks, batches, s)                     \
+             : rounds == 12 ? fused_l31_kt<K_, T_, 12>(L, n, mod, lp, M, key, F, chunks, batches, s)                     \
+                            : fused_l31_kt<K_, T_, 8>(L, n, mod, lp, M, key, F, chunks, batches, s);                     \
+    }
     SDA_FUSED_SHAPES(X)
 #undef X
     return hipSuccess;
@@ -1191,13 +1197,15 @@ hipError_t launch_fused_additive(const GenLayout& L, uint32_t n, const ModParams
                                  uint64_t* acc_lo, int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs,
                                  size_t dimension, hipStream_t s, bool* fused) {
     *fused = false;
-    if (rounds != 20 || L.rand) return hipSuccess;
+    if ((rounds != 20 && rounds != 12 && rounds != 8) || L.rand) return hipSuccess;
     const uint64_t chunks = ceil_div(ceil_div(L.len, 2), kThreads);
     FuseArgs F;
     if (!fuse_plan(L, chunks, acc_lo, acc_hi, d_prev, prev_rows, jobs, dimension, F)) return hipSuccess;
     *fused = true;
-   
-    fused_additive_kernel<20><<<dim3((unsigned)F.grid), dim3(kThreads), 0, s>>>(L, n, mod, key, chunks, F);
+    const dim3 grid((unsigned)F.grid), block(kThreads);
+    if (rounds == 20) fused_additive_kernel<20><<<grid, block, 0, s>>>(L, n, mod, key, chunks, F);
+    else if (rounds == 12) fused_additive_kernel<12><<<grid, block, 0, s>>>(L, n, mod, key, chunks, F);
+    else fused_additive_kernel<8><<<grid, block, 0, s>>>(L, n, mod, key, chunks, F);
     return hipGetLastError();
 }
 
