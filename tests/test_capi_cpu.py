@@ -158,3 +158,14 @@ def test_abi_misuse_returns_codes_not_crashes(built):
     assert lib.sda_secret_masker_new(C.byref(m), C.byref(h)) == bad and not h.value
     s = capi.SharingScheme(capi.SHARING_ADDITIVE, 3, 1 << 62, 0, 0, 0, 0)
     assert lib.sda_share_combiner_new(C.byref(s), C.byref(h)) == capi.ERR_UNSUPPORTED
+
+
+def test_header_is_plain_c(built):
+    """the boundary is a C ABI: include/sda_hip.h must compile as C99 (what bindgen / cgo / a C caller reads) and as
+    C++11, warning-free under -pedantic."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "sda_hip.h")
+    for cmd in (["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", hdr],
+                ["g++", "-x", "c++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
