@@ -183,7 +183,7 @@ def measure_fused(env, name, dim, P, steps, warmup, row_align=16, verify=True):
         launch_ms.append(ms.value)
     all_ms = sum(launch_ms) / len(launch_ms)                 # what rocprofv3 --stats averages (K+1 launches)
     full = launch_ms[1:steps]                                # launches that carry both roles
-    full_ms = sum(full) / len(full) if full else float("nan")
+    full_ms = sum(full) / len(full) if full else None        # needs >= 2 steps
     for e in evs:
         lib.sda_event_destroy(e)
     verified, reveal_ms = None, None
@@ -454,6 +454,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-additional", action="store_true", help="skip the short config-2 (additive) run")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1:
