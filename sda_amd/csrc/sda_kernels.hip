@@ -1002,8 +1002,10 @@ hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, ui
     }
 }
 
+// every split of k + t = 7 (the tss-valid family for n = 8: k + t + 1 = 2^3), the BASELINE shapes, small shapes and a
+// few splits of k + t = 15 (n = 26 / 80); anything else takes the generic kernel (about half the rate)
 #define SDA_PACKED_L31_SHAPES(X) X(3, 1) X(3, 4) X(8, 2) X(8, 7) X(1, 1) X(2, 1) X(1, 2) X(2, 2) X(1, 3) X(3, 0) \
-    X(4, 0) X(2, 0) X(1, 0) X(2, 5) X(4, 3) X(4, 4) X(5, 3)
+    X(4, 0) X(2, 0) X(1, 0) X(2, 5) X(4, 3) X(4, 4) X(5, 3) X(5, 2) X(6, 1) X(1, 6) X(7, 0) X(12, 3) X(10, 5) X(4, 11)
 
 bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n) {
     if ((uint64_t)n * (k + t) > SDA_MAT_ARG_MAX) return false;

@@ -107,7 +107,10 @@ def test_additive_generate_injected(gpu, n, q, dim):
 
 PACKED_SHAPES = [(3, 1, 8, 8, 9), (3, 4, 8, 8, 9), (8, 2, 26, 16, 27), (8, 7, 26, 16, 27), (1, 1, 8, 8, 9),
                  (2, 1, 8, 8, 9), (1, 2, 8, 8, 9), (2, 5, 8, 8, 9), (4, 3, 26, 8, 27),
-                 (5, 3, 26, 16, 27), (3, 0, 8, 8, 9)]   # the last two have no compiled fast path
+                 (5, 3, 26, 16, 27), (3, 0, 8, 8, 9),
+                 (5, 2, 8, 8, 9), (6, 1, 8, 8, 9), (1, 6, 8, 8, 9), (7, 0, 8, 8, 9),      # the rest of the k + t = 7 family
+                 (12, 3, 26, 16, 27), (10, 5, 26, 16, 27), (4, 11, 26, 16, 27),          # splits of k + t = 15
+                 (6, 2, 8, 16, 9), (9, 6, 26, 16, 27)]                                   # not compiled: generic kernel
 
 
 @pytest.mark.parametrize("k,t,n,o2,o3", PACKED_SHAPES)
@@ -197,7 +200,7 @@ def test_drbg_rejection_path(gpu):
 def test_packed_generate_drbg_vs_oracle(gpu):
     from sda_amd import crypto
     from oracle import coracle
-    for (k, t, n, o2, o3) in [(3, 1, 8, 8, 9), (3, 4, 8, 8, 9), (8, 2, 26, 16, 27), (5, 3, 26, 16, 27)]:
+    for (k, t, n, o2, o3) in [s for s in PACKED_SHAPES if s[1] > 0]:           # every shape that draws randomness
         sch = crypto.PackedShamir(k, n, t, P62, W[o2], W[o3])
         gen = crypto.ShareGenerator(sch)
         gen.set_drbg_key(KEY)

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Share-gen rate of several (k, t) splits, compiled shapes vs the generic fallback; run on the GPU box."""
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from sda_amd import capi, crypto
+from sda_amd.device import DeviceBuffer, synchronize
+P62 = 4611686006577364993
+W = {8: 631229665360524489, 9: 3451275676410824977, 16: None, 27: None}
+lib = capi.load()
+dim, P = 1 << 20, 500
+sec = DeviceBuffer(P * dim)
+capi.check(lib.sda_fill_synthetic_dev(sec.ptr, P, dim, dim, 0, 3, P62, None))
+for (k, t) in [(4, 3), (5, 2), (6, 1), (1, 6), (7, 0), (3, 4), (2, 5), (6, 2)]:   # the last one is not compiled: generic kernel
+    n = 8
+    sch = crypto.PackedShamir(k, n, t, P62, W[8], W[9])
+    gen = crypto.ShareGenerator(sch)
+    B = (dim + k - 1) // k
+    Bs = (B + 15) // 16 * 16
+    out = DeviceBuffer(n * P * Bs)
+    def run():
+        gen.generate_batch_dev(sec.ptr, P, dim, dim, out.ptr, Bs, P * Bs, first_participant=0)
+    run(); synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); run(); synchronize(); ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[1]
+    print(f"k={k} t={t} n={n}: {dt*1e3:.2f} ms  {P*dim/dt/1e9:.1f} Gelem/s")
