@@ -422,6 +422,74 @@ __global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, u
     packed_gen_l31_body<K, T, ROUNDS, VEC>(L, n, mod, lp, M, key, chunks, batches, blockIdx.x);
 }
 
+// ---- run-time (k, t): the same arithmetic for shapes that have no compiled instance ---------------------------------
+// k and t are kernel arguments, KTMAX (4 / 8 / 12 / 16) bounds k + t.  The value limbs of the terms beyond k + t are
+// zero and every group of four terms is either done in full or skipped by a wave-uniform branch, so a dot product
+// costs what the next multiple of four terms costs; the matrix row may be read up to three entries past its end
+// (MatArg is zero-padded and n (k + t) + 3 <= SDA_MAT_ARG_MAX is required).
+template <int KTMAX>
+__device__ __forceinline__ uint64_t l31_dot_rt(const uint64_t* __restrict__ row, const int32_t (&v0)[KTMAX],
+                                               const int32_t (&v1)[KTMAX], uint32_t kt, const L31Params& P) {
+    uint64_t r = 0;
+#pragma unroll
+    for (int g = 0; g < KTMAX; g += 4) {
+        if ((uint32_t)g < kt) {
+            const int64_t top = l31_group<4>(row + g, v0 + g, v1 + g, P);
+            const uint64_t u = condsub((uint64_t)top + P.p2, P.p2);
+            r = g == 0 ? u : condsub(r + u, P.p2);
+        }
+    }
+    return condsub(r, P.p);
+}
+
+template <int KTMAX, int ROUNDS>
+__global__ __launch_bounds__(kThreads) void packed_gen_l31_rt_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t,
+                                                                     ModParams mod, L31Params lp, MatArg M, DrbgKey key,
+                                                                     uint64_t chunks, uint64_t batches, bool vec) {
+    const uint32_t kt = k + t;
+    uint64_t p, chunk;
+    split_item(blockIdx.x, chunks, p, chunk);
+    const uint64_t pair = chunk * kThreads + threadIdx.x;
+    const uint64_t b0 = 2 * pair;
+    const bool in0 = b0 < batches, in1 = b0 + 1 < batches;
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
+    const uint64_t e0 = b0 * k;
+    const uint64_t stream = L.first_participant + p;
+    const QuadCol qc = quad_col(key);
+    int32_t a0[KTMAX], a1[KTMAX], c0[KTMAX], c1[KTMAX];
+#pragma unroll
+    for (int i = 0; i < KTMAX; ++i) {
+        uint64_t x = 0, y = 0;
+        if ((uint32_t)i < k) {                                               // wave-uniform
+            const uint64_t a = e0 + i, b = e0 + k + i;
+            x = a < L.len ? canon_i64(sp[a], mod.m, mod.mu) : 0;
+            y = b < L.len ? canon_i64(sp[b], mod.m, mod.mu) : 0;
+        } else if ((uint32_t)i < kt) {
+            if (rp) {
+                x = in0 ? canon_i64(rp[b0 * t + (i - k)], mod.m, mod.mu) : 0;
+                y = in1 ? canon_i64(rp[(b0 + 1) * t + (i - k)], mod.m, mod.mu) : 0;
+            } else {
+                drbg_pair<ROUNDS>(key, qc, stream, pair, t, (uint32_t)i - k, mod, x, y);
+            }
+        }
+        centre_limbs(x, lp, a0[i], a1[i]);
+        centre_limbs(y, lp, c0[i], c1[i]);
+    }
+    int64_t* op = L.out + p * L.out_stride_participant + b0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint64_t* row = &M.e[(size_t)j * kt];
+        const uint64_t a = l31_dot_rt<KTMAX>(row, a0, a1, kt, lp);
+        const uint64_t b = l31_dot_rt<KTMAX>(row, c0, c1, kt, lp);
+        int64_t* o = op + (size_t)j * L.out_stride_clerk;
+        if (vec && in1) store2(o, a, b);
+        else {
+            if (in0) o[0] = (int64_t)a;
+            if (in1) o[1] = (int64_t)b;
+        }
+    }
+}
+
 // any-shape fallback: one lane = one batch, matrix and randomness read from global memory
 __global__ __launch_bounds__(kThreads) void packed_gen_generic_kernel(GenLayout L, uint32_t n, uint32_t k,
                                                                       uint32_t t, ModParams mod, MontParams mont,
@@ -1007,12 +1075,16 @@ hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, ui
 #define SDA_PACKED_L31_SHAPES(X) X(3, 1) X(3, 4) X(8, 2) X(8, 7) X(1, 1) X(2, 1) X(1, 2) X(2, 2) X(1, 3) X(3, 0) \
     X(4, 0) X(2, 0) X(1, 0) X(2, 5) X(4, 3) X(4, 4) X(5, 3) X(5, 2) X(6, 1) X(1, 6) X(7, 0) X(12, 3) X(10, 5) X(4, 11)
 
-bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n) {
-    if ((uint64_t)n * (k + t) > SDA_MAT_ARG_MAX) return false;
+static bool packed_l31_compiled(uint32_t k, uint32_t t) {
 #define X(K_, T_) if (k == K_ && t == T_) return true;
     SDA_PACKED_L31_SHAPES(X)
 #undef X
     return false;
+}
+bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n) {
+    if ((uint64_t)n * (k + t) > SDA_MAT_ARG_MAX) return false;
+    if (packed_l31_compiled(k, t)) return true;
+    return k >= 1 && k + t <= 16 && (uint64_t)n * (k + t) + 3 <= SDA_MAT_ARG_MAX;     // run-time (k, t) kernel
 }
 
 template <int K, int T, int ROUNDS>
@@ -1034,12 +1106,35 @@ static hipError_t packed_l31_launch_kt(const GenLayout& L, uint32_t n, const Mod
     return hipSuccess;
 }
 
+template <int KTMAX, int ROUNDS>
+static hipError_t packed_l31_launch_rt(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                       const L31Params& lp, const MatArg& M, const DrbgKey& key, hipStream_t s) {
+    const uint64_t batches = ceil_div(L.len, k);
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        const bool vec = aligned16(S.out) && S.out_stride_participant % 2 == 0 && S.out_stride_clerk % 2 == 0;
+        packed_gen_l31_rt_kernel<KTMAX, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(
+            S, n, k, t, mod, lp, M, key, chunks, batches, vec);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
 template <int ROUNDS>
 static hipError_t packed_l31_launch_r(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
                                       const L31Params& lp, const MatArg& M, const DrbgKey& key, hipStream_t s) {
 #define X(K_, T_) if (k == K_ && t == T_) return packed_l31_launch_kt<K_, T_, ROUNDS>(L, n, mod, lp, M, key, s);
     SDA_PACKED_L31_SHAPES(X)
 #undef X
+    const uint32_t kt = k + t;
+    if (kt <= 4) return packed_l31_launch_rt<4, ROUNDS>(L, n, k, t, mod, lp, M, key, s);
+    if (kt <= 8) return packed_l31_launch_rt<8, ROUNDS>(L, n, k, t, mod, lp, M, key, s);
+    if (kt <= 12) return packed_l31_launch_rt<12, ROUNDS>(L, n, k, t, mod, lp, M, key, s);
+    if (kt <= 16) return packed_l31_launch_rt<16, ROUNDS>(L, n, k, t, mod, lp, M, key, s);
     return hipErrorInvalidValue;
 }
 

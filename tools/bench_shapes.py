@@ -11,9 +11,10 @@ lib = capi.load()
 dim, P = 1 << 20, 500
 sec = DeviceBuffer(P * dim)
 capi.check(lib.sda_fill_synthetic_dev(sec.ptr, P, dim, dim, 0, 3, P62, None))
-for (k, t) in [(4, 3), (5, 2), (6, 1), (1, 6), (7, 0), (3, 4), (2, 5), (6, 2)]:   # the last one is not compiled: generic kernel
-    n = 8
-    sch = crypto.PackedShamir(k, n, t, P62, W[8], W[9])
+W[16], W[27] = 2589100645267092065, 365137883145458390
+for (k, t, n, o2, o3) in [(4, 3, 8, 8, 9), (5, 2, 8, 8, 9), (6, 1, 8, 8, 9), (7, 0, 8, 8, 9), (3, 4, 8, 8, 9), (8, 7, 26, 16, 27),
+                          (6, 2, 8, 16, 9), (9, 6, 26, 16, 27)]:   # the last two are not compiled: generic kernel
+    sch = crypto.PackedShamir(k, n, t, P62, W[o2], W[o3])
     gen = crypto.ShareGenerator(sch)
     B = (dim + k - 1) // k
     Bs = (B + 15) // 16 * 16
