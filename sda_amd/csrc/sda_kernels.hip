@@ -622,9 +622,9 @@ __global__ __launch_bounds__(kThreads) void combine_update_kernel(uint64_t* __re
 // shares are still written to HBM by one tile's launch and read back by the next one's (the unfused
 // contract of SURVEY.md 8d); only the schedule changes.
 // =================================================================================================
-#ifndef SDA_FUSE_UNROLL
-#define SDA_FUSE_UNROLL 16
-#endif
+// row loads in flight per lane in the clerk-sum role (the share-gen role's 84 VGPRs are allocated anyway; 8 and 24
+// measured within 1 %)
+static constexpr int kFuseUnroll = 16;
 struct FuseArgs {
     uint64_t* acc_lo; int64_t* acc_hi; const int64_t* prev;       // clerk-sum of the previous tile
     size_t job_stride, n_rows, row_stride, dimension, rows_per_split;
@@ -642,7 +642,7 @@ __device__ __forceinline__ bool fuse_role(const FuseArgs& F, uint64_t b, uint64_
 
 __device__ __forceinline__ void fuse_combine(const FuseArgs& F, uint64_t q) {
     const size_t bx = q % F.col_blocks, t = q / F.col_blocks;
-    combine_body<true, SDA_FUSE_UNROLL>(F.acc_lo, F.acc_hi, F.prev, F.job_stride, F.n_rows, F.row_stride, F.dimension, F.rows_per_split,
+    combine_body<true, kFuseUnroll>(F.acc_lo, F.acc_hi, F.prev, F.job_stride, F.n_rows, F.row_stride, F.dimension, F.rows_per_split,
                           F.splits > 1, bx, t % F.jobs, t / F.jobs);
 }
 
@@ -1255,7 +1255,6 @@ static bool fuse_plan(const GenLayout& L, uint64_t chunks, uint64_t* acc_lo, int
     if (have_comb && !(aligned16(d_prev) && (F.job_stride % 2 == 0) && (F.row_stride % 2 == 0))) return false;
     return true;
 }
-
 
 template <int K, int T, int ROUNDS>
 static hipError_t fused_l31_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const L31Params& lp, const MatArg& M,
