@@ -43,6 +43,8 @@ WORKLOADS = {
                      desc="BASELINE config 4 shape: packed Shamir t=2 k=8 n=26, dim 1048576, 62-bit prime"),
     "packed26_ref": dict(kind="packed", n=26, k=8, t=7, o2=16, o3=27, participants=1_000_000,
                          desc="reference-valid tss shape t=7 k=8 n=26 (t+k+1 = 16, n+1 = 27), dim 1048576"),
+    "packed_k4t3": dict(kind="packed", n=8, k=4, t=3, o2=8, o3=9, participants=100_000,
+                        desc="tss-valid shape t=3 k=4 n=8 through the run-time (k, t) dual-role kernel, dim 1048576"),
     "additive": dict(kind="additive", n=3, k=1, t=2, o2=8, o3=9, participants=10_000,
                      desc="BASELINE config 2: additive 3-way, dim 1048576, 62-bit modulus, 10k participants"),
 }

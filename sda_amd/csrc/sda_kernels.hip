@@ -443,12 +443,13 @@ __device__ __forceinline__ uint64_t l31_dot_rt(const uint64_t* __restrict__ row,
 }
 
 template <int KTMAX, int ROUNDS>
-__global__ __launch_bounds__(kThreads) void packed_gen_l31_rt_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t,
-                                                                     ModParams mod, L31Params lp, MatArg M, DrbgKey key,
-                                                                     uint64_t chunks, uint64_t batches, bool vec) {
+__device__ __forceinline__ void packed_gen_l31_rt_body(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
+                                                       const ModParams& mod, const L31Params& lp, const MatArg& M,
+                                                       const DrbgKey& key, uint64_t chunks, uint64_t batches, bool vec,
+                                                       uint64_t item) {
     const uint32_t kt = k + t;
     uint64_t p, chunk;
-    split_item(blockIdx.x, chunks, p, chunk);
+    split_item(item, chunks, p, chunk);
     const uint64_t pair = chunk * kThreads + threadIdx.x;
     const uint64_t b0 = 2 * pair;
     const bool in0 = b0 < batches, in1 = b0 + 1 < batches;
@@ -488,6 +489,13 @@ __global__ __launch_bounds__(kThreads) void packed_gen_l31_rt_kernel(GenLayout L
             if (in1) o[1] = (int64_t)b;
         }
     }
+}
+
+template <int KTMAX, int ROUNDS>
+__global__ __launch_bounds__(kThreads) void packed_gen_l31_rt_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t,
+                                                                     ModParams mod, L31Params lp, MatArg M, DrbgKey key,
+                                                                     uint64_t chunks, uint64_t batches, bool vec) {
+    packed_gen_l31_rt_body<KTMAX, ROUNDS>(L, n, k, t, mod, lp, M, key, chunks, batches, vec, blockIdx.x);
 }
 
 // any-shape fallback: one lane = one batch, matrix and randomness read from global memory
@@ -658,6 +666,15 @@ __global__ __launch_bounds__(kThreads) void fused_packed_l31_kernel(GenLayout L,
                                                                     uint64_t batches, FuseArgs F) {
     uint64_t idx;
     if (!fuse_dispatch(F, blockIdx.x, idx)) packed_gen_l31_body<K, T, ROUNDS, true>(L, n, mod, lp, M, key, chunks, batches, idx);
+}
+
+template <int KTMAX, int ROUNDS>
+__global__ __launch_bounds__(kThreads) void fused_packed_l31_rt_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t,
+                                                                       ModParams mod, L31Params lp, MatArg M, DrbgKey key,
+                                                                       uint64_t chunks, uint64_t batches, FuseArgs F) {
+    uint64_t idx;
+    if (!fuse_dispatch(F, blockIdx.x, idx))
+        packed_gen_l31_rt_body<KTMAX, ROUNDS>(L, n, k, t, mod, lp, M, key, chunks, batches, true, idx);
 }
 
 template <int ROUNDS>
@@ -1286,7 +1303,20 @@ hipError_t launch_fused_packed_l31(const GenLayout& L, uint32_t n, uint32_t k, u
     }
     SDA_FUSED_SHAPES(X)
 #undef X
-    return hipSuccess;
+    // no compiled instance: the run-time (k, t) form, when the shape fits it
+    const uint32_t kt = k + t;
+    if (k < 1 || kt > 16 || (uint64_t)n * kt + 3 > SDA_MAT_ARG_MAX) return hipSuccess;
+    *fused = true;
+    const dim3 grid((unsigned)F.grid), block(kThreads);
+#define RT(KTMAX_)                                                                                                      \
+    do {                                                                                                                 \
+        if (rounds == 20) fused_packed_l31_rt_kernel<KTMAX_, 20><<<grid, block, 0, s>>>(L, n, k, t, mod, lp, M, key, chunks, batches, F); \
+        else if (rounds == 12) fused_packed_l31_rt_kernel<KTMAX_, 12><<<grid, block, 0, s>>>(L, n, k, t, mod, lp, M, key, chunks, batches, F); \
+        else fused_packed_l31_rt_kernel<KTMAX_, 8><<<grid, block, 0, s>>>(L, n, k, t, mod, lp, M, key, chunks, batches, F); \
+    } while (0)
+    if (kt <= 4) RT(4); else if (kt <= 8) RT(8); else if (kt <= 12) RT(12); else RT(16);
+#undef RT
+    return hipGetLastError();
 }
 
 hipError_t launch_fused_additive(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,

@@ -733,7 +733,8 @@ def test_odd_strides_and_unaligned_bases_dev(gpu):
             assert np.array_equal(S[j], coracle.combine(P62, rows))
 
 
-@pytest.mark.parametrize("kind", ["packed_k3_t1_n8", "packed_k8_t2_n26", "additive_n3", "packed_odd_strides"])
+@pytest.mark.parametrize("kind", ["packed_k3_t1_n8", "packed_k8_t2_n26", "additive_n3", "packed_odd_strides",
+                                  "packed_k4_t3_n8", "packed_k6_t2_n8", "packed_k9_t6_n26"])    # the last three: run-time (k, t) form
 def test_dual_role_pipeline_equals_separate_launches(gpu, kind):
     """sda_share_generator_generate_combine_dev (tile i+1 generated while tile i is summed, one grid) must
     produce exactly the shares and clerk sums of generate_batch_dev + combiner update_dev."""
@@ -746,6 +747,15 @@ def test_dual_role_pipeline_equals_separate_launches(gpu, kind):
         sch, k, t, n = crypto.Additive(3, P62), 1, 2, 3
     elif kind == "packed_k8_t2_n26":
         k, t, n = 8, 2, 26
+        sch = crypto.PackedShamir(k, n, t, P62, W[16], W[27])
+    elif kind == "packed_k4_t3_n8":
+        k, t, n = 4, 3, 8
+        sch = crypto.PackedShamir(k, n, t, P62, W[8], W[9])
+    elif kind == "packed_k6_t2_n8":
+        k, t, n = 6, 2, 8
+        sch = crypto.PackedShamir(k, n, t, P62, W[16], W[9])
+    elif kind == "packed_k9_t6_n26":
+        k, t, n = 9, 6, 26
         sch = crypto.PackedShamir(k, n, t, P62, W[16], W[27])
     else:
         k, t, n = 3, 1, 8
