@@ -534,6 +534,15 @@ def test_cpp_host_mirror_full_loop(gpu):
     assert "all scenarios OK" in out.stdout
 
 
+def test_c_abi_walkthrough(gpu):
+    """examples/c_abi_walkthrough.c: the README walkthrough and the packed-Shamir + ChaCha-mask loop through the raw
+    C ABI from plain C99 (what a Rust / cgo binding would call)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "c_abi_walkthrough")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "c_abi_walkthrough: OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_modsum_parts_dev(gpu):
     """cross-GPU partial-sum reducer: 8 parts of (q-1) must not wrap (a plain u64 SUM would)."""
     from sda_amd.capi import check
