@@ -295,10 +295,13 @@ int sda_secret_masker_mask(sda_secret_masker_t* m,
 
 /* device-resident batch: participate.rs:52-54 for a whole tile of participants.  Full: masks[p][i] uniform from the
  * on-device CSPRNG (stream first_participant + p; reproducible with sda_secret_masker_set_drbg_key),
- * masked[p][i] = (secrets[p][i] + masks[p][i]) mod q.  None: masked = secrets, d_masks untouched.  ChaCha draws an
- * OS-entropy seed per participant (chacha.rs:29-33) -> SDA_ERR_UNSUPPORTED, use sda_secret_masker_mask.  The P mask
- * vectors are combined on the recipient side exactly like shares (full.rs:37-52 == combiner.rs:15-29): feed them to
- * an sda_share_combiner begun with jobs == 1. */
+ * masked[p][i] = (secrets[p][i] + masks[p][i]) mod q.  None: masked = secrets, d_masks untouched.  ChaCha: one
+ * OS-entropy seed per participant (chacha.rs:29-33), its ceil(seed_bitsize/32) words written to d_masks[p][..]
+ * (the "mask" a participant sends is its seed, chacha.rs:48-50; mask_stride >= that many), masked[p][i] =
+ * (secrets[p][i] + i-th rand-0.3 ChaChaRng gen_range value of that seed) mod q; len must equal the scheme's dimension
+ * (SDA_ERR_ASSERTION, chacha.rs:26); the call synchronises `stream`.  Full masks are combined on the recipient side
+ * exactly like shares (full.rs:37-52 == combiner.rs:15-29): feed them to an sda_share_combiner begun with
+ * jobs == 1; ChaCha seeds go to sda_mask_combiner_combine. */
 int sda_secret_masker_mask_batch_dev(sda_secret_masker_t* m, const int64_t* d_secrets, size_t participants, size_t len,
                                      size_t secrets_stride, uint64_t first_participant, int64_t* d_masks,
                                      size_t mask_stride, int64_t* d_masked, size_t masked_stride, void* stream);

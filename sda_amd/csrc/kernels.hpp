@@ -146,6 +146,18 @@ hipError_t launch_chacha_mask_slow(const uint32_t* d_seeds, const uint32_t* d_li
                                    uint64_t* d_acc_lo, int64_t* d_acc_hi, bool subtract_naive,
                                    hipStream_t s);
 
+// the same expansion applied to each participant's own vector: out[p][i] = (secrets[p][i] + mask_i(seed p)) mod m
+// (chacha.rs:36-47 for a device-resident tile).  Fast pass for every participant (rejections recorded in d_rejects,
+// zeroed by the caller), then the repair pass for the listed ones: shift list (1..3 rejections), exact-order list
+// (more; d_exact_list == nullptr walks participants 0..n_exact-1 in stream order and needs no fast pass).
+hipError_t launch_chacha_apply_fast(const uint32_t* d_seeds, size_t participants, size_t dimension, const ModParams& mod,
+                                    uint64_t zone, const int64_t* d_secrets, size_t secrets_stride, int64_t* d_out,
+                                    size_t out_stride, RejectRecord* d_rejects, hipStream_t s);
+hipError_t launch_chacha_apply_repair(const uint32_t* d_seeds, const uint32_t* d_shift_list, size_t n_shift,
+                                      const uint32_t* d_exact_list, size_t n_exact, const RejectRecord* d_rejects,
+                                      size_t dimension, const ModParams& mod, uint64_t zone, const int64_t* d_secrets,
+                                      size_t secrets_stride, int64_t* d_out, size_t out_stride, hipStream_t s);
+
 // ---- zig-zag LEB128 codec of share vectors (sodium.rs:36-41, :83-89) - varint_kernels.hip -------------
 struct VarintRows {
     const int64_t* values;    // row r at values + r*row_stride

@@ -1054,8 +1054,57 @@ extern "C" int sda_secret_masker_mask_batch_dev(sda_secret_masker_t* m, const in
     if (participants == 0 || len == 0) return SDA_OK;
     if (!d_secrets || !d_masked) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
     if (secrets_stride < len || masked_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "stride < len");
-    if (c.scheme.kind == SDA_MASKING_CHACHA)
-        return fail(SDA_ERR_UNSUPPORTED, "ChaCha masking draws one OS-entropy seed per participant (chacha.rs:29-33): use sda_secret_masker_mask");
+    if (c.scheme.kind == SDA_MASKING_CHACHA) {                                // chacha.rs:24-54 for every participant
+        if (len != c.scheme.dimension)
+            return fail(SDA_ERR_ASSERTION, "assertion failed: `(left == right)` (dimension %llu, secrets %zu) - chacha.rs:26",
+                        (unsigned long long)c.scheme.dimension, len);
+        const size_t nw = c.seed_words();
+        if (!d_masks || mask_stride < nw) return fail(SDA_ERR_INVALID_ARGUMENT, "d_masks must hold %zu seed words per participant", nw);
+        SDA_TRY(c.ctx.use());
+        hipStream_t s = c.ctx.pick(stream);
+        // one OS-entropy seed per participant (chacha.rs:29-33); the "mask" a participant sends is its seed (chacha.rs:48-50)
+        std::vector<uint32_t> raw(participants * nw ? participants * nw : 1);
+        SDA_TRY(os_entropy(raw.data(), participants * nw * 4));
+        std::vector<int64_t> words(participants * nw);
+        std::vector<uint32_t> key8(participants * 8, 0u);
+        for (size_t p = 0; p < participants; ++p)
+            for (size_t i = 0; i < nw; ++i) {
+                words[p * nw + i] = (int64_t)raw[p * nw + i];
+                if (i < 8) key8[p * 8 + i] = raw[p * nw + i];
+            }
+        HIP_TRY(hipMemcpy2DAsync(d_masks, mask_stride * 8, words.data(), nw * 8, nw * 8, participants, hipMemcpyHostToDevice, s));
+        SDA_TRY(c.d_seeds.reserve(participants * 32));
+        HIP_TRY(hipMemcpyAsync(c.d_seeds.p, key8.data(), participants * 32, hipMemcpyHostToDevice, s));
+        const uint64_t zone = rand03_zone(c.mod.m);
+        const double p_rej = (double)(UINT64_MAX - zone + 1) / 18446744073709551616.0;
+        const uint32_t* seeds = c.d_seeds.as<uint32_t>();
+        if (p_rej * (double)len > 1.0 || len >= 0xFFFFFFF0ull) {               // rejections are the rule: exact order for all
+            HIP_TRY(launch_chacha_apply_repair(seeds, nullptr, 0, nullptr, participants, nullptr, len, c.mod, zone, d_secrets,
+                                               secrets_stride, d_masked, masked_stride, s));
+            HIP_TRY(hipStreamSynchronize(s));                                  // the host vectors above are in flight until here
+            return SDA_OK;
+        }
+        SDA_TRY(c.d_flags.reserve(participants * sizeof(RejectRecord)));
+        HIP_TRY(hipMemsetAsync(c.d_flags.p, 0, participants * sizeof(RejectRecord), s));
+        HIP_TRY(launch_chacha_apply_fast(seeds, participants, len, c.mod, zone, d_secrets, secrets_stride, d_masked, masked_stride,
+                                         c.d_flags.as<RejectRecord>(), s));
+        std::vector<RejectRecord> rec(participants);
+        HIP_TRY(hipMemcpyAsync(rec.data(), c.d_flags.p, participants * sizeof(RejectRecord), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<uint32_t> shift, exact;
+        for (size_t p = 0; p < participants; ++p)
+            if (rec[p].count) (rec[p].count <= 3 ? shift : exact).push_back((uint32_t)p);
+        if (!shift.empty() || !exact.empty()) {
+            SDA_TRY(c.d_list.reserve((shift.size() + exact.size()) * 4));
+            uint32_t* dl = c.d_list.as<uint32_t>();
+            if (!shift.empty()) HIP_TRY(hipMemcpyAsync(dl, shift.data(), shift.size() * 4, hipMemcpyHostToDevice, s));
+            if (!exact.empty()) HIP_TRY(hipMemcpyAsync(dl + shift.size(), exact.data(), exact.size() * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(launch_chacha_apply_repair(seeds, dl, shift.size(), dl + shift.size(), exact.size(), c.d_flags.as<RejectRecord>(),
+                                               len, c.mod, zone, d_secrets, secrets_stride, d_masked, masked_stride, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        return SDA_OK;
+    }
     if (c.scheme.kind == SDA_MASKING_NONE) {                                  // none.rs:13-19: identity, no mask
         HIP_TRY(hipMemcpy2DAsync(d_masked, masked_stride * 8, d_secrets, secrets_stride * 8, len * 8, participants,
                                  hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));

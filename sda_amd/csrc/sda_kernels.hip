@@ -826,12 +826,25 @@ __device__ __forceinline__ uint64_t block_candidate(const uint32_t (&o)[16], uin
 
 // Shift correction for seeds whose <= 3 rejected candidates (all below `dimension`) are recorded: the mask of
 // position i is candidate f(i) = i + #{rejected <= f(i)} instead of candidate i.
+// where the masks go: into the 128-bit column accumulators (mask combine, chacha.rs:56-77), or - APPLY - onto a
+// participant's own secrets, out[s][i] = (secrets[s][i] + mask_i(seed s)) mod m (mask, chacha.rs:36-47)
+struct MaskApply {
+    const int64_t* secrets; size_t secrets_stride;
+    int64_t* out; size_t out_stride;
+    ModParams mod;
+    __device__ __forceinline__ void put(uint32_t s, uint64_t i, uint64_t candidate) const {
+        const uint64_t x = canon_i64(secrets[(size_t)s * secrets_stride + i], mod.m, mod.mu);
+        out[(size_t)s * out_stride + i] = (int64_t)addmod(x, barrett_mod64(candidate, mod.m, mod.mu), mod.m);
+    }
+};
+
+template <bool APPLY>
 __global__ __launch_bounds__(kThreads) void chacha_mask_shift_kernel(const uint32_t* __restrict__ seeds,
                                                                      const uint32_t* __restrict__ list,
                                                                      const RejectRecord* __restrict__ rejects,
                                                                      size_t dimension, uint64_t zone,
                                                                      uint64_t* __restrict__ acc_lo,
-                                                                     int64_t* __restrict__ acc_hi) {
+                                                                     int64_t* __restrict__ acc_hi, MaskApply ap) {
     const uint32_t s = list[blockIdx.y];
     const uint32_t R = rejects[s].count;                                  // 1..3 by construction of the list
     uint32_t x0 = rejects[s].pos[0], x1 = R > 1 ? rejects[s].pos[1] : 0xFFFFFFFFu, x2 = R > 2 ? rejects[s].pos[2] : 0xFFFFFFFFu;
@@ -877,18 +890,48 @@ __global__ __launch_bounds__(kThreads) void chacha_mask_shift_kernel(const uint3
                 ++idx;
             }
         }
-        const uint64_t ov = block_candidate(o0, m);                       // what the fast kernel added here
-        acc_atomic_add(acc_lo + i, acc_hi + i, nv - ov, nv < ov ? -1 : 0);
+        if (APPLY) ap.put(s, i, nv);                                      // overwrite what the fast pass wrote here
+        else {
+            const uint64_t ov = block_candidate(o0, m);                   // what the fast kernel added here
+            acc_atomic_add(acc_lo + i, acc_hi + i, nv - ov, nv < ov ? -1 : 0);
+        }
+    }
+}
+
+// APPLY fast pass: participant s = blockIdx.y of the slice, one lane = one ChaCha block = 8 positions
+__global__ __launch_bounds__(kThreads) void chacha_mask_apply_kernel(const uint32_t* __restrict__ seeds, size_t dimension,
+                                                                     uint64_t zone, RejectRecord* __restrict__ rejects,
+                                                                     MaskApply ap) {
+    const uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t pos0 = j * 8;
+    if (pos0 >= dimension) return;
+    const uint32_t s = blockIdx.y;
+    uint32_t key[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) key[w] = seeds[(size_t)s * 8 + w];
+    uint32_t o[16];
+    chacha_block_lane<20>(key, (uint32_t)j, (uint32_t)(j >> 32), 0u, 0u, o);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (pos0 + m >= dimension) break;
+        const uint64_t v = ((uint64_t)o[2 * m] << 32) | o[2 * m + 1];
+        if (v >= zone) {
+            const uint32_t k = atomicAdd(&rejects[s].count, 1u);
+            if (k < 3) rejects[s].pos[k] = (uint32_t)(pos0 + m);
+        }
+        ap.put(s, pos0 + m, v);
     }
 }
 
 // exact expansion for the listed seeds; one workgroup per seed walks the candidate stream in order.
 // With subtract_naive the fast kernel's "candidate i -> position i" contribution is taken back.
+template <bool APPLY>
 __global__ __launch_bounds__(kThreads) void chacha_mask_slow_kernel(const uint32_t* __restrict__ seeds,
                                                                     const uint32_t* __restrict__ list, size_t dimension,
                                                                     ModParams mod, uint64_t zone,
                                                                     uint64_t* __restrict__ acc_lo,
-                                                                    int64_t* __restrict__ acc_hi, bool subtract_naive) {
+                                                                    int64_t* __restrict__ acc_hi, bool subtract_naive,
+                                                                    MaskApply ap) {
     __shared__ uint32_t wave_tot[kThreads / 64];
     __shared__ uint32_t chunk_total;
     const uint32_t s = list ? list[blockIdx.x] : blockIdx.x;
@@ -927,13 +970,16 @@ __global__ __launch_bounds__(kThreads) void chacha_mask_slow_kernel(const uint32
         uint64_t pos = accepted_base + wave_off + (incl - cnt);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            if (subtract_naive) {
+            if (!APPLY && subtract_naive) {
                 const uint64_t ci = j * 8 + m;                           // naive position of candidate
                 if (ci < dimension && r[m] != 0)
                     acc_atomic_add(acc_lo + ci, acc_hi + ci, (uint64_t)0 - r[m], -1);
             }
             if (okmask & (1u << m)) {
-                if (pos < dimension) acc_atomic_add(acc_lo + pos, acc_hi + pos, r[m], 0);
+                if (pos < dimension) {
+                    if (APPLY) ap.put(s, pos, r[m]);
+                    else acc_atomic_add(acc_lo + pos, acc_hi + pos, r[m], 0);
+                }
                 ++pos;
             }
         }
@@ -1419,8 +1465,8 @@ hipError_t launch_chacha_mask_shift(const uint32_t* d_seeds, const uint32_t* d_l
     if (hipError_t e = grid_check(pos_blocks)) return e;
     for (size_t l0 = 0; l0 < n_list; l0 += 65535) {
         const unsigned nl = (unsigned)(n_list - l0 < 65535 ? n_list - l0 : 65535);
-        chacha_mask_shift_kernel<<<dim3((unsigned)pos_blocks, nl), dim3(kThreads), 0, s>>>(d_seeds, d_list + l0, d_rejects,
-                                                                                           dimension, zone, d_acc_lo, d_acc_hi);
+        chacha_mask_shift_kernel<false><<<dim3((unsigned)pos_blocks, nl), dim3(kThreads), 0, s>>>(
+            d_seeds, d_list + l0, d_rejects, dimension, zone, d_acc_lo, d_acc_hi, MaskApply{});
     }
     return hipGetLastError();
 }
@@ -1430,8 +1476,48 @@ hipError_t launch_chacha_mask_slow(const uint32_t* d_seeds, const uint32_t* d_li
                                    bool subtract_naive, hipStream_t s) {
     if (n_list == 0 || dimension == 0) return hipSuccess;
     if (hipError_t e = grid_check(n_list)) return e;
-    chacha_mask_slow_kernel<<<dim3((unsigned)n_list), dim3(kThreads), 0, s>>>(d_seeds, d_list, dimension, mod, zone,
-                                                                              d_acc_lo, d_acc_hi, subtract_naive);
+    chacha_mask_slow_kernel<false><<<dim3((unsigned)n_list), dim3(kThreads), 0, s>>>(d_seeds, d_list, dimension, mod, zone,
+                                                                                     d_acc_lo, d_acc_hi, subtract_naive, MaskApply{});
+    return hipGetLastError();
+}
+
+// ---- masks applied to each participant's own vector (chacha.rs:24-54 for a device-resident tile) ------------------
+hipError_t launch_chacha_apply_fast(const uint32_t* d_seeds, size_t participants, size_t dimension, const ModParams& mod,
+                                    uint64_t zone, const int64_t* d_secrets, size_t secrets_stride, int64_t* d_out,
+                                    size_t out_stride, RejectRecord* d_rejects, hipStream_t s) {
+    if (participants == 0 || dimension == 0) return hipSuccess;
+    const uint64_t pos_blocks = ceil_div(ceil_div(dimension, 8), kThreads);
+    if (hipError_t e = grid_check(pos_blocks)) return e;
+    uint64_t per = 0xFFFFFFFFull / (pos_blocks * kThreads);
+    if (per > 65535) per = 65535;
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (size_t p0 = 0; p0 < participants; p0 += per) {
+        const unsigned np = (unsigned)(participants - p0 < per ? participants - p0 : per);
+        const MaskApply ap{d_secrets + p0 * secrets_stride, secrets_stride, d_out + p0 * out_stride, out_stride, mod};
+        chacha_mask_apply_kernel<<<dim3((unsigned)pos_blocks, np), dim3(kThreads), 0, s>>>(d_seeds + p0 * 8, dimension, zone,
+                                                                                         d_rejects + p0, ap);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_chacha_apply_repair(const uint32_t* d_seeds, const uint32_t* d_shift_list, size_t n_shift,
+                                      const uint32_t* d_exact_list, size_t n_exact, const RejectRecord* d_rejects,
+                                      size_t dimension, const ModParams& mod, uint64_t zone, const int64_t* d_secrets,
+                                      size_t secrets_stride, int64_t* d_out, size_t out_stride, hipStream_t s) {
+    if (dimension == 0) return hipSuccess;
+    const MaskApply ap{d_secrets, secrets_stride, d_out, out_stride, mod};
+    const uint64_t pos_blocks = ceil_div(ceil_div(dimension, 8), kThreads);
+    if (hipError_t e = grid_check(pos_blocks)) return e;
+    for (size_t l0 = 0; l0 < n_shift; l0 += 65535) {
+        const unsigned nl = (unsigned)(n_shift - l0 < 65535 ? n_shift - l0 : 65535);
+        chacha_mask_shift_kernel<true><<<dim3((unsigned)pos_blocks, nl), dim3(kThreads), 0, s>>>(
+            d_seeds, d_shift_list + l0, d_rejects, dimension, zone, nullptr, nullptr, ap);
+    }
+    if (n_exact) {      // d_exact_list == nullptr: every participant 0..n_exact-1 in stream order
+        if (hipError_t e = grid_check(n_exact)) return e;
+        chacha_mask_slow_kernel<true><<<dim3((unsigned)n_exact), dim3(kThreads), 0, s>>>(d_seeds, d_exact_list, dimension, mod,
+                                                                                        zone, nullptr, nullptr, false, ap);
+    }
     return hipGetLastError();
 }
 

@@ -448,10 +448,51 @@ def test_masked_participation_on_device(gpu, P, dim, pad):
     d2 = DeviceBuffer(P * stride).zero()
     none.mask_batch_dev(d_sec.ptr, P, dim, stride, 0, 0, d2.ptr, stride)
     assert np.array_equal(d2.to_numpy().reshape(P, stride)[:, :dim], sec[:, :dim])
-    from sda_amd import capi
-    with pytest.raises(capi.SdaError):
-        crypto.SecretMasker(crypto.ChaCha(q, dim, 128)).mask_batch_dev(d_sec.ptr, P, dim, stride, d_mask.ptr, stride,
-                                                                     d_masked.ptr, stride)
+
+
+@pytest.mark.parametrize("q,dim,P,bits", [(P62, 1237, 9, 128), (433, 40, 50, 128), (P62, 8, 3, 64),
+                                          ((1 << 62) - (1 << 51), 1500, 120, 128),   # ~0.7 rejections per seed: shift + exact
+                                          ((1 << 62) - (1 << 51), 40, 800, 256),     # rejections near the end: tail walk
+                                          ((1 << 61) + 1, 8, 300, 128),              # 12 % rejection on 8 candidates
+                                          ((1 << 61) + 1, 3000, 4, 128)])            # rejections are the rule: exact order for all
+def test_chacha_masking_of_a_device_tile(gpu, q, dim, P, bits):
+    """chacha.rs:24-54 for a device-resident tile: every participant gets an OS-entropy seed (returned as its mask,
+    chacha.rs:48-50) and masked[p][i] = (secret + i-th rand-0.3 gen_range value of that seed) mod q, bit-exact against
+    the oracle's expansion of the seeds read back - through the fast pass, the parallel shift repair, the exact-order
+    walk and the all-exact form; the recipient's MaskCombiner over the same seeds then unmasks the sum."""
+    from sda_amd import capi, crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(dim * 7 + P)
+    nw = (bits + 31) // 32
+    stride, mstride = dim + 3, nw + 1
+    sec = np.zeros((P, stride), dtype=np.int64)
+    sec[:, :dim] = rng.integers(-(1 << 62), 1 << 62, size=(P, dim), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec)
+    d_seed = DeviceBuffer(P * mstride).zero()
+    d_masked = DeviceBuffer(P * stride).zero()
+    sch = crypto.ChaCha(q, dim, bits)
+    crypto.SecretMasker(sch).mask_batch_dev(d_sec.ptr, P, dim, stride, d_seed.ptr, mstride, d_masked.ptr, stride)
+    seeds = d_seed.to_numpy().reshape(P, mstride)
+    masked = d_masked.to_numpy().reshape(P, stride)
+    assert not seeds[:, nw:].any() and not masked[:, dim:].any()
+    assert ((seeds[:, :nw] >= 0) & (seeds[:, :nw] < (1 << 32))).all()          # u32 words (chacha.rs:30-33)
+    assert len({tuple(r) for r in seeds[:, :nw]}) == P                           # fresh entropy per participant
+    for p in range(P):
+        mask = coracle.chacha_expand(seeds[p, :nw], q, dim)
+        assert np.array_equal(masked[p, :dim], coracle.addsub(sec[p, :dim], mask, q)), p
+    # recipient: combine the seeds, combine the masked vectors, unmask == sum of the secrets
+    total_mask = crypto.MaskCombiner(sch).combine(np.ascontiguousarray(seeds[:, :nw]))
+    total_masked = coracle.combine(q, masked[:, :dim])
+    assert np.array_equal(crypto.SecretUnmasker(sch).unmask((total_mask, total_masked)), coracle.combine(q, sec[:, :dim]))
+    with pytest.raises(AssertionError):                                          # assert_eq!, chacha.rs:26
+        try:
+            crypto.SecretMasker(sch).mask_batch_dev(d_sec.ptr, P, dim - 1 if dim > 1 else 2, stride, d_seed.ptr, mstride,
+                                                    d_masked.ptr, stride)
+        except capi.SdaError as e:
+            if e.code == capi.ERR_ASSERTION:
+                raise AssertionError(e.message)
+            raise
 
 
 def test_scheme_validation(gpu):

@@ -94,5 +94,11 @@ out["full_mask_combine_dev_2000x1Mi"] = {"ms": dt * 1e3, "elements_per_s": P * d
 um = crypto.SecretUnmasker(crypto.Full(P62))
 dt = timed(lambda: um.unmask_dev(tot.ptr, d_masked.ptr, dim, o3.ptr), reps=5)
 out["unmask_dev_1Mi"] = {"ms": dt * 1e3, "elements_per_s": dim / dt}
+# M2 on device: ChaCha-seeded masking of the same tile (chacha.rs:24-54 x 2000 participants; seeds from OS entropy)
+mkc = crypto.SecretMasker(crypto.ChaCha(P62, dim, 128))
+d_seedw = DeviceBuffer(P * 4)
+dt = timed(lambda: mkc.mask_batch_dev(sec.ptr, P, dim, dim, d_seedw.ptr, 4, d_masked.ptr, dim), reps=3)
+out["chacha_mask_batch_dev_2000x1Mi"] = {"ms": dt * 1e3, "elements_per_s": P * dim / dt,
+                                        "note": "rand-0.3 ChaChaRng expansion of one seed per participant, 8 B read + 8 B written per element"}
 del sec, d_mask, d_masked
 print(json.dumps(out, indent=1))
