@@ -374,7 +374,8 @@ struct sda_share_generator {
     std::vector<uint64_t> Mmont;         // n x (k+t), Montgomery form
     MatArg* matarg = nullptr;            // fast path (kernarg copy)
     bool fast = false;
-    bool l31 = false;                    // k + t <= 4: balanced-31-bit-limb kernel
+    bool l31 = false;                    // balanced-31-bit-limb kernel, matrix in the kernarg segment
+    bool l31g = false;                   // the same with run-time (k, t) and the matrix in global memory (d_M)
     L31Params lp{};
     Drbg drbg;
     Ctx ctx;
@@ -416,9 +417,7 @@ static int build_l31(sda_share_generator* g) {
     g->lp.p = p; g->lp.p2 = 2 * p; g->lp.h = (p + 1) / 2;
     g->lp.p0 = (int32_t)(p % B); g->lp.p1 = (int32_t)(p >> 31);
     g->lp.pinvB = (uint32_t)((B - inv) % B); g->lp.pad = 0;
-    g->matarg = new (std::nothrow) MatArg();
-    if (!g->matarg) return fail(SDA_ERR_ALLOC, "out of memory");
-    memset(g->matarg, 0, sizeof(MatArg));
+    std::vector<uint64_t> packed(g->Mmont.size() + 3, 0);               // three zero entries past the end (see l31_dot_rt)
     const uint64_t r64_inv_to_r62 = h_powmod(4 % p, p - 2, p);          // Mmont holds M * 2^64: divide by 4
     for (size_t i = 0; i < g->Mmont.size(); ++i) {
         const uint64_t mr = h_mulmod(g->Mmont[i], r64_inv_to_r62, p);   // M * 2^62 mod p
@@ -427,8 +426,17 @@ static int build_l31(sda_share_generator* g) {
         int64_t m0 = (int64_t)(((uint64_t)c64 & (B - 1)));
         if (m0 >= (int64_t)(B >> 1)) m0 -= (int64_t)B;
         const int64_t m1 = (c64 - m0) / (int64_t)B;
-        g->matarg->e[i] = (uint64_t)(uint32_t)(int32_t)m0 | ((uint64_t)(uint32_t)(int32_t)m1 << 32);
+        packed[i] = (uint64_t)(uint32_t)(int32_t)m0 | ((uint64_t)(uint32_t)(int32_t)m1 << 32);
     }
+    if (g->l31g) {                                                      // matrix in global memory
+        SDA_TRY(g->d_M.reserve(packed.size() * 8));
+        HIP_TRY(hipMemcpy(g->d_M.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
+        return SDA_OK;
+    }
+    g->matarg = new (std::nothrow) MatArg();
+    if (!g->matarg) return fail(SDA_ERR_ALLOC, "out of memory");
+    memset(g->matarg, 0, sizeof(MatArg));
+    memcpy(g->matarg->e, packed.data(), g->Mmont.size() * 8);
     return SDA_OK;
 }
 
@@ -462,7 +470,9 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
     if (st == SDA_OK && !g->additive) {
         g->l31 = packed_l31_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64");
         g->fast = !g->l31 && packed_fast_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC");
-        if (g->l31) {
+        g->l31g = !g->l31 && !g->fast && packed_l31_global_path_available(g->k, g->t) && !getenv("SDA_FORCE_GENERIC") &&
+                  !getenv("SDA_FORCE_MONT64");
+        if (g->l31 || g->l31g) {
             st = build_l31(g);
         } else if (g->fast) {
             g->matarg = new (std::nothrow) MatArg();
@@ -531,6 +541,11 @@ extern "C" int sda_share_generator_generate_batch_dev(sda_share_generator_t* g, 
     }
     if (g->fast) {
         HIP_TRY(launch_packed_generate(L, g->n, g->k, g->t, g->mod, g->mont, *g->matarg, g->drbg.key, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->l31g) {
+        HIP_TRY(launch_packed_generate_l31_global(L, g->n, g->k, g->t, g->mod, g->lp, g->d_M.as<uint64_t>(), g->drbg.key,
+                                                  g->drbg.rounds, s));
         return SDA_OK;
     }
     // any-shape path: materialise the CSPRNG draws first (identical values to the fused path)

@@ -444,9 +444,9 @@ __device__ __forceinline__ uint64_t l31_dot_rt(const uint64_t* __restrict__ row,
 
 template <int KTMAX, int ROUNDS>
 __device__ __forceinline__ void packed_gen_l31_rt_body(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
-                                                       const ModParams& mod, const L31Params& lp, const MatArg& M,
-                                                       const DrbgKey& key, uint64_t chunks, uint64_t batches, bool vec,
-                                                       uint64_t item) {
+                                                       const ModParams& mod, const L31Params& lp,
+                                                       const uint64_t* __restrict__ Mrows, const DrbgKey& key,
+                                                       uint64_t chunks, uint64_t batches, bool vec, uint64_t item) {
     const uint32_t kt = k + t;
     uint64_t p, chunk;
     split_item(item, chunks, p, chunk);
@@ -479,7 +479,7 @@ __device__ __forceinline__ void packed_gen_l31_rt_body(const GenLayout& L, uint3
     }
     int64_t* op = L.out + p * L.out_stride_participant + b0;
     for (uint32_t j = 0; j < n; ++j) {
-        const uint64_t* row = &M.e[(size_t)j * kt];
+        const uint64_t* row = Mrows + (size_t)j * kt;
         const uint64_t a = l31_dot_rt<KTMAX>(row, a0, a1, kt, lp);
         const uint64_t b = l31_dot_rt<KTMAX>(row, c0, c1, kt, lp);
         int64_t* o = op + (size_t)j * L.out_stride_clerk;
@@ -495,7 +495,17 @@ template <int KTMAX, int ROUNDS>
 __global__ __launch_bounds__(kThreads) void packed_gen_l31_rt_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t,
                                                                      ModParams mod, L31Params lp, MatArg M, DrbgKey key,
                                                                      uint64_t chunks, uint64_t batches, bool vec) {
-    packed_gen_l31_rt_body<KTMAX, ROUNDS>(L, n, k, t, mod, lp, M, key, chunks, batches, vec, blockIdx.x);
+    packed_gen_l31_rt_body<KTMAX, ROUNDS>(L, n, k, t, mod, lp, &M.e[0], key, chunks, batches, vec, blockIdx.x);
+}
+
+// the same with the matrix in global memory (n (k + t) beyond the kernarg budget, or k + t up to 32): the row entries
+// are wave-uniform, so they still arrive by scalar loads
+template <int KTMAX, int ROUNDS>
+__global__ __launch_bounds__(kThreads) void packed_gen_l31_rtg_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t,
+                                                                      ModParams mod, L31Params lp,
+                                                                      const uint64_t* __restrict__ Mg, DrbgKey key,
+                                                                      uint64_t chunks, uint64_t batches, bool vec) {
+    packed_gen_l31_rt_body<KTMAX, ROUNDS>(L, n, k, t, mod, lp, Mg, key, chunks, batches, vec, blockIdx.x);
 }
 
 // any-shape fallback: one lane = one batch, matrix and randomness read from global memory
@@ -674,7 +684,7 @@ __global__ __launch_bounds__(kThreads) void fused_packed_l31_rt_kernel(GenLayout
                                                                        uint64_t chunks, uint64_t batches, FuseArgs F) {
     uint64_t idx;
     if (!fuse_dispatch(F, blockIdx.x, idx))
-        packed_gen_l31_rt_body<KTMAX, ROUNDS>(L, n, k, t, mod, lp, M, key, chunks, batches, true, idx);
+        packed_gen_l31_rt_body<KTMAX, ROUNDS>(L, n, k, t, mod, lp, &M.e[0], key, chunks, batches, true, idx);
 }
 
 template <int ROUNDS>
@@ -1210,6 +1220,42 @@ hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k
         case 8: return packed_l31_launch_r<8>(L, n, k, t, mod, lp, M, key, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+template <int KTMAX, int ROUNDS>
+static hipError_t packed_l31_launch_rtg(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                        const L31Params& lp, const uint64_t* d_M, const DrbgKey& key, hipStream_t s) {
+    const uint64_t batches = ceil_div(L.len, k);
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        const bool vec = aligned16(S.out) && S.out_stride_participant % 2 == 0 && S.out_stride_clerk % 2 == 0;
+        packed_gen_l31_rtg_kernel<KTMAX, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(
+            S, n, k, t, mod, lp, d_M, key, chunks, batches, vec);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
+bool packed_l31_global_path_available(uint32_t k, uint32_t t) { return k >= 1 && k + t <= 32; }
+
+// d_M: n (k + t) limb-31 packed entries followed by three zero entries (device memory)
+hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                             const L31Params& lp, const uint64_t* d_M, const DrbgKey& key, int rounds,
+                                             hipStream_t s) {
+    const uint32_t kt = k + t;
+#define RTG(KTMAX_)                                                                                        \
+    (rounds == 20 ? packed_l31_launch_rtg<KTMAX_, 20>(L, n, k, t, mod, lp, d_M, key, s)                    \
+     : rounds == 12 ? packed_l31_launch_rtg<KTMAX_, 12>(L, n, k, t, mod, lp, d_M, key, s)                  \
+     : rounds == 8 ? packed_l31_launch_rtg<KTMAX_, 8>(L, n, k, t, mod, lp, d_M, key, s) : hipErrorInvalidValue)
+    if (kt <= 8) return RTG(8);
+    if (kt <= 16) return RTG(16);
+    if (kt <= 32) return RTG(32);
+#undef RTG
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,

@@ -11,9 +11,11 @@ lib = capi.load()
 dim, P = 1 << 20, 500
 sec = DeviceBuffer(P * dim)
 capi.check(lib.sda_fill_synthetic_dev(sec.ptr, P, dim, dim, 0, 3, P62, None))
-W[16], W[27] = 2589100645267092065, 365137883145458390
+W[16], W[27], W[32], W[64], W[3] = 2589100645267092065, 365137883145458390, 1942624553499164220, 2724396144719537715, 3
 for (k, t, n, o2, o3) in [(4, 3, 8, 8, 9), (5, 2, 8, 8, 9), (6, 1, 8, 8, 9), (7, 0, 8, 8, 9), (3, 4, 8, 8, 9), (8, 7, 26, 16, 27),
-                          (6, 2, 8, 16, 9), (9, 6, 26, 16, 27)]:   # the last two are not compiled: generic kernel
+                          (6, 2, 8, 16, 9), (9, 6, 26, 16, 27),    # run-time (k, t) kernel
+                          (3, 4, 80, 8, 3), (10, 7, 26, 32, 27), (20, 11, 40, 32, 3),   # the same, matrix in global memory
+                          (20, 13, 8, 64, 9)]:                     # generic kernel
     sch = crypto.PackedShamir(k, n, t, P62, W[o2], W[o3])
     gen = crypto.ShareGenerator(sch)
     B = (dim + k - 1) // k
