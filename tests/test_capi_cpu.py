@@ -145,6 +145,17 @@ def test_abi_misuse_returns_codes_not_crashes(built):
     assert lib.sda_varint_decode(None, u8, 4, buf, 4, C.byref(n)) == bad
     assert lib.sda_positive(None, 4, 433, None) == bad and lib.sda_positive(None, 0, 433, None) == capi.OK
     assert lib.sda_event_create(None) == bad and lib.sda_dev_malloc(None, 8) == bad
+    # the entry points added for the pipelined / wire-format / device-resident forms
+    assert lib.sda_share_generator_generate_combine_dev(None, None, None, 0, 0, 0, 0, None, 0, 0, None, 0, None) == bad
+    assert lib.sda_varint_encode_dev(None, None, 1, 1, 1, None, 0, None, None, None) == bad
+    assert lib.sda_varint_decode_dev(None, None, 0, None, 1, 1, None, 1, None, None) == bad
+    assert lib.sda_varint_encode_rows_dev(None, None, 1, 1, 1, None, 16, None, None) == bad
+    assert lib.sda_varint_decode_rows_dev(None, None, 16, None, 1, 1, None, 1, None, None) == bad
+    assert lib.sda_share_combiner_update_varint_dev(None, None, None, 0, None, 1, None, None) == bad
+    assert lib.sda_share_combiner_update_varint_rows_dev(None, None, None, 16, None, 1, None, None) == bad
+    assert lib.sda_secret_masker_mask_batch_dev(None, None, 1, 1, 1, 0, None, 1, None, 1, None) == bad
+    assert lib.sda_secret_unmasker_unmask_dev(None, None, None, 1, None, None) == bad
+    assert lib.sda_varint_slot_size(3) == 32 and lib.sda_varint_slot_size(0) == 0 and lib.sda_varint_max_encoded_size(3) == 30
     assert lib.sda_last_error() != b""
     # free functions accept NULL
     for f in ("sda_share_generator_free", "sda_share_combiner_free", "sda_secret_reconstructor_free",

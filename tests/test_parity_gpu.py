@@ -847,3 +847,47 @@ def test_dual_role_pipeline_equals_separate_launches(gpu, kind):
     # and against the oracle: clerk 0's sum over all tiles
     host = np.concatenate([r.to_numpy().reshape(n, P, Bs)[0, :, :B] for r in ref_shares])
     assert np.array_equal(sums.to_numpy()[:B], coracle.combine(P62, host))
+
+
+def test_device_entry_points_refuse_bad_arguments(gpu):
+    """with a live device: wrong sizes, strides, states and alignments come back as status codes (and leave the
+    library usable), they do not launch anything."""
+    import ctypes as C
+    from sda_amd import capi, crypto
+    from sda_amd.device import DeviceBuffer
+    lib = gpu
+    bad, state = capi.ERR_INVALID_ARGUMENT, capi.ERR_STATE
+    sch = crypto.PackedShamir(3, 8, 1, P62, W[8], W[9])
+    gen, comb, codec = crypto.ShareGenerator(sch), crypto.ShareCombiner(sch), crypto.VarintCodec()
+    buf = DeviceBuffer(4096).zero()
+    st = DeviceBuffer(1).zero()
+    g, c, v = gen._h, comb._h, codec._h
+    # generate: NULL device pointers, empty work is fine
+    assert lib.sda_share_generator_generate_batch_dev(g, None, 2, 10, 10, None, 0, 0, buf.ptr, 16, 64, None) == bad
+    assert lib.sda_share_generator_generate_batch_dev(g, buf.ptr, 0, 10, 10, None, 0, 0, buf.ptr, 16, 64, None) == capi.OK
+    # combiner: update / finish / pipelined step before begin
+    assert lib.sda_share_combiner_update_dev(c, buf.ptr, 64, 2, 16, None) == state
+    assert lib.sda_share_combiner_finish_dev(c, buf.ptr, None) == state
+    assert lib.sda_share_generator_generate_combine_dev(g, c, buf.ptr, 1, 10, 10, 0, buf.ptr, 16, 64, None, 0, None) == state
+    comb.begin_dev(8, 5)
+    # pipelined step: the combiner must match the generator's (share_count, batches)
+    assert lib.sda_share_generator_generate_combine_dev(g, c, buf.ptr, 1, 10, 10, 0, buf.ptr, 16, 64, None, 0, None) == bad
+    assert lib.sda_share_generator_generate_combine_dev(g, c, buf.ptr, 1, 15, 15, 0, buf.ptr, 16, 64, None, 3, None) == bad   # d_prev NULL
+    # wire format: rows not a multiple of the jobs, missing offsets, misaligned slots, short slots
+    assert lib.sda_share_combiner_update_varint_dev(c, v, buf.ptr, 100, buf.ptr, 9, st.ptr, None) == bad
+    assert lib.sda_share_combiner_update_varint_dev(c, v, buf.ptr, 100, None, 16, st.ptr, None) == bad
+    assert lib.sda_share_combiner_update_varint_rows_dev(c, v, buf.ptr + 8, 64, buf.ptr, 8, st.ptr, None) == bad
+    assert lib.sda_share_combiner_update_varint_rows_dev(c, v, buf.ptr, 40, buf.ptr, 8, st.ptr, None) == bad
+    assert lib.sda_varint_encode_rows_dev(v, buf.ptr, 2, 10, 10, buf.ptr + 1024, 96, buf.ptr + 2048, None) == bad       # slot < 10 * len
+    assert lib.sda_varint_encode_rows_dev(v, buf.ptr, 2, 10, 9, buf.ptr + 1024, 112, buf.ptr + 2048, None) == bad       # stride < len
+    assert lib.sda_varint_decode_dev(v, buf.ptr, 100, None, 3, 4, buf.ptr + 1024, 4, st.ptr, None) == bad              # offsets needed
+    assert lib.sda_varint_decode_rows_dev(v, buf.ptr, 24, buf.ptr + 512, 2, 2, buf.ptr + 1024, 2, st.ptr, None) == bad  # slot % 16
+    # masking: strides, scheme mismatch
+    mk = crypto.SecretMasker(crypto.Full(P62))
+    assert lib.sda_secret_masker_mask_batch_dev(mk._h, buf.ptr, 2, 10, 9, 0, buf.ptr + 1024, 10, buf.ptr + 2048, 10, None) == bad
+    mc = crypto.SecretMasker(crypto.ChaCha(P62, 10, 128))
+    assert lib.sda_secret_masker_mask_batch_dev(mc._h, buf.ptr, 2, 9, 10, 0, buf.ptr + 1024, 4, buf.ptr + 2048, 10, None) == capi.ERR_ASSERTION
+    assert lib.sda_secret_masker_mask_batch_dev(mc._h, buf.ptr, 2, 10, 10, 0, buf.ptr + 1024, 3, buf.ptr + 2048, 10, None) == bad
+    # and the handles still work
+    secrets = np.arange(10, dtype=np.int64)
+    assert gen.generate(secrets).shape == (8, 4)
