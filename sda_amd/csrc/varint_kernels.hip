@@ -51,17 +51,34 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* lds_waves
 }
 
 // ---- encode ---------------------------------------------------------------------------------------
+// Only the workgroup total matters here, so the 2048 values of a block are dealt to the lanes in coalesced pairs
+// (pair q of the block -> lane q % 256, one 16-byte load when the pair lies inside a row and is aligned) instead of
+// the 8 consecutive values per lane the write kernel needs.
 __global__ __launch_bounds__(kVT) void varint_len_kernel(VarintRows R, uint32_t* __restrict__ block_bytes) {
     __shared__ uint32_t waves[kVT / 64];
     const uint64_t N = (uint64_t)R.rows * R.len;
-    const uint64_t g0 = ((uint64_t)blockIdx.x * kVT + threadIdx.x) * kVals;
+    const uint64_t base = (uint64_t)blockIdx.x * kVT * kVals;
+    const bool vec_ok = (((uintptr_t)R.values) & 15u) == 0 && (R.row_stride & 1u) == 0;
     uint32_t sum = 0;
-    if (g0 < N) {
-        uint64_t r = g0 / R.len, i = g0 - r * R.len;
+    uint64_t g = base + 2 * (uint64_t)threadIdx.x;
+    if (g < N) {
+        uint64_t r = g / R.len, i = g - r * R.len;
 #pragma unroll
-        for (int k = 0; k < kVals; ++k) {
-            if (g0 + k < N) sum += varint_len(zigzag(R.values[r * R.row_stride + i]));
-            if (++i == R.len) { i = 0; ++r; }
+        for (int u = 0; u < kVals / 2; ++u) {
+            if (g < N) {
+                const int64_t* p = R.values + r * R.row_stride + i;
+                if (vec_ok && i + 1 < R.len && (i & 1u) == 0) {
+                    typedef long long ll2v __attribute__((ext_vector_type(2)));
+                    const ll2v v = __builtin_nontemporal_load(reinterpret_cast<const ll2v*>(p));
+                    sum += varint_len(zigzag(v.x)) + varint_len(zigzag(v.y));
+                } else {
+                    sum += varint_len(zigzag(p[0]));
+                    if (g + 1 < N) sum += varint_len(zigzag(i + 1 < R.len ? p[1] : R.values[(r + 1) * R.row_stride]));
+                }
+            }
+            g += 2 * kVT;
+            i += 2 * kVT;
+            if (i >= R.len) { const uint64_t q = i / R.len; r += q; i -= q * R.len; }
         }
     }
     uint32_t total;
