@@ -8,6 +8,7 @@
 #include "../../include/sda_hip.h"
 
 #include <hip/hip_runtime_api.h>
+#include <errno.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -169,6 +170,7 @@ int os_entropy(void* buf, size_t len) {
     size_t got = 0;
     while (got < len) {
         ssize_t r = getrandom(b + got, len - got, 0);
+        if (r < 0 && errno == EINTR) continue;
         if (r <= 0) return fail(SDA_ERR_INVALID_ARGUMENT, "getrandom failed");
         got += (size_t)r;
     }
