@@ -102,15 +102,23 @@ class Env:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+        # SDA_DIST_BACKEND=gloo + SDA_SHARE_GPU=1: a rehearsal of the N > 1 path on a ONE-GPU box - every rank runs its
+        # kernels on device 0 and the exchange is staged through host memory (sda_amd.distributed does that for gloo)
+        self.backend = os.environ.get("SDA_DIST_BACKEND", "nccl")
+        device_index = 0 if os.environ.get("SDA_SHARE_GPU") == "1" else self.local_rank
+        torch.cuda.set_device(device_index)
+        self.dev = torch.device("cuda", device_index)
         self.use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", device_id=self.dev)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+        self.ctl_dev = self.dev if self.backend == "nccl" else torch.device("cpu")   # where the tiny control tensors live
         self.lib = capi.load()
-        capi.check(self.lib.sda_set_device(self.local_rank))
+        capi.check(self.lib.sda_set_device(device_index))
 
     def barrier(self):
         self.torch.cuda.synchronize(self.dev)
@@ -164,7 +172,7 @@ def measure_fused(env, name, dim, P, steps, warmup, row_align=16, verify=True):
     sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
     if env.use_dist:
         modular_allreduce(sums, P62)
-        tw = torch.zeros(1, dtype=torch.float64, device=dev)
+        tw = torch.zeros(1, dtype=torch.float64, device=env.ctl_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     env.barrier()
     t0 = time.perf_counter()
@@ -175,7 +183,7 @@ def measure_fused(env, name, dim, P, steps, warmup, row_align=16, verify=True):
     env.barrier()
     dt = time.perf_counter() - t0
     if env.use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=env.ctl_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms = C.c_float()
@@ -336,7 +344,7 @@ def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=Tr
         # with the real message sizes
         with torch.cuda.stream(s_comb):
             modular_allreduce(sums, P62)
-        tw = torch.zeros(1, dtype=torch.float64, device=dev)
+        tw = torch.zeros(1, dtype=torch.float64, device=env.ctl_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     env.barrier()
     t0 = time.perf_counter()
@@ -348,7 +356,7 @@ def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=Tr
     env.barrier()
     dt = time.perf_counter() - t0
     if env.use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=env.ctl_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -54,11 +54,15 @@ def modular_allreduce(partial: torch.Tensor, modulus: int, group=None,
         return reduce_fn(flat.unsqueeze(0), modulus).reshape(partial.shape)
     n = flat.numel()
     seg = (n + world - 1) // world                      # slice owned by each rank
-    padded = torch.zeros(seg * world, dtype=torch.int64, device=flat.device)
-    padded[:n] = flat
+    # gloo moves host memory only: with device tensors (a one-GPU rehearsal of the multi-rank path) the two exchanges are
+    # staged through the host, the modular sum of the slices still runs on the device
+    staged = flat.is_cuda and dist.get_backend(group) == "gloo"
+    wire_dev = torch.device("cpu") if staged else flat.device
+    padded = torch.zeros(seg * world, dtype=torch.int64, device=wire_dev)
+    padded[:n] = flat.to(wire_dev)
     recv = torch.empty_like(padded)                     # [world][seg]: slice `rank` of every peer
     dist.all_to_all_single(recv, padded, group=group)
-    mine = reduce_fn(recv.view(world, seg), modulus)    # exact modular sum of the G slices
-    gathered = torch.empty(seg * world, dtype=torch.int64, device=flat.device)
-    dist.all_gather_into_tensor(gathered, mine.contiguous(), group=group)
-    return gathered[:n].reshape(partial.shape)
+    mine = reduce_fn(recv.to(flat.device).view(world, seg), modulus)    # exact modular sum of the G slices
+    gathered = torch.empty(seg * world, dtype=torch.int64, device=wire_dev)
+    dist.all_gather_into_tensor(gathered, mine.contiguous().to(wire_dev), group=group)
+    return gathered[:n].to(flat.device).reshape(partial.shape)
