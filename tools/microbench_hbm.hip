@@ -35,9 +35,11 @@ __global__ __launch_bounds__(256) void k(const long long* __restrict__ in, long 
 __global__ __launch_bounds__(256) void kmix(const long long* __restrict__ in, long long* __restrict__ out,
                                             const long long* __restrict__ prev, size_t dim, size_t B, size_t Bs, size_t P,
                                             size_t chunks, unsigned long long n_gen, unsigned long long n_comb,
-                                            unsigned col_blocks, long long* sink) {
-    const unsigned long long b = blockIdx.x, period = 15;
-    const unsigned long long q = b / period, rem = b - q * period;
+                                            unsigned col_blocks, long long* sink, unsigned G) {
+    // G = 1: every 15th workgroup is a clerk-sum item; G > 1: runs of G clerk-sum items followed by 14 G share-gen chunks
+    const unsigned long long b = blockIdx.x, period = 15ull * G;
+    const unsigned long long grp = b / period, off = b - grp * period;
+    const unsigned long long q = grp * G + (off < G ? off : G), rem = off < G ? 0 : 1;
     if (rem == 0 && q < n_comb) {
         const size_t bx = q % col_blocks, t = q / col_blocks, job = t % 8, split = t / 8;
         const size_t c0 = 2 * (bx * 256 + threadIdx.x);
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void kmix(const long long* __restrict__ in, lo
         if ((a ^ c) == 0x1234567) *sink = a;
         return;
     }
-    const unsigned long long before = q + (rem ? 1 : 0);
+    const unsigned long long before = q;                         // clerk-sum positions below b
     const unsigned long long idx = b - (before < n_comb ? before : n_comb);
     if (idx >= n_gen) return;
     const size_t p = idx / chunks, chunk = idx - p * chunks;
@@ -109,14 +111,19 @@ int main() {
         const unsigned long long n_gen = chunks * P, n_comb = (unsigned long long)col_blocks * 8 * 4;
         const unsigned long long grid = n_gen + n_comb;
         hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-        float best = 1e9f;
-        for (int r = 0; r < 6; ++r) {
-            CHK(hipEventRecord(e0));
-            kmix<<<dim3((unsigned)grid), dim3(256)>>>(in, out, prev, dim, B, Bs, P, chunks, n_gen, n_comb, col_blocks, sink);
-            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
-            float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (r && ms < best) best = ms;
+        const unsigned Gs[] = {1, 9, 33, 129, 1025};
+        for (unsigned gi = 0; gi < 5; ++gi) {
+            float best = 1e9f;
+            for (int r = 0; r < 5; ++r) {
+                CHK(hipEventRecord(e0));
+                kmix<<<dim3((unsigned)grid), dim3(256)>>>(in, out, prev, dim, B, Bs, P, chunks, n_gen, n_comb, col_blocks, sink, Gs[gi]);
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (r && ms < best) best = ms;
+            }
+            char name[96];
+            snprintf(name, sizeof name, "dual-role traffic, runs of %u (106.2 GB)", Gs[gi]);
+            printf("%-44s %7.3f ms  %6.2f TB/s\n", name, best, (rd + 2 * wr) / (best * 1e-3) / 1e12);
         }
-        printf("%-44s %7.3f ms  %6.2f TB/s\n", "dual-role traffic, no arithmetic (106.2 GB)", best, (rd + 2 * wr) / (best * 1e-3) / 1e12);
     }
     return 0;
 }
