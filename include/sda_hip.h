@@ -31,6 +31,16 @@
  *    full.rs:24-26, chacha.rs:29-33, tss::share).  Here it is injectable: pass `rand` to reproduce a
  *    given draw sequence (parity tests), or NULL to use the handle's on-device CSPRNG (ChaCha20
  *    keyed from OS entropy; spec in DESIGN.md "sda-drbg-v1").
+ *  - CSPRNG uniqueness contract: a handle's master key is 32 bytes of OS entropy, and EVERY call that
+ *    draws from the CSPRNG runs under its own call key = KDF(master key, call index) (one ChaCha20 block
+ *    on the host).  `first_participant` only offsets the streams INSIDE one call (participant p of the
+ *    call uses stream first_participant + p), so repeating it in a later call, or mixing host and device
+ *    calls on one handle, can never repeat a keystream.  Stream ids are 56 bits: first_participant +
+ *    participants > 2^56 is refused (SDA_ERR_INVALID_ARGUMENT).
+ *    Deterministic mode - TESTS AND BENCHMARKS ONLY: after sda_*_set_drbg_key(key) the given key is the
+ *    stream key of every call and the caller's stream ids select the streams (host calls take 0, 1, 2, ...).
+ *    Runs are then reproducible, and two calls with overlapping stream ids DO repeat their randomness:
+ *    uniqueness is the caller's job in that mode, which is why no production caller should enter it.
  */
 #ifndef SDA_HIP_H
 #define SDA_HIP_H
@@ -42,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SDA_HIP_ABI_VERSION 1
+#define SDA_HIP_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum sda_status {
@@ -63,7 +73,9 @@ enum sda_status {
     SDA_ERR_NO_DEVICE = -10,                 /* no usable gfx950 device - there is no CPU fallback */
     SDA_ERR_HIP = -11,                       /* a HIP runtime call or kernel launch failed         */
     SDA_ERR_ALLOC = -12,                     /* host or device allocation failed                   */
-    SDA_ERR_STATE = -13                      /* streaming call out of order (update before begin)  */
+    SDA_ERR_STATE = -13,                     /* streaming call out of order (update before begin)  */
+    SDA_ERR_ENTROPY = -14,                   /* getrandom() failed: no key material, nothing was generated */
+    SDA_ERR_COMM = -15                       /* an RCCL call failed (multi-GPU reduce)              */
 };
 
 /* ---- scheme parameters (the wire enums stay intact) ---------------------------------------- */
@@ -144,9 +156,17 @@ uint64_t sda_share_generator_share_count(const sda_share_generator_t* g);       
 uint64_t sda_share_generator_batch_count(const sda_share_generator_t* g, size_t len); /* B              */
 uint64_t sda_share_generator_rand_count(const sda_share_generator_t* g, size_t len);  /* B * rand/batch */
 
-/* Key of the on-device CSPRNG used when rand == NULL (default: 32 bytes of OS entropy).  Setting
- * it makes NULL-rand runs reproducible (tests, bench). */
+/* TEST / BENCH ONLY - deterministic mode (see "CSPRNG uniqueness contract" above).
+ *   set_drbg_key        : `key` becomes the stream key of every call; stream ids are the caller's
+ *                         (device calls: first_participant + p; host calls: 0, 1, 2, ...).
+ *   set_drbg_master_key : `key` replaces the OS-entropy master key but the per-call key derivation stays on
+ *                         (call i runs under KDF(key, i)): pins the derivation itself in the parity tests.
+ *   set_drbg_rounds     : ChaCha rounds of the CSPRNG, 20 (default) / 12 / 8, for the A/B measurements of
+ *                         DESIGN.md; refused with SDA_ERR_STATE unless one of the two setters above was called
+ *                         first, so a production handle always runs ChaCha20. */
 int sda_share_generator_set_drbg_key(sda_share_generator_t* g, const uint8_t key[32]);
+int sda_share_generator_set_drbg_master_key(sda_share_generator_t* g, const uint8_t key[32]);
+int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int rounds);
 
 /* generate(&mut self, secrets) -> Vec<Vec<Share>>   - sharing/mod.rs:14-17, batched.rs:18-53.
  *   secrets[len]               any i64
@@ -163,8 +183,9 @@ int sda_share_generator_generate(sda_share_generator_t* g,
 
 /* P participants at once, everything resident in HBM (the bench / multi-GPU form).
  *   d_secrets : participant p at d_secrets + p*secrets_stride, `len` values each
- *   d_rand    : NULL -> on-device CSPRNG, stream id = first_participant + p; else participant p's
- *               draws at d_rand + p*rand_stride (rand_count values each)
+ *   d_rand    : NULL -> on-device CSPRNG under this call's own key, stream id = first_participant + p
+ *               (any value, e.g. 0, is safe in production - see the uniqueness contract above); else
+ *               participant p's draws at d_rand + p*rand_stride (rand_count values each)
  *   d_out     : share (p, clerk j, batch b) at d_out + p*out_stride_participant
  *                                                   + j*out_stride_clerk + b
  *               e.g. job-major [n][P][B] (what the server's snapshot transposition produces,
@@ -232,7 +253,8 @@ int sda_share_generator_generate_combine_dev(sda_share_generator_t* g, sda_share
                                              int64_t* d_out, size_t out_stride_participant, size_t out_stride_clerk,
                                              const int64_t* d_prev, size_t prev_participants, void* stream);
 
-/* host-buffer streaming form (tiles are uploaded, accumulated, discarded) */
+/* host-buffer streaming form (tiles are uploaded, accumulated, discarded); ONE job: update/finish on a combiner begun
+ * with begin_dev(jobs != 1) are refused with SDA_ERR_STATE */
 int sda_share_combiner_begin(sda_share_combiner_t* c, size_t dimension);
 int sda_share_combiner_update(sda_share_combiner_t* c, const int64_t* shares, size_t n_rows,
                               size_t row_stride);
@@ -275,7 +297,10 @@ int sda_secret_reconstructor_reconstruct_dev(sda_secret_reconstructor_t* r,
 /* new_secret_masker(&scheme) - masking/mod.rs:33-53 */
 int  sda_secret_masker_new(const sda_masking_scheme_t* scheme, sda_secret_masker_t** out);
 void sda_secret_masker_free(sda_secret_masker_t* m);
+/* TEST / BENCH ONLY, as for the share generator */
 int  sda_secret_masker_set_drbg_key(sda_secret_masker_t* m, const uint8_t key[32]);
+int  sda_secret_masker_set_drbg_master_key(sda_secret_masker_t* m, const uint8_t key[32]);
+int  sda_secret_masker_set_drbg_rounds(sda_secret_masker_t* m, int rounds);
 
 /* length of the mask vector mask() returns for `len` secrets: None 0 (none.rs:15), Full len
  * (full.rs:24-26), ChaCha ceil(seed_bitsize/32) seed words (chacha.rs:31,48-50) */

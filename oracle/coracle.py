@@ -133,6 +133,14 @@ def drbg_fill(key: bytes, stream, batches, T, modulus, rounds=20):
     return out
 
 
+def drbg_call_key(master: bytes, call_index: int) -> bytes:
+    """key of the call_index-th CSPRNG-drawing call of a handle whose master key is `master`"""
+    assert len(master) == 32
+    out = (C.c_uint8 * 32)()
+    lib().sdao_drbg_call_key((C.c_uint8 * 32)(*master), C.c_uint64(call_index), out)
+    return bytes(out)
+
+
 def fill_synthetic(participants, length, first_participant, seed, modulus):
     out = np.empty((participants, length), dtype=np.int64)
     lib().sdao_fill_synthetic(out.ctypes.data_as(I64P), C.c_size_t(participants), C.c_size_t(length), C.c_size_t(length),

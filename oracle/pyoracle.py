@@ -710,6 +710,14 @@ def drbg_value(key: bytes, stream: int, b: int, T: int, i: int, m: int, rounds: 
     return val
 
 
+def drbg_call_key(master: bytes, call_index: int) -> bytes:
+    """sda-drbg-v1 call key: words 0..7 of ChaCha20(key = master, counter = call index, nonce = "sdak" "dfv1")."""
+    kw = [int.from_bytes(master[4 * j:4 * j + 4], "little") for j in range(8)]
+    st = list(CHACHA_CONST) + kw + [call_index & MASK32, (call_index >> 32) & MASK32, 0x6b616473, 0x31766664]
+    o = chacha_block(st, 20)
+    return b"".join(int(w).to_bytes(4, "little") for w in o[:8])
+
+
 def drbg_fill(key: bytes, stream: int, batches: int, T: int, m: int, rounds: int = 20) -> List[int]:
     return [drbg_value(key, stream, b, T, i, m, rounds) for b in range(batches) for i in range(T)]
 

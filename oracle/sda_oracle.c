@@ -333,6 +333,27 @@ static void drbg_state(const uint32_t key[8], uint64_t I, uint64_t stream, uint3
     st[15] = ((uint32_t)(stream >> 32) & 0xFFFFFFu) | (attempt << 24);
 }
 
+/* sda-drbg-v1 call key (sda_amd/csrc/host_chacha.hpp): words 0..7 of the ChaCha20 block keyed with the
+ * handle's master key, block counter = call index, nonce words "sdak" "dfv1". */
+void sdao_drbg_call_key(const uint8_t master_bytes[32], uint64_t call_index, uint8_t out_bytes[32]) {
+    uint32_t st[16], o[16];
+    memcpy(st, CHACHA_CONST, 16);
+    for (int i = 0; i < 8; ++i)
+        st[4 + i] = (uint32_t)master_bytes[4 * i] | ((uint32_t)master_bytes[4 * i + 1] << 8) |
+                    ((uint32_t)master_bytes[4 * i + 2] << 16) | ((uint32_t)master_bytes[4 * i + 3] << 24);
+    st[12] = (uint32_t)call_index;
+    st[13] = (uint32_t)(call_index >> 32);
+    st[14] = 0x6b616473u;
+    st[15] = 0x31766664u;
+    sdao_chacha_block(st, 20, o);
+    for (int i = 0; i < 8; ++i) {
+        out_bytes[4 * i] = (uint8_t)o[i];
+        out_bytes[4 * i + 1] = (uint8_t)(o[i] >> 8);
+        out_bytes[4 * i + 2] = (uint8_t)(o[i] >> 16);
+        out_bytes[4 * i + 3] = (uint8_t)(o[i] >> 24);
+    }
+}
+
 /* out[b*T + i] for b < batches, i < T */
 void sdao_drbg_fill(const uint8_t key_bytes[32], int rounds, uint64_t stream, size_t batches, uint32_t T,
                     int64_t modulus, int64_t* out) {

@@ -31,6 +31,8 @@ ERR_NO_DEVICE = -10
 ERR_HIP = -11
 ERR_ALLOC = -12
 ERR_STATE = -13
+ERR_ENTROPY = -14
+ERR_COMM = -15
 
 SHARING_ADDITIVE, SHARING_PACKED_SHAMIR = 0, 1
 MASKING_NONE, MASKING_FULL, MASKING_CHACHA = 0, 1, 2
@@ -77,6 +79,8 @@ SIGNATURES = {
     "sda_share_generator_batch_count": (C.c_uint64, [_H, C.c_size_t]),
     "sda_share_generator_rand_count": (C.c_uint64, [_H, C.c_size_t]),
     "sda_share_generator_set_drbg_key": (C.c_int, [_H, c_u8p]),
+    "sda_share_generator_set_drbg_master_key": (C.c_int, [_H, c_u8p]),
+    "sda_share_generator_set_drbg_rounds": (C.c_int, [_H, C.c_int]),
     "sda_share_generator_generate": (C.c_int, [_H, c_i64p, C.c_size_t, c_i64p, C.c_size_t, c_i64p, C.c_size_t]),
     "sda_share_generator_generate_batch_dev": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                                          C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p,
@@ -104,6 +108,8 @@ SIGNATURES = {
     "sda_secret_masker_new": (C.c_int, [_MS, _HP]),
     "sda_secret_masker_free": (None, [_H]),
     "sda_secret_masker_set_drbg_key": (C.c_int, [_H, c_u8p]),
+    "sda_secret_masker_set_drbg_master_key": (C.c_int, [_H, c_u8p]),
+    "sda_secret_masker_set_drbg_rounds": (C.c_int, [_H, C.c_int]),
     "sda_secret_masker_mask_len": (C.c_uint64, [_H, C.c_size_t]),
     "sda_secret_masker_mask": (C.c_int, [_H, c_i64p, C.c_size_t, c_i64p, C.c_size_t, c_i64p, C.c_size_t, c_sizep,
                                          c_i64p]),

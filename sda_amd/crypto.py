@@ -164,8 +164,19 @@ class ShareGenerator(_Handle):
         check(self._lib.sda_share_generator_new(C.byref(cs), C.byref(self._h)))
 
     def set_drbg_key(self, key: bytes):
-        assert len(key) == 32
+        """TEST / BENCH ONLY: deterministic mode (the caller's stream ids select the CSPRNG streams)"""
+        if len(key) != 32:
+            raise ValueError("the CSPRNG key is exactly 32 bytes")
         check(self._lib.sda_share_generator_set_drbg_key(self._h, (C.c_uint8 * 32)(*key)))
+
+    def set_drbg_master_key(self, key: bytes):
+        """TEST ONLY: fixed master key, per-call key derivation stays on"""
+        if len(key) != 32:
+            raise ValueError("the CSPRNG key is exactly 32 bytes")
+        check(self._lib.sda_share_generator_set_drbg_master_key(self._h, (C.c_uint8 * 32)(*key)))
+
+    def set_drbg_rounds(self, rounds: int):
+        check(self._lib.sda_share_generator_set_drbg_rounds(self._h, rounds))
 
     def batch_count(self, length: int) -> int:
         return int(self._lib.sda_share_generator_batch_count(self._h, length))
@@ -225,16 +236,23 @@ class ShareCombiner(_Handle):
     # streaming / accumulating form (fixes the FIXME at client/src/clerk.rs:71-72)
     def begin(self, dimension: int):
         check(self._lib.sda_share_combiner_begin(self._h, dimension))
+        self._dimension = dimension
 
     def update(self, tile) -> None:
         t = np.ascontiguousarray(tile, dtype=np.int64)
         assert t.ndim == 2
         check(self._lib.sda_share_combiner_update(self._h, _ptr(t), t.shape[0], t.shape[1]))
 
-    def finish(self, dimension: int) -> np.ndarray:
-        out = np.empty(max(dimension, 1), dtype=np.int64)
+    def finish(self, dimension: Optional[int] = None) -> np.ndarray:
+        """the dimension is the one given to begin(); an argument is accepted only if it agrees"""
+        have = getattr(self, "_dimension", None)
+        if have is None:
+            raise SdaError(capi.ERR_STATE, "finish before begin")
+        if dimension is not None and dimension != have:
+            raise ValueError(f"finish({dimension}) on a combiner begun with dimension {have}")
+        out = np.empty(max(have, 1), dtype=np.int64)
         check(self._lib.sda_share_combiner_finish(self._h, _ptr(out)))
-        return out[:dimension]
+        return out[:have]
 
     def update_encoded(self, codec: "VarintCodec", raw: bytes) -> None:
         """one participant's wire-format share vector (the opened sealed-box payload, sodium.rs:83-89)"""
@@ -256,6 +274,7 @@ class ShareCombiner(_Handle):
 
     def begin_dev(self, jobs: int, dimension: int, stream: int = 0):
         check(self._lib.sda_share_combiner_begin_dev(self._h, jobs, dimension, stream or None))
+        self._dimension = dimension if jobs == 1 else None
 
     def update_dev(self, d_shares: int, job_stride: int, n_rows: int, row_stride: int, stream: int = 0):
         check(self._lib.sda_share_combiner_update_dev(self._h, d_shares, job_stride, n_rows, row_stride, stream or None))
@@ -308,7 +327,18 @@ class SecretMasker(_Handle):
         check(self._lib.sda_secret_masker_new(C.byref(cs), C.byref(self._h)))
 
     def set_drbg_key(self, key: bytes):
+        """TEST / BENCH ONLY: deterministic mode"""
+        if len(key) != 32:
+            raise ValueError("the CSPRNG key is exactly 32 bytes")
         check(self._lib.sda_secret_masker_set_drbg_key(self._h, (C.c_uint8 * 32)(*key)))
+
+    def set_drbg_master_key(self, key: bytes):
+        if len(key) != 32:
+            raise ValueError("the CSPRNG key is exactly 32 bytes")
+        check(self._lib.sda_secret_masker_set_drbg_master_key(self._h, (C.c_uint8 * 32)(*key)))
+
+    def set_drbg_rounds(self, rounds: int):
+        check(self._lib.sda_secret_masker_set_drbg_rounds(self._h, rounds))
 
     def mask(self, secrets, rand=None) -> Tuple[np.ndarray, np.ndarray]:
         s = _vec(secrets)

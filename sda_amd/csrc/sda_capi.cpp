@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "host_chacha.hpp"
 #include "host_math.hpp"
 #include "kernels.hpp"
 #include "modarith.hpp"
@@ -73,13 +74,15 @@ extern "C" const char* sda_strerror(int status) {
         case SDA_ERR_HIP: return "HIP runtime error";
         case SDA_ERR_ALLOC: return "allocation failed";
         case SDA_ERR_STATE: return "call out of order";
+        case SDA_ERR_ENTROPY: return "the operating system's entropy source failed";
+        case SDA_ERR_COMM: return "RCCL communicator error";
         default: return "unknown status";
     }
 }
 
 extern "C" const char* sda_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sda_abi_version(void) { return SDA_HIP_ABI_VERSION; }
-extern "C" const char* sda_version(void) { return "sda-hip 0.1.0 (gfx950)"; }
+extern "C" const char* sda_version(void) { return "sda-hip 0.2.0 (gfx950)"; }
 
 // -------------------------------------------------------------------------------------------------
 // device context
@@ -152,6 +155,11 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
     }
+    // for buffers that held secrets, shares, randomness or seeds: zero the memory before it returns to the allocator
+    void wipe_release() {
+        if (p) { (void)hipMemset(p, 0, cap); (void)hipDeviceSynchronize(); }
+        release();
+    }
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -171,7 +179,7 @@ int os_entropy(void* buf, size_t len) {
     while (got < len) {
         ssize_t r = getrandom(b + got, len - got, 0);
         if (r < 0 && errno == EINTR) continue;
-        if (r <= 0) return fail(SDA_ERR_INVALID_ARGUMENT, "getrandom failed");
+        if (r <= 0) return fail(SDA_ERR_ENTROPY, "getrandom failed (errno %d)", errno);
         got += (size_t)r;
     }
     return SDA_OK;
@@ -183,22 +191,53 @@ void key_from_bytes(const uint8_t key[32], DrbgKey& k) {
                  ((uint32_t)key[4 * i + 3] << 24);
 }
 
+// sda-drbg-v1 key management.  Production: the master key is 32 bytes of OS entropy and EVERY call that
+// draws from the CSPRNG runs under its own call key = KDF(master, call index) - the caller's `first_participant` only
+// offsets the streams inside that call, so repeating it can never repeat a keystream.  Deterministic mode (tests,
+// bench): set_drbg_key() makes the given key the stream key of every call and the caller's stream ids select the
+// streams - reproducible, and therefore the caller's responsibility.
 struct Drbg {
-    DrbgKey key;
-    int rounds = 20;
-    uint64_t next_stream = 0;
+    DrbgKey key{};                  // master key (production) / stream key (deterministic mode)
+    bool deterministic = false;
+    bool derive = true;             // false only in deterministic mode
+    int rounds = 20;                // 12 / 8 only through set_rounds() in deterministic mode (bench A/B)
+    uint64_t next_stream = 0;       // host forms in deterministic mode
+    uint64_t calls = 0;             // call-key index
     int init() {
         uint8_t raw[32];
         SDA_TRY(os_entropy(raw, sizeof raw));
         key_from_bytes(raw, key);
-        const char* r = getenv("SDA_DRBG_ROUNDS");     // 20 (default), 12 or 8
-        if (r) {
-            int v = atoi(r);
-            if (v == 20 || v == 12 || v == 8) rounds = v;
-        }
+        explicit_bzero(raw, sizeof raw);
         return SDA_OK;
     }
+    void set_stream_key(const uint8_t k[32]) { key_from_bytes(k, key); deterministic = true; derive = false; next_stream = 0; calls = 0; }
+    void set_master_key(const uint8_t k[32]) { key_from_bytes(k, key); deterministic = true; derive = true; next_stream = 0; calls = 0; }
+    int set_rounds(int r) {
+        if (!deterministic) return fail(SDA_ERR_STATE, "the round count can only be changed on a handle in deterministic (test / bench) mode: call set_drbg_key first");
+        if (r != 20 && r != 12 && r != 8) return fail(SDA_ERR_INVALID_ARGUMENT, "rounds must be 20, 12 or 8");
+        rounds = r;
+        return SDA_OK;
+    }
+    // key of one API call
+    DrbgKey call_key() {
+        if (!derive) return key;
+        DrbgKey k;
+        h_drbg_call_key(key.w, calls++, k.w);
+        return k;
+    }
+    // stream id of a host-form call (one participant)
+    uint64_t host_stream() { return derive ? 0 : next_stream++; }
+    void wipe() { explicit_bzero(&key, sizeof key); }
 };
+
+// stream ids are 56 bits wide in the block layout (word 15 keeps 8 bits for the retry attempt)
+int check_streams(uint64_t first, uint64_t count) {
+    const uint64_t lim = 1ull << 56;
+    if (first >= lim || count > lim - first)
+        return fail(SDA_ERR_INVALID_ARGUMENT, "CSPRNG stream ids must stay below 2^56 (first_participant %llu + %llu participants)",
+                    (unsigned long long)first, (unsigned long long)count);
+    return SDA_OK;
+}
 
 bool sharing_is_additive(const sda_sharing_scheme_t* s) { return s->kind == SDA_SHARING_ADDITIVE; }
 
@@ -310,6 +349,15 @@ int chacha_accumulate(const Ctx& ctx, const std::vector<uint32_t>& seeds8, size_
     return SDA_OK;
 }
 
+// host vectors that hold key or seed material: zeroed before the memory is released, on every exit path
+template <typename T>
+struct WipedVec : std::vector<T> {
+    using std::vector<T>::vector;
+    ~WipedVec() {
+        if (!this->empty()) explicit_bzero(this->data(), this->size() * sizeof(T));
+    }
+};
+
 // seed words (i64, used `as u32`, chacha.rs:62-64) -> 8 ChaCha key words (rand 0.3 from_seed: at most 8)
 void seed_to_key(const int64_t* words, size_t n_words, uint32_t* key8) {
     for (int i = 0; i < 8; ++i) key8[i] = (size_t)i < n_words ? (uint32_t)(uint64_t)words[i] : 0u;
@@ -399,11 +447,19 @@ static int build_packed_share_matrix(const sda_sharing_scheme_t& s, uint64_t p, 
     return SDA_OK;
 }
 
+// The scheme descriptor travels over the network in the reference protocol (Aggregation resource): every field is
+// bounded on its own BEFORE any sum is formed, so no u64 wrap-around can slip through.
 static int validate_packed(const sda_sharing_scheme_t& s) {
-    if (s.secret_count < 1) return fail(SDA_ERR_INVALID_ARGUMENT, "secret_count must be >= 1");
-    if (s.share_count < 1) return fail(SDA_ERR_INVALID_ARGUMENT, "share_count must be >= 1");
-    if (s.secret_count + s.privacy_threshold > 4096 || s.share_count > 65535)
-        return fail(SDA_ERR_UNSUPPORTED, "packed scheme too large");
+    if (s.secret_count < 1 || s.secret_count > 4096) return fail(SDA_ERR_INVALID_ARGUMENT, "secret_count must be in 1..4096");
+    if (s.privacy_threshold > 4096) return fail(SDA_ERR_INVALID_ARGUMENT, "privacy_threshold must be <= 4096");
+    if (s.share_count < 1 || s.share_count > 65535) return fail(SDA_ERR_INVALID_ARGUMENT, "share_count must be in 1..65535");
+    if (s.secret_count + s.privacy_threshold > 4096)
+        return fail(SDA_ERR_UNSUPPORTED, "packed scheme too large (secret_count + privacy_threshold > 4096)");
+    // tss zero-extends the t + k + 1 coefficients to n + 1 evaluation points: fewer shares than t + k can never be
+    // reconstructed (reconstruct_limit() = t + k)
+    if (s.share_count < s.secret_count + s.privacy_threshold)
+        return fail(SDA_ERR_INVALID_ARGUMENT, "share_count must be >= secret_count + privacy_threshold (the reconstruction threshold)");
+    // privacy_threshold == 0 is accepted (tss does when secret_count + 1 is a power of two): a sharing without privacy
     if (s.modulus < 3 || (s.modulus & 1) == 0 || !h_is_prime((uint64_t)s.modulus))
         return fail(SDA_ERR_INVALID_ARGUMENT, "prime_modulus %lld is not an odd prime", (long long)s.modulus);
     return SDA_OK;
@@ -497,8 +553,9 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
 extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
     if (!g) return;
     if (g->ctx.device >= 0) (void)hipSetDevice(g->ctx.device);
-    g->d_M.release(); g->d_secrets.release(); g->d_rand.release(); g->d_out.release();
+    g->d_M.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
     g->ctx.destroy();
+    g->drbg.wipe();
     delete g->matarg;
     delete g;
 }
@@ -512,8 +569,64 @@ extern "C" uint64_t sda_share_generator_rand_count(const sda_share_generator_t* 
 }
 extern "C" int sda_share_generator_set_drbg_key(sda_share_generator_t* g, const uint8_t key[32]) {
     if (!g || !key) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
-    key_from_bytes(key, g->drbg.key);
-    g->drbg.next_stream = 0;
+    g->drbg.set_stream_key(key);
+    return SDA_OK;
+}
+extern "C" int sda_share_generator_set_drbg_master_key(sda_share_generator_t* g, const uint8_t key[32]) {
+    if (!g || !key) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    g->drbg.set_master_key(key);
+    return SDA_OK;
+}
+extern "C" int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int rounds) {
+    if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    return g->drbg.set_rounds(rounds);
+}
+
+// one call of the generator under the CSPRNG key `key` (the call key, or the stream key in deterministic mode)
+static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, const int64_t* d_secrets,
+                               size_t participants, size_t len, size_t secrets_stride,
+                               const int64_t* d_rand, size_t rand_stride,
+                               uint64_t first_participant, int64_t* d_out,
+                               size_t out_stride_participant, size_t out_stride_clerk,
+                               void* stream) {
+    if (participants == 0 || len == 0) return SDA_OK;
+    if (!d_secrets || !d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
+    if (!d_rand) SDA_TRY(check_streams(first_participant, participants));
+    SDA_TRY(g->ctx.use());
+    hipStream_t s = g->ctx.pick(stream);
+    GenLayout L;
+    L.secrets = d_secrets; L.secrets_stride = secrets_stride;
+    L.rand = d_rand; L.rand_stride = rand_stride;
+    L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
+    L.participants = participants; L.len = len; L.first_participant = first_participant;
+    if (g->additive) {
+        HIP_TRY(launch_additive_generate(L, g->n, g->mod, key, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->l31) {
+        HIP_TRY(launch_packed_generate_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, key, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->fast) {
+        HIP_TRY(launch_packed_generate(L, g->n, g->k, g->t, g->mod, g->mont, *g->matarg, key, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->l31g) {
+        HIP_TRY(launch_packed_generate_l31_global(L, g->n, g->k, g->t, g->mod, g->lp, g->d_M.as<uint64_t>(), key,
+                                                  g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    // any-shape path: materialise the CSPRNG draws first (identical values to the fused path)
+    if (!d_rand && g->t > 0) {
+        const size_t batches = (len + g->k - 1) / g->k;
+        const size_t rstride = batches * g->t;
+        SDA_TRY(g->d_rand.reserve(participants * rstride * 8));
+        HIP_TRY(launch_drbg_fill(g->d_rand.as<int64_t>(), rstride, participants, batches, g->t, first_participant, g->mod,
+                                 key, g->drbg.rounds, s));
+        L.rand = g->d_rand.as<int64_t>();
+        L.rand_stride = rstride;
+    }
+    HIP_TRY(launch_packed_generate_generic(L, g->n, g->k, g->t, g->mod, g->mont, g->d_M.as<uint64_t>(), s));
     return SDA_OK;
 }
 
@@ -525,43 +638,11 @@ extern "C" int sda_share_generator_generate_batch_dev(sda_share_generator_t* g, 
                                                       void* stream) {
     if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "generator is NULL");
     if (participants == 0 || len == 0) return SDA_OK;
-    if (!d_secrets || !d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
-    SDA_TRY(g->ctx.use());
-    hipStream_t s = g->ctx.pick(stream);
-    GenLayout L;
-    L.secrets = d_secrets; L.secrets_stride = secrets_stride;
-    L.rand = d_rand; L.rand_stride = rand_stride;
-    L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
-    L.participants = participants; L.len = len; L.first_participant = first_participant;
-    if (g->additive) {
-        HIP_TRY(launch_additive_generate(L, g->n, g->mod, g->drbg.key, g->drbg.rounds, s));
-        return SDA_OK;
-    }
-    if (g->l31) {
-        HIP_TRY(launch_packed_generate_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, g->drbg.key, g->drbg.rounds, s));
-        return SDA_OK;
-    }
-    if (g->fast) {
-        HIP_TRY(launch_packed_generate(L, g->n, g->k, g->t, g->mod, g->mont, *g->matarg, g->drbg.key, g->drbg.rounds, s));
-        return SDA_OK;
-    }
-    if (g->l31g) {
-        HIP_TRY(launch_packed_generate_l31_global(L, g->n, g->k, g->t, g->mod, g->lp, g->d_M.as<uint64_t>(), g->drbg.key,
-                                                  g->drbg.rounds, s));
-        return SDA_OK;
-    }
-    // any-shape path: materialise the CSPRNG draws first (identical values to the fused path)
-    if (!d_rand && g->t > 0) {
-        const size_t batches = (len + g->k - 1) / g->k;
-        const size_t rstride = batches * g->t;
-        SDA_TRY(g->d_rand.reserve(participants * rstride * 8));
-        HIP_TRY(launch_drbg_fill(g->d_rand.as<int64_t>(), rstride, participants, batches, g->t, first_participant, g->mod,
-                                 g->drbg.key, g->drbg.rounds, s));
-        L.rand = g->d_rand.as<int64_t>();
-        L.rand_stride = rstride;
-    }
-    HIP_TRY(launch_packed_generate_generic(L, g->n, g->k, g->t, g->mod, g->mont, g->d_M.as<uint64_t>(), s));
-    return SDA_OK;
+    DrbgKey key = d_rand ? DrbgKey{} : g->drbg.call_key();      // injected randomness draws nothing from the CSPRNG
+    const int st = generate_batch_impl(g, key, d_secrets, participants, len, secrets_stride, d_rand, rand_stride, first_participant,
+                                       d_out, out_stride_participant, out_stride_clerk, stream);
+    explicit_bzero(&key, sizeof key);
+    return st;
 }
 
 extern "C" int sda_share_generator_generate(sda_share_generator_t* g, const int64_t* secrets, size_t len,
@@ -585,9 +666,11 @@ extern "C" int sda_share_generator_generate(sda_share_generator_t* g, const int6
         HIP_TRY(hipMemcpyAsync(g->d_rand.p, rand, want_rand * 8, hipMemcpyHostToDevice, g->ctx.stream));
         d_rand = g->d_rand.as<int64_t>();
     }
-    const uint64_t stream_id = g->drbg.next_stream++;
-    int st = sda_share_generator_generate_batch_dev(g, g->d_secrets.as<int64_t>(), 1, len, len, d_rand, want_rand, stream_id,
-                                                    g->d_out.as<int64_t>(), (size_t)g->n * Bs, Bs, nullptr);
+    DrbgKey key = d_rand ? DrbgKey{} : g->drbg.call_key();
+    const uint64_t stream_id = d_rand ? 0 : g->drbg.host_stream();
+    int st = generate_batch_impl(g, key, g->d_secrets.as<int64_t>(), 1, len, len, d_rand, want_rand, stream_id,
+                                 g->d_out.as<int64_t>(), (size_t)g->n * Bs, Bs, nullptr);
+    explicit_bzero(&key, sizeof key);
     if (st == SDA_OK) {
         hipError_t e = hipMemcpy2DAsync(out, B * 8, g->d_out.p, Bs * 8, B * 8, g->n, hipMemcpyDeviceToHost, g->ctx.stream);
         if (e != hipSuccess) st = fail(SDA_ERR_HIP, "hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
@@ -689,23 +772,28 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     L.secrets = d_secrets; L.secrets_stride = secrets_stride; L.rand = nullptr; L.rand_stride = 0;
     L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
     L.participants = len ? participants : 0; L.len = len; L.first_participant = first_participant;
+    if (L.participants) SDA_TRY(check_streams(first_participant, participants));
+    DrbgKey key = g->drbg.call_key();
     bool fused = false;
+    hipError_t he = hipSuccess;
     if (g->additive) {
-        HIP_TRY(launch_fused_additive(L, g->n, g->mod, g->drbg.key, g->drbg.rounds, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(),
-                                      d_prev, prev_participants, c->jobs, c->dimension, s, &fused));
+        he = launch_fused_additive(L, g->n, g->mod, key, g->drbg.rounds, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(),
+                                   d_prev, prev_participants, c->jobs, c->dimension, s, &fused);
     } else if (g->l31) {
-        HIP_TRY(launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, g->drbg.key, g->drbg.rounds,
-                                        c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
-                                        c->dimension, s, &fused));
+        he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, key, g->drbg.rounds,
+                                     c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
+                                     c->dimension, s, &fused);
     }
-    if (fused) return SDA_OK;
+    int st = SDA_OK;
+    if (he != hipSuccess) st = fail(SDA_ERR_HIP, "dual-role launch failed: %s", hipGetErrorString(he));
     // layouts / shapes the dual-role kernel does not cover: the two ordinary launches, same result
-    if (prev_participants > 0)
-        SDA_TRY(sda_share_combiner_update_dev(c, d_prev, out_stride_clerk, prev_participants, out_stride_participant, stream));
-    if (participants > 0 && len > 0)
-        SDA_TRY(sda_share_generator_generate_batch_dev(g, d_secrets, participants, len, secrets_stride, nullptr, 0, first_participant,
-                                                       d_out, out_stride_participant, out_stride_clerk, stream));
-    return SDA_OK;
+    if (st == SDA_OK && !fused && prev_participants > 0)
+        st = sda_share_combiner_update_dev(c, d_prev, out_stride_clerk, prev_participants, out_stride_participant, stream);
+    if (st == SDA_OK && !fused && participants > 0 && len > 0)
+        st = generate_batch_impl(g, key, d_secrets, participants, len, secrets_stride, nullptr, 0, first_participant,
+                                 d_out, out_stride_participant, out_stride_clerk, stream);
+    explicit_bzero(&key, sizeof key);
+    return st;
 }
 
 extern "C" int sda_share_combiner_set_residency(sda_share_combiner_t* c, unsigned max_workgroups_per_cu) {
@@ -733,6 +821,7 @@ extern "C" int sda_share_combiner_begin(sda_share_combiner_t* c, size_t dimensio
 extern "C" int sda_share_combiner_update(sda_share_combiner_t* c, const int64_t* shares, size_t n_rows, size_t row_stride) {
     if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
     if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (c->jobs != 1) return fail(SDA_ERR_STATE, "the host form feeds ONE job: the combiner was begun with %zu jobs (use update_dev)", c->jobs);
     if (n_rows == 0 || c->dimension == 0) return SDA_OK;
     if (!shares) return fail(SDA_ERR_INVALID_ARGUMENT, "shares is NULL");
     if (row_stride < c->dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "row_stride < dimension");
@@ -745,6 +834,7 @@ extern "C" int sda_share_combiner_update(sda_share_combiner_t* c, const int64_t*
 extern "C" int sda_share_combiner_finish(sda_share_combiner_t* c, int64_t* out) {
     if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
     if (!c->begun) return fail(SDA_ERR_STATE, "finish before begin");
+    if (c->jobs != 1) return fail(SDA_ERR_STATE, "the host form returns ONE vector: the combiner was begun with %zu jobs (use finish_dev)", c->jobs);
     if (c->dimension == 0) return SDA_OK;
     if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
     SDA_TRY(c->d_out.reserve(c->dimension * 8));
@@ -789,6 +879,8 @@ extern "C" int sda_secret_reconstructor_new(const sda_sharing_scheme_t* scheme, 
     int st = make_mod(scheme->modulus, r->mod);
     if (st == SDA_OK) {
         if (sharing_is_additive(scheme)) {
+            if (scheme->share_count < 1 || scheme->share_count > 65535)
+                st = fail(SDA_ERR_INVALID_ARGUMENT, "share_count must be in 1..65535");
             r->additive = true;
             r->n = (uint32_t)scheme->share_count;
         } else {
@@ -934,9 +1026,10 @@ struct MaskCore {
     }
     void destroy() {
         if (ctx.device >= 0) (void)hipSetDevice(ctx.device);
-        acc.release(); tile.release(); d_a.release(); d_b.release(); d_out.release();
-        d_seeds.release(); d_flags.release(); d_list.release();
+        acc.release(); tile.wipe_release(); d_a.wipe_release(); d_b.wipe_release(); d_out.wipe_release();
+        d_seeds.wipe_release(); d_flags.release(); d_list.release();
         ctx.destroy();
+        drbg.wipe();
     }
     size_t seed_words() const { return (size_t)((scheme.seed_bitsize + 31) / 32); }   // chacha.rs:31
 };
@@ -973,9 +1066,17 @@ extern "C" void sda_secret_unmasker_free(sda_secret_unmasker_t* u) { mask_handle
 
 extern "C" int sda_secret_masker_set_drbg_key(sda_secret_masker_t* m, const uint8_t key[32]) {
     if (!m || !key) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
-    key_from_bytes(key, m->core.drbg.key);
-    m->core.drbg.next_stream = 0;
+    m->core.drbg.set_stream_key(key);
     return SDA_OK;
+}
+extern "C" int sda_secret_masker_set_drbg_master_key(sda_secret_masker_t* m, const uint8_t key[32]) {
+    if (!m || !key) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    m->core.drbg.set_master_key(key);
+    return SDA_OK;
+}
+extern "C" int sda_secret_masker_set_drbg_rounds(sda_secret_masker_t* m, int rounds) {
+    if (!m) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    return m->core.drbg.set_rounds(rounds);
 }
 
 extern "C" uint64_t sda_secret_masker_mask_len(const sda_secret_masker_t* m, size_t len) {
@@ -1022,8 +1123,11 @@ extern "C" int sda_secret_masker_mask(sda_secret_masker_t* m, const int64_t* sec
             HIP_TRY(launch_addsub_mod(c.d_b.as<int64_t>(), c.d_a.as<int64_t>(), len, false, c.mod, c.tile.as<int64_t>(), s));
             HIP_TRY(hipMemcpyAsync(c.d_b.p, c.tile.p, len * 8, hipMemcpyDeviceToDevice, s));
         } else {
-            HIP_TRY(launch_full_mask_drbg(c.d_a.as<int64_t>(), len, 1, len, c.drbg.next_stream++, c.mod, c.drbg.key, c.drbg.rounds,
-                                          c.d_b.as<int64_t>(), len, c.d_out.as<int64_t>(), len, s));
+            DrbgKey key = c.drbg.call_key();
+            const hipError_t he = launch_full_mask_drbg(c.d_a.as<int64_t>(), len, 1, len, c.drbg.host_stream(), c.mod, key, c.drbg.rounds,
+                                                        c.d_b.as<int64_t>(), len, c.d_out.as<int64_t>(), len, s);
+            explicit_bzero(&key, sizeof key);
+            HIP_TRY(he);
         }
         HIP_TRY(hipMemcpyAsync(mask_out, c.d_b.p, len * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(masked_out, c.d_out.p, len * 8, hipMemcpyDeviceToHost, s));
@@ -1034,15 +1138,15 @@ extern "C" int sda_secret_masker_mask(sda_secret_masker_t* m, const int64_t* sec
 
     // ChaCha - chacha.rs:24-54
     const size_t nw = c.seed_words();
-    std::vector<int64_t> seed(nw);
+    WipedVec<int64_t> seed(nw);
     if (rand) {
         for (size_t i = 0; i < nw; ++i) seed[i] = (int64_t)(uint32_t)(uint64_t)rand[i];    // words are u32 (chacha.rs:30-33)
     } else {
-        std::vector<uint32_t> raw(nw ? nw : 1);
+        WipedVec<uint32_t> raw(nw ? nw : 1);
         SDA_TRY(os_entropy(raw.data(), nw * 4));                              // OsRng seed, chacha.rs:29-33
         for (size_t i = 0; i < nw; ++i) seed[i] = (int64_t)raw[i];
     }
-    std::vector<uint32_t> key8(8);
+    WipedVec<uint32_t> key8(8);
     seed_to_key(seed.data(), nw, key8.data());
     if (len) {
         SDA_TRY(c.acc.reset(len, s));
@@ -1080,10 +1184,10 @@ extern "C" int sda_secret_masker_mask_batch_dev(sda_secret_masker_t* m, const in
         SDA_TRY(c.ctx.use());
         hipStream_t s = c.ctx.pick(stream);
         // one OS-entropy seed per participant (chacha.rs:29-33); the "mask" a participant sends is its seed (chacha.rs:48-50)
-        std::vector<uint32_t> raw(participants * nw ? participants * nw : 1);
+        WipedVec<uint32_t> raw(participants * nw ? participants * nw : 1);
         SDA_TRY(os_entropy(raw.data(), participants * nw * 4));
-        std::vector<int64_t> words(participants * nw);
-        std::vector<uint32_t> key8(participants * 8, 0u);
+        WipedVec<int64_t> words(participants * nw);
+        WipedVec<uint32_t> key8(participants * 8, 0u);
         for (size_t p = 0; p < participants; ++p)
             for (size_t i = 0; i < nw; ++i) {
                 words[p * nw + i] = (int64_t)raw[p * nw + i];
@@ -1129,9 +1233,13 @@ extern "C" int sda_secret_masker_mask_batch_dev(sda_secret_masker_t* m, const in
     }
     if (!d_masks) return fail(SDA_ERR_INVALID_ARGUMENT, "d_masks is NULL");
     if (mask_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "stride < len");
+    SDA_TRY(check_streams(first_participant, participants));
     SDA_TRY(c.ctx.use());
-    HIP_TRY(launch_full_mask_drbg(d_secrets, secrets_stride, participants, len, first_participant, c.mod, c.drbg.key,
-                                  c.drbg.rounds, d_masks, mask_stride, d_masked, masked_stride, c.ctx.pick(stream)));
+    DrbgKey key = c.drbg.call_key();
+    const hipError_t he = launch_full_mask_drbg(d_secrets, secrets_stride, participants, len, first_participant, c.mod, key,
+                                                c.drbg.rounds, d_masks, mask_stride, d_masked, masked_stride, c.ctx.pick(stream));
+    explicit_bzero(&key, sizeof key);
+    HIP_TRY(he);
     return SDA_OK;
 }
 
@@ -1163,7 +1271,7 @@ extern "C" int sda_mask_combiner_combine(sda_mask_combiner_t* mc, const int64_t*
     const size_t dimension = (size_t)c.scheme.dimension;
     if (dimension == 0) return SDA_OK;
     if (!out || out_cap < dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small");
-    std::vector<uint32_t> key8(n_rows * 8);
+    WipedVec<uint32_t> key8(n_rows * 8);
     for (size_t r = 0; r < n_rows; ++r) {
         if (row_lens[r] > 0 && !rows[r]) return fail(SDA_ERR_INVALID_ARGUMENT, "rows[%zu] is NULL", r);
         seed_to_key(rows[r], row_lens[r], key8.data() + r * 8);

@@ -160,6 +160,7 @@ def main():
                                             (7, 16, 2, (1 << 61) + 1, 20), (1, 10, 3, P, 12), (1, 10, 3, P, 8)]:
         drbg["cases"].append({"stream": stream, "batches": batches, "T": T, "modulus": m, "rounds": rounds,
                               "values": po.drbg_fill(key, stream, batches, T, m, rounds)})
+    drbg["call_keys"] = [{"call_index": i, "key_hex": po.drbg_call_key(key, i).hex()} for i in (0, 1, 2, (1 << 32) + 5)]
     with open(os.path.join(OUT, "drbg.json"), "w") as f:
         json.dump({"generator": "tests/golden/gen_golden.py", "spec": "sda-drbg-v1 (DESIGN.md)", **drbg}, f, indent=1)
     print("wrote", sorted(x for x in os.listdir(OUT) if x.endswith(".json")))

@@ -197,6 +197,17 @@ def test_c_oracle_chacha_combine():
     assert coracle.chacha_combine([], 433, 4).tolist() == [0, 0, 0, 0]
 
 
+def test_drbg_call_key_c_equals_python_and_golden():
+    """the per-call key derivation of sda-drbg-v1 (one RFC 7539 ChaCha20 block; the block function itself is pinned by
+    the RFC vectors above)"""
+    g = load_golden("drbg.json")
+    key = bytes.fromhex(g["key_hex"])
+    for c in g["call_keys"]:
+        assert po.drbg_call_key(key, c["call_index"]).hex() == c["key_hex"]
+        assert coracle.drbg_call_key(key, c["call_index"]).hex() == c["key_hex"]
+    assert len({c["key_hex"] for c in g["call_keys"]}) == len(g["call_keys"])
+
+
 def test_drbg_spec_c_equals_python_and_golden():
     g = load_golden("drbg.json")
     key = bytes.fromhex(g["key_hex"])

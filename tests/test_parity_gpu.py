@@ -111,9 +111,9 @@ PACKED_SHAPES = [(3, 1, 8, 8, 9), (3, 4, 8, 8, 9), (8, 2, 26, 16, 27), (8, 7, 26
                  (5, 3, 26, 16, 27), (3, 0, 8, 8, 9),
                  (5, 2, 8, 8, 9), (6, 1, 8, 8, 9), (1, 6, 8, 8, 9), (7, 0, 8, 8, 9),      # the rest of the k + t = 7 family
                  (12, 3, 26, 16, 27), (10, 5, 26, 16, 27), (4, 11, 26, 16, 27),          # splits of k + t = 15
-                 (6, 2, 8, 16, 9), (9, 6, 26, 16, 27), (2, 9, 8, 16, 9), (1, 4, 26, 8, 27),  # run-time (k, t) kernel
+                 (6, 2, 8, 16, 9), (9, 6, 26, 16, 27), (2, 9, 26, 16, 27), (1, 4, 26, 8, 27),  # run-time (k, t) kernel
                  (10, 7, 26, 32, 27), (3, 2, 100, 8, 3), (3, 4, 80, 8, 3), (20, 11, 40, 32, 3),   # run-time (k, t), matrix in global memory
-                 (20, 13, 8, 64, 9)]                                                      # generic kernel (k + t > 32)
+                 (20, 13, 80, 64, 3)]                                                     # k + t > 32
 
 
 @pytest.mark.parametrize("k,t,n,o2,o3", PACKED_SHAPES)
@@ -164,16 +164,16 @@ def test_small_prime_packed_matches_tss_fft_path(gpu):
 
 # ---- device CSPRNG (sda-drbg-v1) ----------------------------------------------------------------------
 @pytest.mark.parametrize("case", range(6))
-def test_drbg_matches_spec(gpu, case, monkeypatch):
+def test_drbg_matches_spec(gpu, case):
     """Additive shares 0..n-2 ARE the raw draws, so generate(rand=NULL) exposes the CSPRNG stream."""
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     g = load_golden("drbg.json")
     c = g["cases"][case]
-    monkeypatch.setenv("SDA_DRBG_ROUNDS", str(c["rounds"]))
     T, B, m = c["T"], c["batches"], c["modulus"]
     gen = crypto.ShareGenerator(crypto.Additive(T + 1, m))
     gen.set_drbg_key(bytes.fromhex(g["key_hex"]))
+    gen.set_drbg_rounds(c["rounds"])                      # accepted in deterministic mode only
     secrets = DeviceBuffer.from_numpy(np.zeros(B + (B & 1), dtype=np.int64))
     Bs = B + (B & 1)
     out = DeviceBuffer((T + 1) * Bs)
@@ -198,6 +198,64 @@ def test_drbg_rejection_path(gpu):
     got2 = gen.generate(np.zeros(dim, dtype=np.int64))       # stream 1: fresh randomness per call
     assert np.array_equal(got2[:2], coracle.drbg_fill(KEY, 1, dim, 2, m).reshape(dim, 2).T)
     assert not np.array_equal(got, got2)
+
+
+def test_call_key_derivation_and_stream_hygiene(gpu):
+    """The CSPRNG uniqueness contract of sda_hip.h: every drawing call of a handle runs under its own key
+    KDF(master, call index), so repeating `first_participant` never repeats a keystream; deterministic streams exist
+    only after set_drbg_key; stream ids are 56 bits; the round count cannot be lowered on a production handle."""
+    from sda_amd import crypto, capi
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    m, T, B, P = P62, 2, 1000, 3
+    sch = crypto.Additive(T + 1, m)
+    secrets = DeviceBuffer.from_numpy(np.zeros(P * B, dtype=np.int64))
+    out = DeviceBuffer(P * (T + 1) * B)
+
+    def draws(gen, first):
+        gen.generate_batch_dev(secrets.ptr, P, B, B, out.ptr, (T + 1) * B, B, first_participant=first)
+        return out.to_numpy().reshape(P, T + 1, B)[:, :T, :].copy()
+
+    def want(key, first):
+        return np.stack([coracle.drbg_fill(key, first + p, B, T, m).reshape(B, T).T for p in range(P)])
+
+    master = bytes((7 * i + 3) & 0xFF for i in range(32))
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_master_key(master)
+    a, b, c = draws(gen, 5), draws(gen, 5), draws(gen, 0)          # the same first_participant twice, then another
+    assert np.array_equal(a, want(coracle.drbg_call_key(master, 0), 5))
+    assert np.array_equal(b, want(coracle.drbg_call_key(master, 1), 5))
+    assert np.array_equal(c, want(coracle.drbg_call_key(master, 2), 0))
+    assert not np.array_equal(a, b)
+    # the host form draws a call key too (call 3), stream 0
+    h = gen.generate(np.zeros(B, dtype=np.int64))
+    assert np.array_equal(h[:T], want(coracle.drbg_call_key(master, 3), 0)[0])
+    # production handle (OS-entropy master key): identical arguments, different randomness
+    prod = crypto.ShareGenerator(sch)
+    assert not np.array_equal(draws(prod, 0), draws(prod, 0))
+    with pytest.raises(capi.SdaError) as e:
+        prod.set_drbg_rounds(8)
+    assert e.value.code == capi.ERR_STATE
+    # deterministic mode: the caller's ids select the streams (and DO repeat)
+    det = crypto.ShareGenerator(sch)
+    det.set_drbg_key(master)
+    assert np.array_equal(draws(det, 5), draws(det, 5))
+    assert np.array_equal(draws(det, 5), want(master, 5))
+    # 56-bit stream ids
+    for first in (1 << 56, (1 << 56) - 1, (1 << 64) - 1):
+        with pytest.raises(capi.SdaError) as e:
+            draws(det, first)
+        assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    draws(det, (1 << 56) - P)                                        # the last admissible ids
+    # the masker obeys the same contract
+    mk = crypto.SecretMasker(crypto.Full(m))
+    mk.set_drbg_master_key(master)
+    m1, _ = mk.mask(np.zeros(B, dtype=np.int64))
+    m2, _ = mk.mask(np.zeros(B, dtype=np.int64))
+    assert np.array_equal(m1, coracle.drbg_fill(coracle.drbg_call_key(master, 0), 0, B, 1, m))
+    assert np.array_equal(m2, coracle.drbg_fill(coracle.drbg_call_key(master, 1), 0, B, 1, m))
+    with pytest.raises(ValueError):
+        mk.set_drbg_key(b"short")
 
 
 def test_packed_generate_drbg_vs_oracle(gpu):
@@ -501,9 +559,31 @@ def test_scheme_validation(gpu):
     for bad in (crypto.Additive(3, 1), crypto.Additive(0, 433), crypto.Additive(3, 1 << 62),
                 crypto.PackedShamir(3, 8, 4, 435, 354, 150),           # composite modulus
                 crypto.PackedShamir(3, 8, 4, 433, 1, 150),             # omega_secrets of order 1: nodes collide
-                crypto.PackedShamir(0, 8, 4, 433, 354, 150)):
+                crypto.PackedShamir(0, 8, 4, 433, 354, 150),
+                # the descriptor is network-supplied: u64 wrap-arounds must not pass
+                crypto.PackedShamir((1 << 64) - 1, 8, 2, 433, 354, 150),   # k + t wraps to 1
+                crypto.PackedShamir(3, 8, (1 << 64) - 2, 433, 354, 150),   # k + t wraps to 1
+                crypto.PackedShamir(3, 1 << 32, 4, 433, 354, 150),         # share_count would truncate to 0
+                crypto.PackedShamir(5, 8, 4, 433, 354, 150)):              # share_count < t + k: never reconstructible
         with pytest.raises(capi.SdaError):
             crypto.ShareGenerator(bad)
+        if isinstance(bad, crypto.PackedShamir):
+            with pytest.raises(capi.SdaError):
+                crypto.SecretReconstructor(bad, 10)
+    with pytest.raises(capi.SdaError):
+        crypto.SecretReconstructor(crypto.Additive(0, 433), 10)
+    with pytest.raises(capi.SdaError):
+        crypto.SecretReconstructor(crypto.Additive(1 << 40, 433), 10)
+    crypto.ShareGenerator(crypto.PackedShamir(3, 8, 0, 433, 354, 150))     # t = 0 is accepted (documented)
+    # host finish on a multi-job combiner is refused instead of overrunning its buffer
+    comb = crypto.ShareCombiner(crypto.Additive(3, 433))
+    comb.begin_dev(2, 8)
+    out = np.zeros(16, dtype=np.int64)
+    assert capi.load().sda_share_combiner_finish(comb._h, out.ctypes.data_as(capi.c_i64p)) == capi.ERR_STATE
+    comb.begin(8)
+    with pytest.raises(ValueError):
+        comb.finish(4)
+    assert comb.finish().shape == (8,)
 
 
 # ---- BASELINE-size property tests (size-independent invariants; data stays in HBM) ------------------------
