@@ -6,13 +6,15 @@ One "step" = one pass of the hot path over one tile of synthetic participants re
   per-clerk modular sum             ->  exact 128-bit accumulators [n][B]
 An *element* is one (participant, vector component) pair, so a step processes P_tile * dim elements.
 Default workload = BASELINE config 3 (configs[2]): packed Shamir t=1, k=3, n=8, dim 1,048,576, 62-bit
-prime, 100k participants = 50 steps of a 2000-participant tile (the configuration the north-star
-target is quoted on).  `--workload additive` = config 2 (configs[1]); at N=1 a short run of it is
+prime, 100k participants (the configuration the north-star target is quoted on).  The K timed steps
+cover ALL of them: a step = 100000 / K participants, issued as resident sub-tiles of <= 2500
+(50 steps x 2000; 20 steps x 2 x 2500); `config.workload` is derived from what was processed.  `--workload additive` = config 2 (configs[1]); at N=1 a short run of it is
 attached to the JSON line as `additional_workloads`.
 
 N > 1: one process per GPU (torchrun), participants sharded across ranks (weak scaling: the per-GPU
-tile is fixed), no collective on the data path, ONE modular reduce of the partial clerk sums over
-RCCL at the end of the timed region (sda_amd/distributed.py).
+work is fixed), no collective on the data path, ONE modular reduce of the partial clerk sums over
+RCCL at the end of the timed region - the library's own code behind the C ABI
+(sda_modular_allreduce_dev; torch.distributed only launches the ranks and carries the RCCL id).
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte accounting.
 """
@@ -47,7 +49,30 @@ WORKLOADS = {
                         desc="tss-valid shape t=3 k=4 n=8 through the run-time (k, t) dual-role kernel, dim 1048576"),
     "additive": dict(kind="additive", n=3, k=1, t=2, o2=8, o3=9, participants=10_000,
                      desc="BASELINE config 2: additive 3-way, dim 1048576, 62-bit modulus, 10k participants"),
+    # config 5 on ONE GPU: its 100k participants are spread over 8 GPUs (12.5k each); the dimension is what differs, and
+    # the reveal over 16 Mi secrets is part of it.  --dim defaults to 16777216 for this workload.
+    "packed_dim16m": dict(kind="packed", n=8, k=3, t=1, o2=8, o3=9, participants=12_500, dim=1 << 24, tile_max=125,
+                          desc="BASELINE config 5 per-GPU share: packed Shamir t=1 k=3 n=8, dim 16777216, 62-bit prime, Lagrange reveal"),
 }
+TILE_MAX = 2500      # participants resident per launch (secrets 21 GB + two share buffers of 56 GB at config 3)
+
+
+def plan_steps(target_participants, steps, tile_max):
+    """A step = one pass of the hot path over one batch of participants.  The batch is target / steps participants
+    (rounded up), issued as n_sub resident sub-tiles of p_sub <= tile_max participants each."""
+    per_step = max(1, -(-target_participants // steps))
+    n_sub = -(-per_step // tile_max)
+    p_sub = -(-per_step // n_sub)
+    return n_sub, p_sub
+
+
+def describe(w, dim, participants_total, world):
+    """the label is DERIVED from what the run processes, never a constant"""
+    if w["kind"] == "packed":
+        shape = f"packed Shamir t={w['t']} k={w['k']} n={w['n']}"
+    else:
+        shape = f"additive {w['n']}-way"
+    return f"{shape}, dim {dim}, 62-bit prime modulus, {participants_total} participants ({participants_total // world} per GPU)"
 
 
 def algorithmic_bytes_per_element(n, k):
@@ -71,6 +96,10 @@ def cpu_baseline(w, dim, budget_s=15.0):
     res = {"value": done / dt, "unit": "elements/s", "cores": 1, "kind": "port",
            "sample": f"{parts} participants x dim {dim} (share-gen incl. buffered ChaCha20 draws + clerk-sum), "
                      f"oracle/sda_oracle.c single thread, {dt:.1f} s",
+           "port_notes": "scalar port of the reference's loops in the MATRIX form of packed Shamir (one n x (k+t) "
+                         "modular mat-vec per batch, no per-batch allocation) with BUFFERED ChaCha20 draws - both are "
+                         "concessions in the reference's favour: tss 0.2 runs two recursive FFTs with a Vec per level "
+                         "and the reference makes one OsRng call per draw",
            "host_cpus": os.cpu_count()}
     # the same port over participants on many host cores (the reference itself has no threading);
     # each thread owns a participant range and its own clerk sums - the final n x B modular merge is negligible
@@ -78,7 +107,7 @@ def cpu_baseline(w, dim, budget_s=15.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 64))
+    threads = max(1, avail)                              # ALL host cores (SURVEY.md 8d ii)
     if threads > 1:
         from concurrent.futures import ThreadPoolExecutor
         per = max(1, int(parts * 0.25))
@@ -92,7 +121,11 @@ def cpu_baseline(w, dim, budget_s=15.0):
 
 
 class Env:
-    """process-wide state: device, distributed group, library"""
+    """process-wide state: device, ranks, library, communicator.
+
+    torch.distributed is used ONLY to launch ranks and as a side channel (gloo: the 128-byte RCCL id, barriers, the
+    max-over-ranks of the timing); the data-path reduce is the library's own RCCL code behind the C ABI
+    (sda_comm_init / sda_modular_allreduce_dev)."""
 
     def __init__(self):
         import torch
@@ -102,23 +135,40 @@ class Env:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        # SDA_DIST_BACKEND=gloo + SDA_SHARE_GPU=1: a rehearsal of the N > 1 path on a ONE-GPU box - every rank runs its
-        # kernels on device 0 and the exchange is staged through host memory (sda_amd.distributed does that for gloo)
-        self.backend = os.environ.get("SDA_DIST_BACKEND", "nccl")
-        device_index = 0 if os.environ.get("SDA_SHARE_GPU") == "1" else self.local_rank
+        # SDA_SHARE_GPU=1: a rehearsal of the N > 1 path on a ONE-GPU box - every rank runs its kernels on device 0.
+        # RCCL refuses two ranks on one device, so there the exchange is staged through host memory over gloo
+        # (sda_amd.distributed); the modular sum of the slices still runs on the device.
+        self.share_gpu = os.environ.get("SDA_SHARE_GPU") == "1"
+        device_index = 0 if self.share_gpu else self.local_rank
         torch.cuda.set_device(device_index)
         self.dev = torch.device("cuda", device_index)
         self.use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
-            else:
-                dist.init_process_group(self.backend)
-        self.ctl_dev = self.dev if self.backend == "nccl" else torch.device("cpu")   # where the tiny control tensors live
+            dist.init_process_group("gloo")                                      # control plane only
         self.lib = capi.load()
         capi.check(self.lib.sda_set_device(device_index))
+        self.comm = C.c_void_p()
+        if not self.share_gpu:
+            ident = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                capi.check(self.lib.sda_comm_unique_id(ident))
+            box = [bytes(ident)]
+            if self.use_dist:
+                dist.broadcast_object_list(box, src=0)
+            capi.check(self.lib.sda_comm_init((C.c_uint8 * 128)(*box[0]), self.rank, self.world, C.byref(self.comm)))
+
+    def modular_allreduce(self, t):
+        """sum over ranks mod P62 of the int64 device tensor `t`, on every rank (new tensor)"""
+        torch = self.torch
+        if self.share_gpu and self.use_dist:
+            from sda_amd.distributed import modular_allreduce
+            return modular_allreduce(t, P62)
+        out = torch.empty_like(t)
+        self.capi.check(self.lib.sda_modular_allreduce_dev(self.comm, P62, t.data_ptr(), t.numel(), out.data_ptr(),
+                                                           torch.cuda.current_stream(self.dev).cuda_stream or None))
+        return out
 
     def barrier(self):
         self.torch.cuda.synchronize(self.dev)
@@ -126,23 +176,126 @@ class Env:
             self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
+    def max_over_ranks(self, x: float) -> float:
+        if not self.use_dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-def measure_fused(env, name, dim, P, steps, warmup, row_align=16, verify=True):
-    """Software-pipelined schedule: ONE dual-role launch per step generates tile i while the clerk sums of
-    tile i-1 are accumulated (sda_share_generator_generate_combine_dev); K + 1 launches cover K tiles."""
-    torch, dist, capi, lib, dev = env.torch, env.dist, env.capi, env.lib, env.dev
+    def close(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.use_dist:
+            self.dist.barrier()
+        if self.comm:
+            self.lib.sda_comm_free(self.comm)
+        if self.use_dist:
+            self.dist.destroy_process_group()
+
+
+def _setup(env, name, dim, P, row_align, rounds):
     from sda_amd import crypto
-    from sda_amd.distributed import modular_allreduce
-    rank, world = env.rank, env.world
     w = WORKLOADS[name]
     n, k, t = w["n"], w["k"], w["t"]
     scheme = (crypto.PackedShamir(k, n, t, P62, OMEGA[w["o2"]], OMEGA[w["o3"]]) if w["kind"] == "packed"
               else crypto.Additive(n, P62))
     B = (dim + k - 1) // k
-    Bs = (B + row_align - 1) // row_align * row_align
+    Bs = (B + row_align - 1) // row_align * row_align      # 128-byte aligned rows (row_align = 16 elements)
     gen = crypto.ShareGenerator(scheme)
-    gen.set_drbg_key(KEY)
+    gen.set_drbg_key(KEY)                                   # deterministic mode: reproducible run, verified below
+    if rounds != 20:
+        gen.set_drbg_rounds(rounds)
     comb = crypto.ShareCombiner(scheme)
+    return w, n, k, t, scheme, B, Bs, gen, comb
+
+
+def _verify(env, scheme, secrets, total, P, dim, B, tiles):
+    """size-independent check of the full result: reconstruct(clerk sums) == tiles * world * (column sums of the
+    resident tile) mod p - every sub-tile re-shares the same resident secrets with fresh randomness.  Also times the
+    reveal (Lagrange reconstruction over `dim` secrets, receive.rs:140-152) with HIP events."""
+    import ctypes as C
+    torch, capi, lib, dev = env.torch, env.capi, env.lib, env.dev
+    from sda_amd import crypto
+    rec = crypto.SecretReconstructor(scheme, dim)
+    out = torch.empty(dim, dtype=torch.int64, device=dev)
+    idx = list(range(scheme.reconstruction_threshold()))
+    rows = total[:len(idx)].contiguous()
+    rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim)      # builds the Lagrange matrix once
+    torch.cuda.synchronize(dev)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    capi.check(lib.sda_event_create(C.byref(e0))); capi.check(lib.sda_event_create(C.byref(e1)))
+    reps = 5
+    capi.check(lib.sda_event_record(e0, None))
+    for _ in range(reps):
+        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim)
+    capi.check(lib.sda_event_record(e1, None))
+    ms = C.c_float()
+    capi.check(lib.sda_event_elapsed_ms(e0, e1, C.byref(ms)))
+    lib.sda_event_destroy(e0); lib.sda_event_destroy(e1)
+    reveal_ms = ms.value / reps
+    cs = crypto.ShareCombiner(crypto.Additive(2, P62))   # expected: column sums of the secrets tile, `tiles` times
+    cs.begin_dev(1, dim)
+    for _ in range(tiles):
+        cs.update_dev(secrets.data_ptr(), 0, P, dim)
+    exp = torch.empty(dim, dtype=torch.int64, device=dev)
+    cs.finish_dev(exp.data_ptr())
+    exp_total = env.modular_allreduce(exp)
+    torch.cuda.synchronize(dev)
+    verified = bool(torch.equal(out, exp_total))
+    nrows = len(idx)
+    reveal = {"ms": reveal_ms, "secrets_per_s": dim / (reveal_ms * 1e-3), "dim": dim, "clerk_rows": nrows,
+              "algorithmic_bytes": 8 * (nrows * B + dim),
+              "GBps": 8 * (nrows * B + dim) / (reveal_ms * 1e-3) / 1e9,
+              "note": "Lagrange reconstruction of the dim secrets from t+k clerk sums (receive.rs:140-152): average of 5 "
+                      "reconstruct_dev calls between HIP events, outside the timed region"}
+    return verified, reveal
+
+
+def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, schedule):
+    world = env.world
+    participants_total = world * steps * n_sub * P
+    elements = float(participants_total) * dim
+    value = elements / dt
+    gen_b, comb_b = algorithmic_bytes_per_element(n, k)
+    return {
+        "metric": "share-gen + clerk-sum elements/sec (mod q)", "value": value, "unit": "elements/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": describe(w, dim, participants_total, world), "baseline_config": w["desc"], "name": name,
+                   "dim": dim, "participants_total": participants_total, "participants_per_step_per_gpu": n_sub * P,
+                   "sub_tiles_per_step": n_sub, "tile_participants": P,
+                   "share_count": n, "secret_count": k, "privacy_threshold": t, "modulus": P62,
+                   "randomness": f"on-device ChaCha{rounds} (sda-drbg-v1, deterministic bench key)",
+                   "row_stride_elements": Bs, "schedule": schedule,
+                   "parallelism": f"participants sharded x{world}, one modular reduce (RCCL all-to-all + exact modular "
+                                  f"sum + all-gather, behind the C ABI) at the end"},
+        "path_roofline": {"bytes_per_element": gen_b + comb_b,
+                          "achieved_GBps": value / world * (gen_b + comb_b) / 1e9,
+                          "frac_of_hbm_peak": value / world * (gen_b + comb_b) / 1e9 / HBM_PEAK_GBS},
+    }
+
+
+def _traffic(name, P, dim, key):
+    """PMC HBM bytes per launch (profiles/traffic.json, measured at some tile size; bytes scale with the tile)"""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tr = json.load(open(tpath))
+    except Exception:
+        return None
+    for kk, v in tr.items():
+        parts = kk.split(":")
+        if len(parts) == 3 and parts[0] == name and parts[2] == f"dim{dim}" and key in v:
+            return v[key] * P / int(parts[1][4:])
+    return None
+
+
+def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=True, rounds=20):
+    """Software-pipelined schedule: ONE dual-role launch per sub-tile generates sub-tile i while the clerk sums of
+    sub-tile i-1 are accumulated (sda_share_generator_generate_combine_dev); K tiles take K + 1 launches.
+    A step = n_sub sub-tiles of P participants."""
+    torch, capi, lib, dev = env.torch, env.capi, env.lib, env.dev
+    rank, world = env.rank, env.world
+    w, n, k, t, scheme, B, Bs, gen, comb = _setup(env, name, dim, P, row_align, rounds)
     secrets = torch.empty((P, dim), dtype=torch.int64, device=dev)
     shares = [torch.empty((n, P, Bs), dtype=torch.int64, device=dev) for _ in range(2)]
     capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, rank * P, SEED, P62, None))
@@ -159,132 +312,68 @@ def measure_fused(env, name, dim, P, steps, warmup, row_align=16, verify=True):
         if ev:
             capi.check(lib.sda_event_record(ev[1], None))
 
+    wtiles = warmup * n_sub
     comb.begin_dev(n, B)
-    for i in range(warmup + 1):
-        launch(i, warmup)
+    for i in range(wtiles + 1):
+        launch(i, wtiles)
     torch.cuda.synchronize(dev)
     comb.begin_dev(n, B)                                     # discard the warm-up contributions
+    tiles = steps * n_sub
     evs = []
-    for _ in range(2 * (steps + 1)):
+    for _ in range(2 * (tiles + 1)):
         e = C.c_void_p()
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
     sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
-    if env.use_dist:
-        modular_allreduce(sums, P62)
-        tw = torch.zeros(1, dtype=torch.float64, device=env.ctl_dev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    env.modular_allreduce(sums)                              # connect RCCL outside the timed region, real message size
     env.barrier()
     t0 = time.perf_counter()
-    for i in range(steps + 1):
-        launch(i, steps, evs[2 * i:2 * i + 2])
+    for i in range(tiles + 1):
+        launch(i, tiles, evs[2 * i:2 * i + 2])
     comb.finish_dev(sums.data_ptr())
-    total = modular_allreduce(sums, P62) if env.use_dist else sums
+    total = env.modular_allreduce(sums)                      # X1: the only exchange step
     env.barrier()
-    dt = time.perf_counter() - t0
-    if env.use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=env.ctl_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = env.max_over_ranks(time.perf_counter() - t0)
     ms = C.c_float()
     launch_ms = []
-    for i in range(steps + 1):
+    for i in range(tiles + 1):
         capi.check(lib.sda_event_elapsed_ms(evs[2 * i], evs[2 * i + 1], C.byref(ms)))
         launch_ms.append(ms.value)
     all_ms = sum(launch_ms) / len(launch_ms)                 # what rocprofv3 --stats averages (K+1 launches)
-    full = launch_ms[1:steps]                                # launches that carry both roles
-    full_ms = sum(full) / len(full) if full else None        # needs >= 2 steps
+    full = launch_ms[1:tiles]                                # launches that carry both roles
+    full_ms = sum(full) / len(full) if full else None        # needs >= 2 tiles
     for e in evs:
         lib.sda_event_destroy(e)
-    verified, reveal_ms = None, None
-    if verify:
-        rec = crypto.SecretReconstructor(scheme, dim)
-        out = torch.empty(dim, dtype=torch.int64, device=dev)
-        idx = list(range(scheme.reconstruction_threshold()))
-        rows = total[:len(idx)].contiguous()
-        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim)      # builds the Lagrange matrix once
-        torch.cuda.synchronize(dev)
-        t_rev = time.perf_counter()
-        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim)
-        torch.cuda.synchronize(dev)
-        reveal_ms = (time.perf_counter() - t_rev) * 1e3
-        cs = crypto.ShareCombiner(crypto.Additive(2, P62))
-        cs.begin_dev(1, dim)
-        for _ in range(steps):
-            cs.update_dev(secrets.data_ptr(), 0, P, dim)
-        exp = torch.empty(dim, dtype=torch.int64, device=dev)
-        cs.finish_dev(exp.data_ptr())
-        exp_total = modular_allreduce(exp, P62) if env.use_dist else exp
-        torch.cuda.synchronize(dev)
-        verified = bool(torch.equal(out, exp_total))
-    elements = float(world) * steps * P * dim
-    value = elements / dt
+    verified, reveal = _verify(env, scheme, secrets, total, P, dim, B, tiles) if verify else (None, None)
     gen_b, comb_b = algorithmic_bytes_per_element(n, k)
     per_launch_bytes = P * dim * (gen_b + comb_b)
-    gbs = steps * per_launch_bytes / (sum(launch_ms) * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f"{name}:tile{P}:dim{dim}", {}).get("fused_bytes_per_launch")
-        except Exception:
-            traffic = None
+    gbs = tiles * per_launch_bytes / (sum(launch_ms) * 1e-3) / 1e9
     kern = "fused_packed_l31_kernel" if w["kind"] == "packed" else "fused_additive_kernel"
-    res = {
-        "metric": "share-gen + clerk-sum elements/sec (mod q)", "value": value, "unit": "elements/s",
-        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": w["desc"], "name": name, "dim": dim, "tile_participants": P,
-                   "participants_total": world * steps * P, "share_count": n, "secret_count": k,
-                   "privacy_threshold": t, "modulus": P62, "randomness": f"on-device ChaCha{os.environ.get('SDA_DRBG_ROUNDS', '20')} (sda-drbg-v1)",
-                   "row_stride_elements": Bs,
-                   "schedule": "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid "
-                               "(shares materialised in HBM by one launch, read back by the next); K+1 launches for K tiles",
-                   "parallelism": f"participants sharded x{world}, one modular reduce at the end"},
-        "roofline": {"bound": "hbm", "kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": all_ms,
-                     "launches": steps + 1, "both_roles_launch_ms": full_ms,
-                     "first_launch_ms_share_gen_only": launch_ms[0], "last_launch_ms_clerk_sum_only": launch_ms[-1],
-                     "note": "one launch = share-gen of a tile (8 + 8n/k B/element) + clerk-sum of the previous tile "
-                             "(8n/k B/element); K tiles take K+1 launches (the first only generates, the last only "
-                             "sums), achieved = K x algorithmic_bytes_per_launch / sum of the K+1 launch durations"},
-        "path_roofline": {"bytes_per_element": gen_b + comb_b,
-                          "achieved_GBps": value / world * (gen_b + comb_b) / 1e9,
-                          "frac_of_hbm_peak": value / world * (gen_b + comb_b) / 1e9 / HBM_PEAK_GBS},
-        "verified_reconstruct_equals_sum": verified,
-        "reveal": None if reveal_ms is None else {
-            "ms": reveal_ms, "secrets_per_s": dim / (reveal_ms * 1e-3),
-            "note": "Lagrange reconstruction of the dim secrets from t+k clerk sums (receive.rs:140-152), host-timed "
-                    "around one reconstruct_dev call, outside the timed region"},
-    }
+    res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
+                "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid (shares "
+                "materialised in HBM by one launch, read back by the next); K+1 launches for K tiles")
+    res["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic(name, P, dim, "fused_bytes_per_launch"),
+                       "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": all_ms,
+                       "launches": tiles + 1, "both_roles_launch_ms": full_ms,
+                       "first_launch_ms_share_gen_only": launch_ms[0], "last_launch_ms_clerk_sum_only": launch_ms[-1],
+                       "note": "one launch = share-gen of a tile (8 + 8n/k B/element) + clerk-sum of the previous tile "
+                               "(8n/k B/element); K tiles take K+1 launches (the first only generates, the last only "
+                               "sums), achieved = K x algorithmic_bytes_per_launch / sum of the K+1 launch durations"}
+    res["verified_reconstruct_equals_sum"] = verified
+    res["reveal"] = reveal
     del secrets, shares, sums, total
     torch.cuda.empty_cache()
     return res
 
 
-def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=True):
-    """K timed steps of workload `name`; returns the metric dict (valid on every rank)."""
-    torch, dist, capi, lib, dev = env.torch, env.dist, env.capi, env.lib, env.dev
-    from sda_amd import crypto
-    from sda_amd.distributed import modular_allreduce
+def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, verify=True, rounds=20):
+    """serial schedule: share-gen launch then clerk-sum launch per sub-tile (clean per-kernel timings)"""
+    torch, capi, lib, dev = env.torch, env.capi, env.lib, env.dev
     rank, world = env.rank, env.world
-    w = WORKLOADS[name]
-    n, k, t = w["n"], w["k"], w["t"]
-    if w["kind"] == "packed":
-        scheme = crypto.PackedShamir(k, n, t, P62, OMEGA[w["o2"]], OMEGA[w["o3"]])
-    else:
-        scheme = crypto.Additive(n, P62)
-    B = (dim + k - 1) // k
-    Bs = (B + row_align - 1) // row_align * row_align      # 128-byte aligned rows (row_align = 16 elements)
-
-    gen = crypto.ShareGenerator(scheme)
-    gen.set_drbg_key(KEY)
-    comb = crypto.ShareCombiner(scheme)
+    w, n, k, t, scheme, B, Bs, gen, comb = _setup(env, name, dim, P, row_align, rounds)
     if overlap:
         comb.set_residency(2)            # 8 waves per CU saturate HBM; the rest stay with share generation
-
-    # resident tile: secrets [P][dim], shares job-major [n][P][Bs]  (server snapshot layout, stores.rs:86-101)
     nbuf = 2 if overlap else 1
     secrets = torch.empty((P, dim), dtype=torch.int64, device=dev)
     shares = [torch.empty((n, P, Bs), dtype=torch.int64, device=dev) for _ in range(nbuf)]
@@ -300,11 +389,10 @@ def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=Tr
     comb_done = [torch.cuda.Event() for _ in range(nbuf)]
 
     def step(i, slot, evs=None):
-        """share-gen of tile i into shares[slot] on s_gen; clerk-sum of it on s_comb"""
-        first = (i * world + rank) * P                      # participant ids of this tile (CSPRNG stream ids)
+        first = (i * world + rank) * P
         buf = shares[slot]
         if overlap:
-            s_gen.wait_event(comb_done[slot])               # the previous reader of this buffer is done
+            s_gen.wait_event(comb_done[slot])
         if evs:
             capi.check(lib.sda_event_record(evs[0], h_gen))
         gen.generate_batch_dev(secrets.data_ptr(), P, dim, dim, buf.data_ptr(), Bs, P * Bs,
@@ -324,122 +412,61 @@ def measure(env, name, dim, P, steps, warmup, row_align=16, overlap=0, verify=Tr
 
     for e in comb_done:
         e.record(s_comb)
-    for i in range(warmup):
-        step(-1 - i, i % nbuf)
+    tiles = steps * n_sub
+    for i in range(warmup * n_sub):
+        step(tiles + i, i % nbuf)
     torch.cuda.synchronize(dev)
-    comb.begin_dev(n, B, h_comb or 0)                       # discard the warm-up contributions
+    comb.begin_dev(n, B, h_comb or 0)
     for e in comb_done:
         e.record(s_comb)
-
-    # per-kernel HIP events on the streams the kernels are launched on (4 per step)
     evs = []
-    for _ in range(4 * steps):
+    for _ in range(4 * tiles):
         e = C.c_void_p()
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
-
     sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
-    if env.use_dist:
-        # RCCL connects lazily on the first collective of each kind: do that outside the timed region,
-        # with the real message sizes
-        with torch.cuda.stream(s_comb):
-            modular_allreduce(sums, P62)
-        tw = torch.zeros(1, dtype=torch.float64, device=env.ctl_dev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    env.modular_allreduce(sums)
     env.barrier()
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(tiles):
         step(i, i % nbuf, evs[4 * i:4 * i + 4])
     comb.finish_dev(sums.data_ptr(), h_comb or 0)
-    with torch.cuda.stream(s_comb):
-        total = modular_allreduce(sums, P62) if env.use_dist else sums     # X1: the only exchange step
+    torch.cuda.synchronize(dev)
+    total = env.modular_allreduce(sums)
     env.barrier()
-    dt = time.perf_counter() - t0
-    if env.use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=env.ctl_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
+    dt = env.max_over_ranks(time.perf_counter() - t0)
     gen_ms = comb_ms = 0.0
     ms = C.c_float()
-    for i in range(steps):
+    for i in range(tiles):
         capi.check(lib.sda_event_elapsed_ms(evs[4 * i], evs[4 * i + 1], C.byref(ms))); gen_ms += ms.value
         capi.check(lib.sda_event_elapsed_ms(evs[4 * i + 2], evs[4 * i + 3], C.byref(ms))); comb_ms += ms.value
-    gen_ms /= steps
-    comb_ms /= steps
+    gen_ms /= tiles
+    comb_ms /= tiles
     for e in evs:
         lib.sda_event_destroy(e)
-
-    # size-independent check of the full result: reconstruct(clerk sums) == K * world * (sum of the tile's
-    # secrets) mod p -- every step re-shares the same resident tile with fresh randomness
-    verified, reveal_ms = None, None
-    if verify:
-        rec = crypto.SecretReconstructor(scheme, dim)
-        out = torch.empty(dim, dtype=torch.int64, device=dev)
-        idx = list(range(scheme.reconstruction_threshold()))
-        rows = total[:len(idx)].contiguous()
-        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim)      # builds the Lagrange matrix once
-        torch.cuda.synchronize(dev)
-        t_rev = time.perf_counter()
-        rec.reconstruct_dev(idx, rows.data_ptr(), B, B, out.data_ptr(), dim)
-        torch.cuda.synchronize(dev)
-        reveal_ms = (time.perf_counter() - t_rev) * 1e3
-        cs = crypto.ShareCombiner(crypto.Additive(2, P62))   # expected: column sums of the secrets tile, K times
-        cs.begin_dev(1, dim)
-        for _ in range(steps):
-            cs.update_dev(secrets.data_ptr(), 0, P, dim)
-        exp = torch.empty(dim, dtype=torch.int64, device=dev)
-        cs.finish_dev(exp.data_ptr())
-        exp_total = modular_allreduce(exp, P62) if env.use_dist else exp
-        torch.cuda.synchronize(dev)
-        verified = bool(torch.equal(out, exp_total))
-
-    elements = float(world) * steps * P * dim
-    value = elements / dt
+    verified, reveal = _verify(env, scheme, secrets, total, P, dim, B, tiles) if verify else (None, None)
     gen_b, comb_b = algorithmic_bytes_per_element(n, k)
     per_launch = P * dim
     gen_gbs = per_launch * gen_b / (gen_ms * 1e-3) / 1e9
     comb_gbs = per_launch * comb_b / (comb_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
     dominant_gen = gen_ms >= comb_ms
-    if os.path.exists(tpath):
-        try:
-            tr = json.load(open(tpath)).get(f"{name}:tile{P}:dim{dim}", {})
-            traffic = tr.get("gen_bytes_per_launch" if dominant_gen else "comb_bytes_per_launch")
-        except Exception:
-            traffic = None
     gen_kernel = ("packed_gen_l31_kernel" if w["kind"] == "packed" else "additive_gen_kernel")
-    res = {
-        "metric": "share-gen + clerk-sum elements/sec (mod q)", "value": value, "unit": "elements/s",
-        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": w["desc"], "name": name, "dim": dim, "tile_participants": P,
-                   "participants_total": world * steps * P, "share_count": n, "secret_count": k,
-                   "privacy_threshold": t, "modulus": P62, "randomness": f"on-device ChaCha{os.environ.get('SDA_DRBG_ROUNDS', '20')} (sda-drbg-v1)",
-                   "row_stride_elements": Bs,
-                   "schedule": ("share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares"
-                                if overlap else "one stream, serial"),
-                   "parallelism": f"participants sharded x{world}, one modular reduce at the end"},
-        "roofline": {"bound": "hbm", "kernel": gen_kernel if dominant_gen else "combine_update_kernel",
-                     "achieved": gen_gbs if dominant_gen else comb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (gen_gbs if dominant_gen else comb_gbs) / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": per_launch * (gen_b if dominant_gen else comb_b),
-                     "avg_launch_ms": gen_ms if dominant_gen else comb_ms,
-                     "note": "the share-gen kernel is VALU-bound as measured (SQ PMC: VALU active 94 %), see DESIGN.md"},
-        "kernels": {"share_gen": {"avg_ms": gen_ms, "bytes_per_element": gen_b, "GBps": gen_gbs,
-                                  "frac_of_hbm_peak": gen_gbs / HBM_PEAK_GBS},
-                    "clerk_sum": {"avg_ms": comb_ms, "bytes_per_element": comb_b, "GBps": comb_gbs,
-                                  "frac_of_hbm_peak": comb_gbs / HBM_PEAK_GBS}},
-        "path_roofline": {"bytes_per_element": gen_b + comb_b,
-                          "achieved_GBps": value / world * (gen_b + comb_b) / 1e9,
-                          "frac_of_hbm_peak": value / world * (gen_b + comb_b) / 1e9 / HBM_PEAK_GBS},
-        "verified_reconstruct_equals_sum": verified,
-        "reveal": None if reveal_ms is None else {
-            "ms": reveal_ms, "secrets_per_s": dim / (reveal_ms * 1e-3),
-            "note": "Lagrange reconstruction of the dim secrets from t+k clerk sums (receive.rs:140-152), host-timed "
-                    "around one reconstruct_dev call, outside the timed region"},
-    }
+    res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
+                "share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares" if overlap
+                else "one stream, serial")
+    res["roofline"] = {"bound": "hbm", "kernel": gen_kernel if dominant_gen else "combine_update_kernel",
+                       "achieved": gen_gbs if dominant_gen else comb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": (gen_gbs if dominant_gen else comb_gbs) / HBM_PEAK_GBS,
+                       "traffic": _traffic(name, P, dim, "gen_bytes_per_launch" if dominant_gen else "comb_bytes_per_launch"),
+                       "algorithmic_bytes_per_launch": per_launch * (gen_b if dominant_gen else comb_b),
+                       "avg_launch_ms": gen_ms if dominant_gen else comb_ms,
+                       "note": "the share-gen kernel is VALU-bound as measured (SQ PMC: VALU active 94 %), see DESIGN.md"}
+    res["kernels"] = {"share_gen": {"avg_ms": gen_ms, "bytes_per_element": gen_b, "GBps": gen_gbs,
+                                    "frac_of_hbm_peak": gen_gbs / HBM_PEAK_GBS},
+                      "clerk_sum": {"avg_ms": comb_ms, "bytes_per_element": comb_b, "GBps": comb_gbs,
+                                    "frac_of_hbm_peak": comb_gbs / HBM_PEAK_GBS}}
+    res["verified_reconstruct_equals_sum"] = verified
+    res["reveal"] = reveal
     del secrets, shares, sums, total
     torch.cuda.empty_cache()
     return res
@@ -451,18 +478,23 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="packed", choices=sorted(WORKLOADS))
-    ap.add_argument("--dim", type=int, default=1 << 20)
-    ap.add_argument("--tile", type=int, default=2000, help="participants per step and per GPU")
+    ap.add_argument("--dim", type=int, default=0, help="vector dimension (default: the workload's, 1048576 unless stated)")
+    ap.add_argument("--participants", type=int, default=0,
+                    help="participants per GPU over the whole run (default: the BASELINE configuration's count); a step "
+                         "covers participants / steps of them, issued as resident sub-tiles of at most --tile")
+    ap.add_argument("--tile", type=int, default=0, help=f"largest resident sub-tile, participants (default {TILE_MAX})")
     ap.add_argument("--row-align", type=int, default=16, help="pad share rows to a multiple of this many elements")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: share-gen of tile i+1 runs concurrently with clerk-sum of tile i (two streams, "
                          "double-buffered shares, clerk-sum capped at 2 workgroups per CU); 0: one stream, serial")
     ap.add_argument("--schedule", default="fused", choices=["serial", "fused"],
                     help="serial: share-gen launch then clerk-sum launch per tile; fused: one dual-role launch per "
-                         "step (tile i generated while tile i-1 is summed)")
+                         "tile (tile i generated while tile i-1 is summed)")
+    ap.add_argument("--drbg-rounds", type=int, default=20, choices=[20, 12, 8],
+                    help="ChaCha rounds of the on-device CSPRNG (A/B only; the product runs ChaCha20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--no-additional", action="store_true", help="skip the short config-2 (additive) run")
+    ap.add_argument("--no-additional", action="store_true", help="skip the short config-2 and config-5 runs")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("--steps must be >= 1 and --warmup >= 0")
@@ -471,27 +503,35 @@ def main():
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     env = Env()
-    def run(name, steps, warmup):
-        if args.schedule == "fused" and not args.overlap:
-            return measure_fused(env, name, args.dim, args.tile, steps, warmup, args.row_align, verify=not args.no_verify)
-        return measure(env, name, args.dim, args.tile, steps, warmup, args.row_align, args.overlap, verify=not args.no_verify)
 
-    line = run(args.workload, args.steps, args.warmup)
+    def run(name, steps, warmup, participants=0, dim=0, tile=0):
+        w = WORKLOADS[name]
+        dim = dim or w.get("dim", 1 << 20)
+        n_sub, p_sub = plan_steps(participants or w["participants"], steps, tile or w.get("tile_max", TILE_MAX))
+        if args.schedule == "fused" and not args.overlap:
+            return measure_fused(env, name, dim, p_sub, n_sub, steps, warmup, args.row_align, verify=not args.no_verify,
+                                 rounds=args.drbg_rounds)
+        return measure(env, name, dim, p_sub, n_sub, steps, warmup, args.row_align, args.overlap, verify=not args.no_verify,
+                       rounds=args.drbg_rounds)
+
+    line = run(args.workload, args.steps, args.warmup, args.participants, args.dim, args.tile)
     if env.world == 1 and not args.no_additional and args.workload == "packed":
-        # BASELINE config 2 (additive 3-way, 10k participants = 5 steps of the 2000-participant tile)
+        keep = ("value", "unit", "steps", "ms_per_step", "config", "kernels", "roofline", "path_roofline",
+                "verified_reconstruct_equals_sum", "reveal")
+        # BASELINE config 2 (additive 3-way, 10k participants = 5 steps of 2000)
         add = run("additive", 5, 2)
-        line["additional_workloads"] = {"additive": {k: add[k] for k in ("value", "unit", "ms_per_step", "config", "kernels",
-                                                                          "roofline", "path_roofline",
-                                                                          "verified_reconstruct_equals_sum", "reveal") if k in add}}
+        # BASELINE config 5's shape on one GPU (dim 16,777,216; 4 steps of 125 participants) - carries the reveal time
+        # at that dimension
+        big = run("packed_dim16m", 4, 1, participants=500)
+        line["additional_workloads"] = {"additive": {k: add[k] for k in keep if k in add},
+                                        "packed_dim16m": {k: big[k] for k in keep if k in big}}
     if env.rank == 0:
         if not args.no_cpu_baseline and env.world == 1:
-            line["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.dim)
+            line["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.dim or WORKLOADS[args.workload].get("dim", 1 << 20))
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if env.use_dist:
-        env.dist.barrier()
-        env.dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":

@@ -429,13 +429,33 @@ int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_varint_codec_t
                                      size_t n_bytes);
 
 /* =============================================================================================
- * Cross-GPU modular reduction helper (new; no reference counterpart - SURVEY.md 8e).
- * d_parts holds `parts` vectors of `len` canonical residues (part g at d_parts + g*part_stride);
- * d_out[len] = sum over parts mod modulus.  Used after an all-to-all of per-GPU partial clerk sums
- * (a plain u64 ncclSum would wrap for 8 x 62-bit residues).
+ * Cross-GPU modular reduction (new; no reference counterpart - SURVEY.md 8e: the reference's parties meet over HTTP).
+ * Participants are sharded across the GPUs of a node, one process per GPU, no collective on the data path; the
+ * per-clerk partial sums meet ONCE at the end:
+ *     direct reduce-scatter over the xGMI mesh (ncclSend/ncclRecv of 1/G slices, every GPU pair on its own link)
+ *       -> exact modular sum of the G slices on the device -> direct all-gather of the reduced slices.
+ * Never a sum collective on u64: 8 residues of a 62-bit modulus exceed 2^64.
+ *
+ *   sda_comm_unique_id : rank 0 makes the 128-byte RCCL id; the host hands it to the other ranks (any side channel)
+ *   sda_comm_init      : collective over all ranks; binds the communicator to the calling thread's current device
+ *                        (sda_set_device).  RCCL is loaded on first use (dlopen) - SDA_ERR_COMM if it is missing.
+ *   sda_modular_allreduce_dev : d_partial[len] (any i64, this rank's partial sums) -> d_out[len] = sum over the ranks
+ *                        mod modulus, canonical, on EVERY rank; asynchronous on `stream`; d_out may alias d_partial
+ *                        only when world == 1.  len and modulus must agree on all ranks.
+ *   sda_modsum_parts_dev : the local step on its own: d_out[len] = sum over `parts` vectors (part g at
+ *                        d_parts + g*part_stride) mod modulus.
  * ============================================================================================= */
-int sda_modsum_parts_dev(int64_t modulus, const int64_t* d_parts, size_t parts, size_t part_stride,
-                         size_t len, int64_t* d_out, void* stream);
+typedef struct sda_comm sda_comm_t;
+#define SDA_COMM_ID_BYTES 128
+int  sda_comm_unique_id(uint8_t id[SDA_COMM_ID_BYTES]);
+int  sda_comm_init(const uint8_t id[SDA_COMM_ID_BYTES], int rank, int world, sda_comm_t** out);
+void sda_comm_free(sda_comm_t* c);
+int  sda_comm_rank(const sda_comm_t* c);
+int  sda_comm_world(const sda_comm_t* c);
+int  sda_modular_allreduce_dev(sda_comm_t* c, int64_t modulus, const int64_t* d_partial, size_t len, int64_t* d_out,
+                               void* stream);
+int  sda_modsum_parts_dev(int64_t modulus, const int64_t* d_parts, size_t parts, size_t part_stride,
+                          size_t len, int64_t* d_out, void* stream);
 
 /* Synthetic bench input: d_out[p*stride + i] = splitmix64(seed ^ ((first_participant+p) << 32 | i))
  * mod modulus.  Not on the product path. */

@@ -142,6 +142,12 @@ SIGNATURES = {
                                              C.c_size_t, C.c_void_p, C.c_void_p]),
     "sda_share_combiner_update_varint_rows_dev": (C.c_int, [_H, _H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                             C.c_void_p, C.c_void_p]),
+    "sda_comm_unique_id": (C.c_int, [c_u8p]),
+    "sda_comm_init": (C.c_int, [c_u8p, C.c_int, C.c_int, _HP]),
+    "sda_comm_free": (None, [_H]),
+    "sda_comm_rank": (C.c_int, [_H]),
+    "sda_comm_world": (C.c_int, [_H]),
+    "sda_modular_allreduce_dev": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "sda_modsum_parts_dev": (C.c_int, [C.c_int64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                        C.c_void_p]),
     "sda_fill_synthetic_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64,

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "capi_internal.hpp"
 #include "host_chacha.hpp"
 #include "host_math.hpp"
 #include "kernels.hpp"
@@ -57,6 +58,16 @@ static int fail(int code, const char* fmt, ...) {
         int _s = (expr);           \
         if (_s != SDA_OK) return _s; \
     } while (0)
+
+int capi_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
 
 extern "C" const char* sda_strerror(int status) {
     switch (status) {
@@ -172,6 +183,10 @@ int make_mod(int64_t modulus, ModParams& mod) {
     mod.lemire_thr = h_lemire_thr(mod.m);
     return SDA_OK;
 }
+
+}  // namespace
+int capi_make_mod(int64_t modulus, sda::ModParams& mod) { return make_mod(modulus, mod); }
+namespace {
 
 int os_entropy(void* buf, size_t len) {
     uint8_t* b = static_cast<uint8_t*>(buf);

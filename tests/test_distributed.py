@@ -107,3 +107,17 @@ def test_single_rank_requires_gpu_reducer():
     from sda_amd.distributed import modular_allreduce
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         modular_allreduce(torch.zeros(4, dtype=torch.int64), P62)
+
+
+@pytest.mark.parametrize("world,length", [(1, 10), (2, 7), (3, 20), (8, 1000), (8, 3), (5, 0), (8, 8), (4, 22369)])
+def test_comm_plan_multi_process_cpp(world, length, tmp_path):
+    """The C++ choreography the library runs over RCCL (sda_amd/csrc/comm_plan.hpp, driven by sda_comm.cpp), with an
+    injected socket transport between forked processes and a checker reducer: ragged / empty slices, worst-case
+    residues (a u64 sum collective would wrap), in-place gather."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "comm_plan_test.cpp")
+    exe = str(tmp_path / "comm_plan_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", src, "-o", exe])
+    out = subprocess.run([exe, str(world), str(length), str(P62)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "comm plan ok" in out.stdout

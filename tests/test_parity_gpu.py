@@ -646,6 +646,59 @@ def test_full_dimension_roundtrip(gpu, shape):
 
 
 # ---- host mirror in C++ (the reference's host language is compiled) and multi-GPU helper ---------------------
+def test_config5_dimension_16m_vs_oracle(gpu):
+    """BASELINE config 5's dimension (16,777,216; k=3, t=1, n=8; B = 5,592,406 batches) through the HIP path against the
+    oracle, bit for bit: every participant's shares (device CSPRNG streams reproduced by the oracle), the clerk sums,
+    and the Lagrange reveal over the full 16 Mi secrets from a non-trivial clerk subset
+    (batched.rs:18-53,68-97; combiner.rs:15-29; receive.rs:140-152)."""
+    from sda_amd import crypto
+    from sda_amd.capi import check
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    dim, k, t, n, P = 1 << 24, 3, 1, 8, 3
+    sch = crypto.PackedShamir(k, n, t, P62, W[8], W[9])
+    B = (dim + k - 1) // k
+    assert B == 5_592_406
+    Bs = (B + 15) // 16 * 16
+    d_sec = DeviceBuffer(P * dim)
+    check(gpu.sda_fill_synthetic_dev(d_sec.ptr, P, dim, dim, 40, 77, P62, None))
+    secrets = coracle.fill_synthetic(P, dim, 40, 77, P62)
+    assert np.array_equal(d_sec.to_numpy().reshape(P, dim), secrets)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    d_sh = DeviceBuffer(n * P * Bs).zero()
+    gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_sh.ptr, Bs, P * Bs, first_participant=1000)   # job-major [n][P][Bs]
+    got = d_sh.to_numpy().reshape(n, P, Bs)
+    want = [coracle.packed_generate(P62, k, t, n, W[8], W[9], secrets[p], coracle.drbg_fill(KEY, 1000 + p, B, t, P62))
+            for p in range(P)]
+    for p in range(P):
+        assert np.array_equal(got[:, p, :B], want[p]), f"participant {p}"
+    assert not got[:, :, B:].any()                                       # the row padding is never written
+    # clerk sums: separate launch and the dual-role launch (sum only), both vs the oracle's combine
+    comb = crypto.ShareCombiner(sch)
+    comb.begin_dev(n, B)
+    comb.update_dev(d_sh.ptr, P * Bs, P, Bs)
+    d_sums = DeviceBuffer(n * B)
+    comb.finish_dev(d_sums.ptr)
+    sums = d_sums.to_numpy().reshape(n, B)
+    for c in range(n):
+        assert np.array_equal(sums[c], coracle.combine(P62, np.stack([want[p][c] for p in range(P)]))), f"clerk {c}"
+    comb.begin_dev(n, B)
+    gen.generate_combine_dev(comb, 0, 0, dim, dim, 0, Bs, P * Bs, d_prev=d_sh.ptr, prev_participants=P)
+    d_sums2 = DeviceBuffer(n * B)
+    comb.finish_dev(d_sums2.ptr)
+    assert np.array_equal(d_sums2.to_numpy().reshape(n, B), sums)
+    # reveal over the full dimension from clerks {6, 1, 4, 3}
+    subset = [6, 1, 4, 3]
+    rows = DeviceBuffer.from_numpy(np.ascontiguousarray(sums[subset]))
+    d_out = DeviceBuffer(dim)
+    rec = crypto.SecretReconstructor(sch, dim)
+    assert rec.reconstruct_dev(subset, rows.ptr, B, B, d_out.ptr, dim) == dim
+    out = d_out.to_numpy()
+    assert np.array_equal(out, coracle.packed_reconstruct(P62, k, t, W[8], W[9], dim, subset, sums[subset]))
+    assert np.array_equal(out, coracle.combine(P62, secrets))           # == sum of the secrets mod p
+
+
 def test_cpp_host_mirror_full_loop(gpu):
     """tests/cpp/full_loop.cpp: the reference's full_loop.rs scenarios through sda_amd/host/sda_crypto.hpp,
     with OS randomness like the reference's own tests."""
@@ -680,6 +733,41 @@ def test_modsum_parts_dev(gpu):
     assert out.to_numpy()[0] == (8 * (P62 - 1)) % P62
 
 
+def test_comm_c_abi_single_rank_rccl(gpu, monkeypatch):
+    """sda_comm_* / sda_modular_allreduce_dev through ctypes with one rank: the no-exchange shortcut, and - with
+    SDA_FORCE_COLLECTIVES - the full RCCL path (grouped ncclSend/ncclRecv to itself, modular sum, gather) for ragged
+    lengths.  Inputs are any i64; outputs canonical."""
+    import ctypes as C
+    from sda_amd.capi import check
+    from sda_amd.device import DeviceBuffer
+    ident = (C.c_uint8 * 128)()
+    check(gpu.sda_comm_unique_id(ident))
+    comm = C.c_void_p()
+    check(gpu.sda_comm_init(ident, 0, 1, C.byref(comm)))
+    assert gpu.sda_comm_rank(comm) == 0 and gpu.sda_comm_world(comm) == 1
+    rng = np.random.default_rng(11)
+    try:
+        for force in (False, True):
+            if force:
+                monkeypatch.setenv("SDA_FORCE_COLLECTIVES", "1")
+            for n in (1, 7, 1000, 22369 * 8 + 3):
+                v = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
+                d, o = DeviceBuffer.from_numpy(v), DeviceBuffer(n)
+                check(gpu.sda_modular_allreduce_dev(comm, P62, d.ptr, n, o.ptr, None))
+                check(gpu.sda_dev_synchronize())
+                assert np.array_equal(o.to_numpy(), np.mod(v.astype(object), P62).astype(np.int64)), (force, n)
+        check(gpu.sda_modular_allreduce_dev(comm, P62, None, 0, None, None))           # empty vector: nothing to do
+        assert gpu.sda_modular_allreduce_dev(None, P62, None, 0, None, None) == capi_err()
+        assert gpu.sda_comm_init(ident, 1, 1, C.byref(C.c_void_p())) == capi_err()    # rank out of range
+    finally:
+        gpu.sda_comm_free(comm)
+
+
+def capi_err():
+    from sda_amd import capi
+    return capi.ERR_INVALID_ARGUMENT
+
+
 def test_any_i64_canonicalisation_property(gpu):
     """the boundary accepts ANY i64 (SURVEY.md 8b 'Value domain'): outputs equal python's x % q."""
     from sda_amd import crypto
@@ -703,9 +791,9 @@ def test_any_i64_canonicalisation_property(gpu):
 
 
 def test_bench_under_torchrun_single_rank_rccl(gpu):
-    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, backend nccl = RCCL),
-    with one rank and the collective path forced, so init / all_to_all / all_gather / all_reduce run on
-    real RCCL.  The result must verify (reconstruct == sum of secrets)."""
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run), with one rank and the exchange
+    forced through RCCL (the library's own communicator: ncclCommInitRank, grouped ncclSend/ncclRecv to itself, the
+    modular-sum kernel, the gather).  The result must verify (reconstruct == sum of secrets)."""
     import json
     import subprocess
     import sys
@@ -713,7 +801,7 @@ def test_bench_under_torchrun_single_rank_rccl(gpu):
     env = dict(os.environ, SDA_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
-           "--warmup", "1", "--tile", "64", "--dim", "65536", "--no-cpu-baseline"]
+           "--warmup", "1", "--participants", "128", "--dim", "65536", "--no-cpu-baseline", "--no-additional"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -973,7 +1061,8 @@ def test_device_entry_points_refuse_bad_arguments(gpu):
     assert gen.generate(secrets).shape == (8, 4)
 
 
-@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--schedule", "serial", "--workload", "additive"])])
+@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--schedule", "serial", "--workload", "additive"]),
+                                         (2, ["--workload", "packed26"])])          # config 4's shape (k=8, t=2, n=26)
 def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
     """bench.py's N > 1 path end to end - participant sharding, per-rank CSPRNG streams, the all-to-all / modular
     sum / all-gather exchange, max-over-ranks timing, and the cross-rank verification reconstruct(sum of every rank's
@@ -983,12 +1072,13 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SDA_DIST_BACKEND="gloo", SDA_SHARE_GPU="1")
+    env = dict(os.environ, SDA_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29540 + ranks), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
-           "--tile", "40", "--dim", "65536", "--no-additional", "--no-cpu-baseline"] + extra
+           "--master-port", str(29540 + ranks + 7 * len(extra)), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "3",
+           "--warmup", "1", "--participants", "120", "--dim", "65536", "--no-additional", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == ranks and line["verified_reconstruct_equals_sum"] is True
     assert line["config"]["participants_total"] == ranks * 3 * 40 and line["scaling"] == "weak"
+    assert f"{ranks * 120} participants" in line["config"]["workload"]                 # the label is what was processed
