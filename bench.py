@@ -110,7 +110,7 @@ def cpu_baseline(w, dim, budget_s=15.0):
     threads = max(1, avail)                              # ALL host cores (SURVEY.md 8d ii)
     if threads > 1:
         from concurrent.futures import ThreadPoolExecutor
-        per = max(1, int(parts * 0.25))
+        per = max(1, parts // 16)                           # ~15-30 s with every core busy
         t0 = time.perf_counter()
         with ThreadPoolExecutor(threads) as ex:
             outs = list(ex.map(lambda i: coracle.baseline_pass(*a, per, dim, i * per, SEED, KEY)[0], range(threads)))
@@ -157,7 +157,16 @@ class Env:
             box = [bytes(ident)]
             if self.use_dist:
                 dist.broadcast_object_list(box, src=0)
-            capi.check(self.lib.sda_comm_init((C.c_uint8 * 128)(*box[0]), self.rank, self.world, C.byref(self.comm)))
+            # RCCL prints its version banner to the C stdout at init: keep stdout for the ONE JSON line
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                capi.check(self.lib.sda_comm_init((C.c_uint8 * 128)(*box[0]), self.rank, self.world, C.byref(self.comm)))
+                C.CDLL(None).fflush(None)
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
 
     def modular_allreduce(self, t):
         """sum over ranks mod P62 of the int64 device tensor `t`, on every rank (new tensor)"""

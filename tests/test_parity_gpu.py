@@ -559,17 +559,18 @@ def test_scheme_validation(gpu):
     for bad in (crypto.Additive(3, 1), crypto.Additive(0, 433), crypto.Additive(3, 1 << 62),
                 crypto.PackedShamir(3, 8, 4, 435, 354, 150),           # composite modulus
                 crypto.PackedShamir(3, 8, 4, 433, 1, 150),             # omega_secrets of order 1: nodes collide
-                crypto.PackedShamir(0, 8, 4, 433, 354, 150),
-                # the descriptor is network-supplied: u64 wrap-arounds must not pass
-                crypto.PackedShamir((1 << 64) - 1, 8, 2, 433, 354, 150),   # k + t wraps to 1
+                crypto.PackedShamir(0, 8, 4, 433, 354, 150)):
+        with pytest.raises(capi.SdaError):
+            crypto.ShareGenerator(bad)
+    # the descriptor is network-supplied: u64 wrap-arounds must not pass, for any role
+    for bad in (crypto.PackedShamir((1 << 64) - 1, 8, 2, 433, 354, 150),   # k + t wraps to 1
                 crypto.PackedShamir(3, 8, (1 << 64) - 2, 433, 354, 150),   # k + t wraps to 1
                 crypto.PackedShamir(3, 1 << 32, 4, 433, 354, 150),         # share_count would truncate to 0
                 crypto.PackedShamir(5, 8, 4, 433, 354, 150)):              # share_count < t + k: never reconstructible
         with pytest.raises(capi.SdaError):
             crypto.ShareGenerator(bad)
-        if isinstance(bad, crypto.PackedShamir):
-            with pytest.raises(capi.SdaError):
-                crypto.SecretReconstructor(bad, 10)
+        with pytest.raises(capi.SdaError):
+            crypto.SecretReconstructor(bad, 10)
     with pytest.raises(capi.SdaError):
         crypto.SecretReconstructor(crypto.Additive(0, 433), 10)
     with pytest.raises(capi.SdaError):
