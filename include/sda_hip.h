@@ -429,6 +429,66 @@ int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_varint_codec_t
                                      size_t n_bytes);
 
 /* =============================================================================================
+ * Clerking-job container and `Binary` payloads.
+ *
+ * The reference hands a clerk its job as JSON: `ClerkingJob.encryptions: Vec<Encryption>` (protocol/src/resources.rs:
+ * 128-139), every Encryption::Sodium(Binary) a base64 string (protocol/src/helpers.rs:174-216), assembled by the
+ * server's snapshot transposition (server/src/stores.rs:86-101; server-store-mongodb/src/aggregations.rs:164-195).
+ * "SDAJOBv1" is the same job as ONE contiguous binary blob that can be DMA'd into HBM and consumed in place:
+ *
+ *     offset  0  char  magic[8]        "SDAJOBv1"
+ *             8  u32   header_bytes    64
+ *            12  u32   payload_kind    enum sda_job_payload_kind
+ *            16  u64   rows            number of encryptions (participants) in the job
+ *            24  u64   slot_bytes      bytes reserved per row, a multiple of 16
+ *            32  u64   lengths_offset  64: u64 row_bytes[rows], the byte length of every row's payload
+ *            40  u64   payload_offset  first slot, 16-byte aligned: row r occupies [payload_offset + r * slot_bytes, + row_bytes[r])
+ *            48  u64   total_bytes     payload_offset + rows * slot_bytes
+ *            56  u64   reserved        0
+ *     all integers little-endian.  With the blob at a 16-byte aligned device address `d`, (d + payload_offset,
+ *     slot_bytes, d + lengths_offset) are exactly the (d_bytes, slot_bytes, d_row_bytes) arguments of the slotted-row
+ *     device calls: sda_sealedbox_open_rows_dev (payload kind SEALED), sda_share_combiner_update_varint_rows_dev and
+ *     sda_varint_decode_rows_dev (kind VARINT), sda_base64_decode_rows_dev (kind BASE64_TEXT).
+ *
+ * The container functions are host-only (no device needed).  INTEGRATION.md shows what stores.rs:86-101 would emit.
+ * ============================================================================================= */
+enum sda_job_payload_kind {
+    SDA_JOB_SEALED = 0,       /* raw Encryption::Sodium bytes: sealed boxes (sodium.rs:43)                      */
+    SDA_JOB_VARINT = 1,       /* opened payloads: zig-zag LEB128 share vectors (sodium.rs:36-41)                 */
+    SDA_JOB_BASE64_TEXT = 2   /* the JSON form: base64 text of the sealed boxes (helpers.rs:174-216)             */
+};
+typedef struct sda_job_layout {
+    uint32_t payload_kind;
+    uint64_t rows, slot_bytes, lengths_offset, payload_offset, total_bytes;
+} sda_job_layout_t;
+size_t sda_job_slot_size(size_t max_payload_bytes);                   /* rounded up to 16                          */
+size_t sda_job_container_size(size_t rows, size_t slot_bytes);        /* 0 if slot_bytes is not a multiple of 16   */
+/* writes the header and a zeroed length table into buf[cap] */
+int sda_job_container_init(uint8_t* buf, size_t cap, uint32_t payload_kind, size_t rows, size_t slot_bytes,
+                           sda_job_layout_t* out /* may be NULL */);
+int sda_job_container_set_row(uint8_t* buf, size_t row, const uint8_t* payload, size_t len);
+/* validates magic, geometry and every row length (a job is network input) */
+int sda_job_container_parse(const uint8_t* buf, size_t n_bytes, sda_job_layout_t* out);
+int sda_job_container_get_row(const uint8_t* buf, size_t n_bytes, size_t row, const uint8_t** payload, size_t* len);
+
+/* RFC 4648 base64 (standard alphabet, '=' padding, strict like data_encoding::base64::decode) of P payloads at once,
+ * on the device.
+ *   decode: text row r at d_text + (d_text_offsets ? d_text_offsets[r] : r * text_slot) - any alignment, e.g. straight
+ *           into a JSON document - d_text_bytes[r] characters; raw bytes to d_out + r * out_slot (4-byte aligned rows),
+ *           their count to d_out_bytes[r].  max_chars >= the longest row.  A malformed row (length not a multiple of
+ *           4, foreign character, misplaced '=', stray bits under the padding: "Base64 decoding error",
+ *           helpers.rs:183) ORs 8 into *d_status and sets d_row_status[r] (optional, zero it beforehand).
+ *   encode: raw row r at d_in + r * in_slot (4-byte aligned rows) -> text row at d_text + r * text_slot (16-byte
+ *           aligned rows, text_slot >= sda_base64_encoded_size(max_bytes)), its length to d_text_bytes[r]. */
+size_t sda_base64_encoded_size(size_t n_bytes);
+size_t sda_base64_decoded_max(size_t n_chars);
+int sda_base64_decode_rows_dev(const uint8_t* d_text, const uint64_t* d_text_offsets, size_t text_slot,
+                               const uint64_t* d_text_bytes, size_t rows, size_t max_chars, uint8_t* d_out, size_t out_slot,
+                               uint64_t* d_out_bytes, uint32_t* d_status, uint32_t* d_row_status, void* stream);
+int sda_base64_encode_rows_dev(const uint8_t* d_in, size_t in_slot, const uint64_t* d_in_bytes, size_t rows,
+                               size_t max_bytes, uint8_t* d_text, size_t text_slot, uint64_t* d_text_bytes, void* stream);
+
+/* =============================================================================================
  * Cross-GPU modular reduction (new; no reference counterpart - SURVEY.md 8e: the reference's parties meet over HTTP).
  * Participants are sharded across the GPUs of a node, one process per GPU, no collective on the data path; the
  * per-clerk partial sums meet ONCE at the end:

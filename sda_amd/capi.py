@@ -44,6 +44,14 @@ class SharingScheme(C.Structure):
                 ("omega_secrets", C.c_int64), ("omega_shares", C.c_int64)]
 
 
+class JobLayout(C.Structure):
+    _fields_ = [("payload_kind", C.c_uint32), ("rows", C.c_uint64), ("slot_bytes", C.c_uint64),
+                ("lengths_offset", C.c_uint64), ("payload_offset", C.c_uint64), ("total_bytes", C.c_uint64)]
+
+
+JOB_SEALED, JOB_VARINT, JOB_BASE64_TEXT = 0, 1, 2
+
+
 class MaskingScheme(C.Structure):
     _fields_ = [("kind", C.c_int32), ("modulus", C.c_int64), ("dimension", C.c_uint64),
                 ("seed_bitsize", C.c_uint64)]
@@ -142,6 +150,18 @@ SIGNATURES = {
                                              C.c_size_t, C.c_void_p, C.c_void_p]),
     "sda_share_combiner_update_varint_rows_dev": (C.c_int, [_H, _H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                             C.c_void_p, C.c_void_p]),
+    "sda_job_slot_size": (C.c_size_t, [C.c_size_t]),
+    "sda_job_container_size": (C.c_size_t, [C.c_size_t, C.c_size_t]),
+    "sda_job_container_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_size_t, C.POINTER(JobLayout)]),
+    "sda_job_container_set_row": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "sda_job_container_parse": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(JobLayout)]),
+    "sda_job_container_get_row": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), c_sizep]),
+    "sda_base64_encoded_size": (C.c_size_t, [C.c_size_t]),
+    "sda_base64_decoded_max": (C.c_size_t, [C.c_size_t]),
+    "sda_base64_decode_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                             C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sda_base64_encode_rows_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_void_p]),
     "sda_comm_unique_id": (C.c_int, [c_u8p]),
     "sda_comm_init": (C.c_int, [c_u8p, C.c_int, C.c_int, _HP]),
     "sda_comm_free": (None, [_H]),

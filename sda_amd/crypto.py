@@ -520,3 +520,61 @@ class VarintCodec(_Handle):
                    row_stride: int, d_status: int, stream: int = 0) -> None:
         check(self._lib.sda_varint_decode_dev(self._h, d_bytes, n_bytes, d_row_offsets or None, rows, length, d_values,
                                               row_stride, d_status, stream or None))
+
+
+# ---- clerking-job container + base64 `Binary` payloads -------------------------------------
+class JobContainer:
+    """SDAJOBv1: a ClerkingJob's `encryptions: Vec<Encryption>` (protocol/src/resources.rs:128-139) as one binary blob
+    with fixed slots, laid out so the device calls consume it in place (include/sda_hip.h).  Host-side byte layout."""
+
+    def __init__(self, blob: bytearray, layout: "capi.JobLayout"):
+        self.blob, self.layout = blob, layout
+
+    @classmethod
+    def build(cls, kind: int, payloads: Sequence[bytes], slot_bytes: Optional[int] = None) -> "JobContainer":
+        lib = capi.load()
+        rows = len(payloads)
+        slot = lib.sda_job_slot_size(max((len(p) for p in payloads), default=0)) if slot_bytes is None else slot_bytes
+        size = lib.sda_job_container_size(rows, slot)
+        if rows and size == 0:
+            raise ValueError("slot_bytes must be a multiple of 16")
+        blob = bytearray(max(size, 64))
+        buf = (C.c_uint8 * len(blob)).from_buffer(blob)
+        lay = capi.JobLayout()
+        check(lib.sda_job_container_init(buf, len(blob), kind, rows, slot, C.byref(lay)))
+        for r, p in enumerate(payloads):
+            check(lib.sda_job_container_set_row(buf, r, bytes(p), len(p)))
+        del buf
+        return cls(blob, lay)
+
+    @classmethod
+    def parse(cls, blob: bytes) -> "JobContainer":
+        b = bytearray(blob)
+        lay = capi.JobLayout()
+        check(capi.load().sda_job_container_parse((C.c_uint8 * len(b)).from_buffer(b), len(b), C.byref(lay)))
+        return cls(b, lay)
+
+    def rows(self) -> List[bytes]:
+        L = self.layout
+        lens = np.frombuffer(self.blob, dtype="<u8", count=L.rows, offset=L.lengths_offset)
+        return [bytes(self.blob[L.payload_offset + r * L.slot_bytes:L.payload_offset + r * L.slot_bytes + int(lens[r])])
+                for r in range(L.rows)]
+
+    def __bytes__(self):
+        return bytes(self.blob)
+
+
+def base64_decode_rows_dev(d_text: int, text_slot: int, d_text_bytes: int, rows: int, max_chars: int, d_out: int,
+                           out_slot: int, d_out_bytes: int, d_status: int, d_row_status: int = 0, d_text_offsets: int = 0,
+                           stream: int = 0) -> None:
+    """Binary::from_base64 (helpers.rs:182-184) for `rows` payloads resident in HBM"""
+    check(capi.load().sda_base64_decode_rows_dev(d_text, d_text_offsets or None, text_slot, d_text_bytes, rows, max_chars,
+                                                 d_out, out_slot, d_out_bytes, d_status, d_row_status or None,
+                                                 stream or None))
+
+
+def base64_encode_rows_dev(d_in: int, in_slot: int, d_in_bytes: int, rows: int, max_bytes: int, d_text: int,
+                           text_slot: int, d_text_bytes: int, stream: int = 0) -> None:
+    """Binary::to_base64 (helpers.rs:178-180) for `rows` payloads resident in HBM"""
+    check(capi.load().sda_base64_encode_rows_dev(d_in, in_slot, d_in_bytes, rows, max_bytes, d_text, text_slot,
+                                                 d_text_bytes, stream or None))

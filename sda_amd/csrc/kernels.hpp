@@ -202,6 +202,17 @@ hipError_t launch_varint_stream_combine(const uint8_t* d_bytes, size_t n_bytes, 
 hipError_t launch_varint_rowcheck(const uint8_t* d_bytes, size_t n_bytes, const uint64_t* d_offsets, size_t rows,
                                   size_t len, const uint64_t* d_block_val_off, uint32_t* d_status, hipStream_t s);
 
+// ---- RFC 4648 base64 of `Binary` payloads (protocol/src/helpers.rs:174-216) - wire_kernels.hip ----------------
+// text row r at d_text + (d_offsets ? d_offsets[r] : r * text_slot), d_lengths[r] characters; raw row r at
+// d_out + r * out_slot; max_chars / max_bytes bound the longest row (they size the grid)
+hipError_t launch_base64_decode_rows(const uint8_t* d_text, const uint64_t* d_offsets, size_t text_slot,
+                                     const uint64_t* d_lengths, size_t rows, size_t max_chars, uint8_t* d_out,
+                                     size_t out_slot, uint64_t* d_out_bytes, uint32_t* d_status, uint32_t* d_row_status,
+                                     hipStream_t s);
+hipError_t launch_base64_encode_rows(const uint8_t* d_in, size_t in_slot, const uint64_t* d_in_bytes, size_t rows,
+                                     size_t max_bytes, uint8_t* d_text, size_t text_slot, uint64_t* d_text_bytes,
+                                     hipStream_t s);
+
 // ---- misc ---------------------------------------------------------------------------------------
 // out[i] = sum over g < parts of parts[g*part_stride + i]  mod m   (cross-GPU partial sums)
 hipError_t launch_modsum_parts(const int64_t* d_parts, size_t parts, size_t part_stride, size_t len,

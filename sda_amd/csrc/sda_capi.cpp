@@ -1619,6 +1619,11 @@ static int device_ready() {
     if (sda_device_count() == 0) return fail(SDA_ERR_NO_DEVICE, "%s", sda_strerror(SDA_ERR_NO_DEVICE));
     return SDA_OK;
 }
+int capi_device_ready() {
+    SDA_TRY(device_ready());
+    HIP_TRY(hipSetDevice(g_device < sda_device_count() ? g_device : 0));
+    return SDA_OK;
+}
 
 extern "C" int sda_modsum_parts_dev(int64_t modulus, const int64_t* d_parts, size_t parts, size_t part_stride,
                                     size_t len, int64_t* d_out, void* stream) {

@@ -56,5 +56,50 @@ class DeviceBuffer:
             pass
 
 
+class DeviceBytes:
+    """`nbytes` raw bytes of HBM (wire-format buffers: containers, base64 text, sealed boxes)."""
+
+    def __init__(self, nbytes: int):
+        self._lib = capi.load()
+        self.nbytes = int(nbytes)
+        self._p = C.c_void_p()
+        check(self._lib.sda_dev_malloc(C.byref(self._p), max(self.nbytes, 16)))
+
+    @property
+    def ptr(self) -> int:
+        return self._p.value
+
+    @classmethod
+    def from_bytes(cls, raw) -> "DeviceBytes":
+        a = np.frombuffer(bytes(raw), dtype=np.uint8)
+        b = cls(a.size)
+        if a.size:
+            check(b._lib.sda_dev_upload(b._p, a.ctypes.data_as(C.c_void_p), a.size))
+        return b
+
+    def zero(self) -> "DeviceBytes":
+        check(self._lib.sda_dev_memset(self._p, 0, max(self.nbytes, 1)))
+        return self
+
+    def to_bytes(self, count: int | None = None, offset: int = 0) -> bytes:
+        n = self.nbytes - offset if count is None else count
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        check(self._lib.sda_dev_synchronize())
+        if n:
+            check(self._lib.sda_dev_download(out.ctypes.data_as(C.c_void_p), C.c_void_p(self._p.value + offset), n))
+        return out[:n].tobytes()
+
+    def free(self):
+        if self._p is not None and self._p.value:
+            self._lib.sda_dev_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def synchronize():
     check(capi.load().sda_dev_synchronize())
