@@ -75,7 +75,8 @@ enum sda_status {
     SDA_ERR_ALLOC = -12,                     /* host or device allocation failed                   */
     SDA_ERR_STATE = -13,                     /* streaming call out of order (update before begin)  */
     SDA_ERR_ENTROPY = -14,                   /* getrandom() failed: no key material, nothing was generated */
-    SDA_ERR_COMM = -15                       /* an RCCL call failed (multi-GPU reduce)              */
+    SDA_ERR_COMM = -15,                      /* an RCCL call failed (multi-GPU reduce)              */
+    SDA_ERR_SODIUM_DECRYPTION = -16          /* "Sodium decryption failure"           encryption/sodium.rs:80 */
 };
 
 /* ---- scheme parameters (the wire enums stay intact) ---------------------------------------- */
@@ -487,6 +488,44 @@ int sda_base64_decode_rows_dev(const uint8_t* d_text, const uint64_t* d_text_off
                                uint64_t* d_out_bytes, uint32_t* d_status, uint32_t* d_row_status, void* stream);
 int sda_base64_encode_rows_dev(const uint8_t* d_in, size_t in_slot, const uint64_t* d_in_bytes, size_t rows,
                                size_t max_bytes, uint8_t* d_text, size_t text_slot, uint64_t* d_text_bytes, void* stream);
+
+/* =============================================================================================
+ * Sealed boxes: libsodium crypto_box_seal / crypto_box_seal_open - X25519, XSalsa20-Poly1305,
+ * nonce = BLAKE2b-24(epk || pk) - for a whole job of payloads at once, on the device.  The reference opens the P
+ * encryptions of a clerking job one by one (clerk.rs:79-82 -> ShareDecryptor::decrypt, encryption/sodium.rs:72-92,
+ * `sealedbox::open` at :78) and seals one payload per clerk in participate.rs:82-101 (`sealedbox::seal`, sodium.rs:43).
+ * A sealed box is  epk(32) || tag(16) || ciphertext  = 48 bytes longer than its payload.
+ *
+ *   open_rows_dev : box r at d_boxes + r * slot_bytes, d_row_bytes[r] bytes (the SDAJOBv1 SEALED layout).  The
+ *                   payload goes to d_out + r * out_slot and its length to d_out_bytes[r] - exactly the slotted rows
+ *                   sda_share_combiner_update_varint_rows_dev consumes, so a job is opened, decoded and summed
+ *                   without leaving HBM.  A box that does not authenticate (or is shorter than 48 bytes) gets length
+ *                   0, d_ok[r] = 0 (optional array) and ORs 16 into *d_status: the reference fails the whole job with
+ *                   "Sodium decryption failure" (sodium.rs:80) - check *d_status before using the sums.
+ *   seal_rows_dev : message r at d_msgs + r * msg_slot (d_msg_bytes[r] bytes) is sealed to
+ *                   pks[(r / rows_per_key) % n_pks] (host array of n_pks 32-byte keys; job-major rows [n][P]:
+ *                   rows_per_key = P; participant-major [P][n]: rows_per_key = 1) into d_boxes + r * slot_bytes, its
+ *                   length to d_row_bytes[r].  esk: NULL = a fresh ephemeral key pair per box from OS entropy, as
+ *                   crypto_box_seal draws it; else `rows` injected 32-byte ephemeral secrets (host) - TESTS ONLY, the
+ *                   one way to compare a sealed box bit for bit.
+ *   All rows and slots 16-byte aligned; max_* bound the longest row (they size the launch).  The host forms stage one
+ *   payload through the device (ShareEncryptor::encrypt / ShareDecryptor::decrypt minus the varint codec).
+ * ============================================================================================= */
+#define SDA_SEALBYTES 48
+typedef struct sda_sealedbox sda_sealedbox_t;
+int  sda_sealedbox_new(sda_sealedbox_t** out);
+void sda_sealedbox_free(sda_sealedbox_t* b);
+int  sda_sealedbox_open_rows_dev(sda_sealedbox_t* b, const uint8_t pk[32], const uint8_t sk[32], const uint8_t* d_boxes,
+                                 size_t slot_bytes, const uint64_t* d_row_bytes, size_t rows, size_t max_box_bytes,
+                                 uint8_t* d_out, size_t out_slot, uint64_t* d_out_bytes, uint32_t* d_ok, uint32_t* d_status,
+                                 void* stream);
+int  sda_sealedbox_seal_rows_dev(sda_sealedbox_t* b, const uint8_t* pks, size_t n_pks, size_t rows_per_key, const uint8_t* esk,
+                                 const uint8_t* d_msgs, size_t msg_slot, const uint64_t* d_msg_bytes, size_t rows,
+                                 size_t max_msg_bytes, uint8_t* d_boxes, size_t slot_bytes, uint64_t* d_row_bytes, void* stream);
+int  sda_sealedbox_seal(sda_sealedbox_t* b, const uint8_t pk[32], const uint8_t* esk /* NULL = OS entropy */,
+                        const uint8_t* msg, size_t len, uint8_t* out, size_t out_cap);
+int  sda_sealedbox_open(sda_sealedbox_t* b, const uint8_t pk[32], const uint8_t sk[32], const uint8_t* box, size_t len,
+                        uint8_t* out, size_t out_cap, size_t* out_len);
 
 /* =============================================================================================
  * Cross-GPU modular reduction (new; no reference counterpart - SURVEY.md 8e: the reference's parties meet over HTTP).

@@ -33,6 +33,7 @@ ERR_ALLOC = -12
 ERR_STATE = -13
 ERR_ENTROPY = -14
 ERR_COMM = -15
+ERR_SODIUM_DECRYPTION = -16
 
 SHARING_ADDITIVE, SHARING_PACKED_SHAMIR = 0, 1
 MASKING_NONE, MASKING_FULL, MASKING_CHACHA = 0, 1, 2
@@ -162,6 +163,14 @@ SIGNATURES = {
                                              C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sda_base64_encode_rows_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                              C.c_void_p, C.c_void_p]),
+    "sda_sealedbox_new": (C.c_int, [_HP]),
+    "sda_sealedbox_free": (None, [_H]),
+    "sda_sealedbox_open_rows_dev": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                              C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sda_sealedbox_seal_rows_dev": (C.c_int, [_H, C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t,
+                                              C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "sda_sealedbox_seal": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "sda_sealedbox_open": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, c_sizep]),
     "sda_comm_unique_id": (C.c_int, [c_u8p]),
     "sda_comm_init": (C.c_int, [c_u8p, C.c_int, C.c_int, _HP]),
     "sda_comm_free": (None, [_H]),

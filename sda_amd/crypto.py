@@ -578,3 +578,62 @@ def base64_encode_rows_dev(d_in: int, in_slot: int, d_in_bytes: int, rows: int, 
     """Binary::to_base64 (helpers.rs:178-180) for `rows` payloads resident in HBM"""
     check(capi.load().sda_base64_encode_rows_dev(d_in, in_slot, d_in_bytes, rows, max_bytes, d_text, text_slot,
                                                  d_text_bytes, stream or None))
+
+
+# ---- sealed boxes (SURVEY.md 8f rank 4): encryption/sodium.rs:33-46 (encrypt), :72-92 (decrypt) ----------------------
+class SealedBox(_Handle):
+    """libsodium crypto_box_seal / crypto_box_seal_open on the GPU, one payload (host forms) or a whole job (rows)."""
+    _free = "sda_sealedbox_free"
+    SEALBYTES = 48
+
+    def __init__(self):
+        super().__init__()
+        check(self._lib.sda_sealedbox_new(C.byref(self._h)))
+
+    def seal(self, message: bytes, pk: bytes, esk: Optional[bytes] = None) -> bytes:
+        """sealedbox::seal (sodium.rs:43); esk injects the ephemeral secret key (tests only)"""
+        assert len(pk) == 32 and (esk is None or len(esk) == 32)
+        out = np.empty(len(message) + 48, dtype=np.uint8)
+        check(self._lib.sda_sealedbox_seal(self._h, pk, esk, bytes(message), len(message), out.ctypes.data_as(C.c_void_p), out.size))
+        return out.tobytes()
+
+    def open(self, box: bytes, pk: bytes, sk: bytes) -> bytes:
+        """sealedbox::open (sodium.rs:78); raises SdaError("Sodium decryption failure") like the reference's Err (:80)"""
+        assert len(pk) == 32 and len(sk) == 32
+        out = np.empty(max(len(box), 1), dtype=np.uint8)
+        n = C.c_size_t()
+        check(self._lib.sda_sealedbox_open(self._h, pk, sk, bytes(box), len(box), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def open_rows_dev(self, pk: bytes, sk: bytes, d_boxes: int, slot_bytes: int, d_row_bytes: int, rows: int, max_box_bytes: int,
+                      d_out: int, out_slot: int, d_out_bytes: int, d_status: int, d_ok: int = 0, stream: int = 0) -> None:
+        check(self._lib.sda_sealedbox_open_rows_dev(self._h, pk, sk, d_boxes, slot_bytes, d_row_bytes, rows, max_box_bytes, d_out,
+                                                    out_slot, d_out_bytes, d_ok or None, d_status, stream or None))
+
+    def seal_rows_dev(self, pks: Sequence[bytes], rows_per_key: int, d_msgs: int, msg_slot: int, d_msg_bytes: int, rows: int,
+                      max_msg_bytes: int, d_boxes: int, slot_bytes: int, d_row_bytes: int, esk: Optional[bytes] = None,
+                      stream: int = 0) -> None:
+        allpk = b"".join(pks)
+        assert len(allpk) == 32 * len(pks) and (esk is None or len(esk) == 32 * rows)
+        check(self._lib.sda_sealedbox_seal_rows_dev(self._h, allpk, len(pks), rows_per_key, esk, d_msgs, msg_slot, d_msg_bytes, rows,
+                                                    max_msg_bytes, d_boxes, slot_bytes, d_row_bytes, stream or None))
+
+
+class ShareEncryptor:
+    """encryption/sodium.rs:33-46: zig-zag varint encode every share, then seal the bytes for the clerk's key."""
+
+    def __init__(self, pk: bytes):
+        self.pk, self._box, self._codec = pk, SealedBox(), VarintCodec()
+
+    def encrypt(self, shares, esk: Optional[bytes] = None) -> bytes:
+        return self._box.seal(self._codec.encode(shares), self.pk, esk)
+
+
+class ShareDecryptor:
+    """encryption/sodium.rs:72-92: open the sealed box, decode varints until the reader is empty."""
+
+    def __init__(self, pk: bytes, sk: bytes):
+        self.pk, self.sk, self._box, self._codec = pk, sk, SealedBox(), VarintCodec()
+
+    def decrypt(self, encryption: bytes) -> np.ndarray:
+        return self._codec.decode(self._box.open(encryption, self.pk, self.sk))

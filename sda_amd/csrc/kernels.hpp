@@ -213,6 +213,28 @@ hipError_t launch_base64_encode_rows(const uint8_t* d_in, size_t in_slot, const 
                                      size_t max_bytes, uint8_t* d_text, size_t text_slot, uint64_t* d_text_bytes,
                                      hipStream_t s);
 
+// ---- libsodium sealed boxes, batched (sodium.rs:43, :78) - sealedbox_kernels.hip ----------------------------
+// per-box state written by the setup kernel (one lane per box) and read, wave-uniformly, by the bulk kernels
+struct SboxState {
+    uint32_t subkey[8];      // XSalsa20 subkey = HSalsa20(HSalsa20(X25519, 0), nonce[0:16])
+    uint32_t n0, n1;         // nonce[16:24]
+    uint32_t s[4];           // Poly1305 s
+    uint32_t r64[5], rS[5];  // r^64 and r^1024, 26-bit limbs
+    uint32_t bad, pad[7];    // 1: unusable box (shorter than 48 bytes, all-zero shared secret)
+    uint32_t rpow[64][5];    // r^1 .. r^64
+};
+size_t sbox_regions(size_t max_msg_bytes);          // Poly1305 regions per box (sizes d_partial: rows * regions * 5 words)
+// box r at d_boxes + r * slot (16-byte aligned), d_row_bytes[r] bytes; plaintext to d_out + r * out_slot (16-byte aligned)
+hipError_t launch_sealedbox_open(const uint8_t pk[32], const uint8_t sk[32], const uint8_t* d_boxes, size_t slot,
+                                 const uint64_t* d_row_bytes, size_t rows, size_t max_box_bytes, uint8_t* d_out, size_t out_slot,
+                                 uint64_t* d_out_bytes, uint32_t* d_ok, uint32_t* d_status, SboxState* d_states,
+                                 uint32_t* d_partial, hipStream_t s);
+// message r at d_msgs + r * msg_slot sealed to d_pks[(r / rows_per_key) % n_pks] with the ephemeral secret d_esk[r]
+hipError_t launch_sealedbox_seal(const uint8_t* d_esk, const uint8_t* d_pks, size_t n_pks, size_t rows_per_key,
+                                 const uint8_t* d_msgs, size_t msg_slot, const uint64_t* d_msg_bytes, size_t rows,
+                                 size_t max_msg_bytes, uint8_t* d_boxes, size_t slot, uint64_t* d_row_bytes, SboxState* d_states,
+                                 uint32_t* d_partial, hipStream_t s);
+
 // ---- misc ---------------------------------------------------------------------------------------
 // out[i] = sum over g < parts of parts[g*part_stride + i]  mod m   (cross-GPU partial sums)
 hipError_t launch_modsum_parts(const int64_t* d_parts, size_t parts, size_t part_stride, size_t len,

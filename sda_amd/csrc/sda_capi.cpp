@@ -87,6 +87,7 @@ extern "C" const char* sda_strerror(int status) {
         case SDA_ERR_STATE: return "call out of order";
         case SDA_ERR_ENTROPY: return "the operating system's entropy source failed";
         case SDA_ERR_COMM: return "RCCL communicator error";
+        case SDA_ERR_SODIUM_DECRYPTION: return "Sodium decryption failure";
         default: return "unknown status";
     }
 }

@@ -1,0 +1,317 @@
+// Batch open / seal of libsodium sealed boxes on gfx950: what the reference does one payload at a
+// time through sodiumoxide - `sealedbox::seal` per clerk in participate.rs:82-101 via encryption/sodium.rs:43,
+// `sealedbox::open` for each of the P encryptions of a clerking job in clerk.rs:79-82 via sodium.rs:78.
+//
+//   sbox_setup_kernel   one lane = one box: BLAKE2b nonce, X25519, two HSalsa20, the Poly1305 key and its powers
+//   sbox_stream_kernel  one lane = one 64-byte Salsa20 block: XSalsa20 keystream xor (VALU-bound: 20 rounds per 64 B)
+//   sbox_poly_kernel    one wave = one 16 KiB region of ciphertext: lane-strided Horner with the uniform multiplier
+//                       r^64 (one 130-bit multiply per 16-byte piece, 1 KiB coalesced loads), lane weights r^(l+1)
+//   sbox_final_kernel   one lane = one box: Horner over the regions with r^1024, tag compare (open) / tag store (seal)
+//
+// Pieces are indexed by their distance d from the END of the message (tag = sum c_d r^d + s), so the only ragged
+// region is the one at the start of the message, where missing pieces simply contribute nothing.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+#include "sbox_primitives.hpp"
+
+namespace sda {
+
+using namespace sbx;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static constexpr int kSbThreads = 256;
+static constexpr int kPolySteps = 16;                       // pieces per lane and region: region = 64 * 16 pieces = 16 KiB
+
+struct SboxKeyArg { uint32_t w[8]; };
+
+__device__ __forceinline__ void load_words(uint32_t* w, const uint8_t* p, int n) {       // p is 4-byte aligned
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    for (int i = 0; i < n; ++i) w[i] = q[i];
+}
+
+// common tail of setup: from the shared X25519 secret and the nonce to the per-box state
+__device__ __forceinline__ void derive_state(SboxState& st, const uint32_t shared[8], const uint32_t nonce[6]) {
+    const uint32_t zero4[4] = {0, 0, 0, 0};
+    uint32_t k[8];
+    hsalsa20(k, shared, zero4);                               // crypto_box_beforenm
+    hsalsa20(st.subkey, k, nonce);                            // XSalsa20: subkey from the first 16 nonce bytes
+    st.n0 = nonce[4]; st.n1 = nonce[5];
+    uint32_t b0[16];
+    salsa20_block(b0, st.subkey, st.n0, st.n1, 0);            // stream bytes 0..31 = the one-time Poly1305 key
+    P26 r, rp;
+    p26_clamped_r(r, b0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st.s[i] = b0[4 + i];
+    rp = r;
+    for (int i = 0; i < 64; ++i) {                            // rpow[i] = r^(i+1)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) st.rpow[i][j] = rp.v[j];
+        if (i < 63) { P26 t; p26_mul(t, rp, r); rp = t; }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) st.r64[j] = rp.v[j];
+    for (int s = kPolySteps; s > 1; s >>= 1) { P26 t; p26_mul(t, rp, rp); rp = t; }     // (r^64)^16 = r^1024
+#pragma unroll
+    for (int j = 0; j < 5; ++j) st.rS[j] = rp.v[j];
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) any |= shared[i];
+    st.bad = any == 0 ? 1u : 0u;                              // all-zero shared secret (small-order point): crypto_box refuses it
+}
+
+// OPEN: box r at boxes + r * slot (epk || tag || ciphertext), recipient key pair in the kernel arguments
+__global__ __launch_bounds__(64) void sbox_setup_open_kernel(const uint8_t* __restrict__ boxes, size_t slot,
+                                                             const uint64_t* __restrict__ row_bytes, size_t rows, SboxKeyArg pk,
+                                                             SboxKeyArg sk, SboxState* __restrict__ states) {
+    const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= rows) return;
+    SboxState& st = states[r];
+    if (row_bytes[r] < 48) { st.bad = 1; return; }
+    uint32_t epk[8], nonce[6], shared[8];
+    load_words(epk, boxes + r * slot, 8);
+    seal_nonce(nonce, epk, pk.w);
+    x25519(shared, sk.w, epk);
+    derive_state(st, shared, nonce);
+}
+
+// SEAL: ephemeral secret r at esk + 32 r; recipient key of row r = pks[(r / rows_per_key) % n_pks]; writes epk to the box
+__global__ __launch_bounds__(64) void sbox_setup_seal_kernel(const uint8_t* __restrict__ esk, const uint8_t* __restrict__ pks,
+                                                             size_t n_pks, size_t rows_per_key, uint8_t* __restrict__ boxes,
+                                                             size_t slot, size_t rows, SboxState* __restrict__ states) {
+    const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= rows) return;
+    uint32_t e[8], pk[8], epk[8], nonce[6], shared[8];
+    load_words(e, esk + 32 * r, 8);
+    load_words(pk, pks + 32 * ((r / rows_per_key) % n_pks), 8);
+    const uint32_t base[8] = {9, 0, 0, 0, 0, 0, 0, 0};
+    x25519(epk, e, base);
+    uint32_t* o = reinterpret_cast<uint32_t*>(boxes + r * slot);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = epk[i];
+    seal_nonce(nonce, epk, pk);
+    x25519(shared, e, pk);
+    derive_state(states[r], shared, nonce);
+}
+
+// XSalsa20 xor: in row r at in + r * in_slot + in_off, out likewise; the message of row r has lens[r] - len_sub bytes
+__global__ __launch_bounds__(kSbThreads) void sbox_stream_kernel(const uint8_t* __restrict__ in, size_t in_slot, size_t in_off,
+                                                                 uint8_t* __restrict__ out, size_t out_slot, size_t out_off,
+                                                                 const uint64_t* __restrict__ lens, uint64_t len_sub,
+                                                                 const SboxState* __restrict__ states, size_t row0) {
+    const size_t r = row0 + blockIdx.y;
+    const uint64_t have = lens[r];
+    if (have < len_sub) return;
+    const uint64_t mlen = have - len_sub;
+    const uint64_t J = (uint64_t)blockIdx.x * kSbThreads + threadIdx.x;     // Salsa20 block: message bytes [64 J - 32, 64 J + 32)
+    const uint64_t a = J ? 64 * J - 32 : 0;
+    if (a >= mlen) return;
+    const SboxState& st = states[r];
+    uint32_t key[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) key[i] = st.subkey[i];                      // wave-uniform: scalar loads
+    uint32_t ks[16];
+    salsa20_block(ks, key, st.n0, st.n1, J);
+    const uint8_t* src = in + r * in_slot + in_off + a;
+    uint8_t* dst = out + r * out_slot + out_off + a;
+    const int first = J ? 0 : 2;                                            // block 0: its first 32 bytes are the Poly1305 key
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < first) continue;
+        const uint64_t p = (uint64_t)16 * (i - first);
+        if (a + p >= mlen) break;
+        const uint64_t n = mlen - a - p;
+        if (n >= 16) {
+            uint4 v = *reinterpret_cast<const uint4*>(src + p);
+            v.x ^= ks[4 * i]; v.y ^= ks[4 * i + 1]; v.z ^= ks[4 * i + 2]; v.w ^= ks[4 * i + 3];
+            *reinterpret_cast<uint4*>(dst + p) = v;
+        } else {
+            for (uint32_t b = 0; b < (uint32_t)n; ++b)
+                dst[p + b] = src[p + b] ^ (uint8_t)(ks[4 * i + (b >> 2)] >> (8 * (b & 3)));
+        }
+    }
+}
+
+// Poly1305 partial sums over the ciphertext (row r at ct + r * slot + off, lens[r] - len_sub bytes)
+__global__ __launch_bounds__(kSbThreads) void sbox_poly_kernel(const uint8_t* __restrict__ ct, size_t slot, size_t off,
+                                                               const uint64_t* __restrict__ lens, uint64_t len_sub,
+                                                               const SboxState* __restrict__ states, uint32_t* __restrict__ partial,
+                                                               size_t regions, size_t row0) {
+    const size_t r = row0 + blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t region = (size_t)blockIdx.x * (kSbThreads / 64) + (threadIdx.x >> 6);
+    if (region >= regions) return;
+    const uint64_t have = lens[r];
+    const uint64_t mlen = have >= len_sub ? have - len_sub : 0;
+    const uint64_t npieces = (mlen + 15) / 16;
+    const uint32_t tail = (uint32_t)(mlen & 15);                             // bytes of the last piece (0 = full)
+    const SboxState& st = states[r];
+    P26 R64;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) R64.v[j] = st.r64[j];                        // wave-uniform
+    const uint8_t* base = ct + r * slot + off;
+    P26 h;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) h.v[j] = 0;
+    const uint64_t d0 = (uint64_t)region * 64 * kPolySteps + lane + 1;       // distance from the end, step 0
+    if (d0 - lane <= npieces) {                                              // the region holds at least one piece (wave-uniform)
+        for (int m = kPolySteps - 1; m >= 0; --m) {
+            const uint64_t d = d0 + 64 * (uint64_t)m;
+            P26 t;
+            p26_mul(t, h, R64);
+            h = t;
+            if (d <= npieces) {
+                const uint64_t b = npieces - d;
+                uint32_t w[4];
+                const uint32_t nb = (d == 1 && tail) ? tail : 16u;
+                if (nb == 16) {
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + 16 * b));
+                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                } else {
+                    w[0] = w[1] = w[2] = w[3] = 0;
+                    for (uint32_t i = 0; i < nb; ++i) w[i >> 2] |= (uint32_t)base[16 * b + i] << (8 * (i & 3));
+                }
+                P26 c;
+                p26_from_piece(c, w, nb);
+                p26_add(h, h, c);
+            }
+        }
+        P26 wgt, t;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) wgt.v[j] = st.rpow[lane][j];             // r^(lane+1)
+        p26_mul(t, h, wgt);
+        h = t;
+        p26_carry(h);                                                        // limbs < 2^26: 64 of them sum below 2^32
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        uint32_t v = h.v[j];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+        h.v[j] = v;
+    }
+    if (lane == 0) {
+        uint32_t* o = partial + (r * regions + region) * 5;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) o[j] = h.v[j];
+    }
+}
+
+// one lane per box: total = sum over regions of partial[region] * (r^1024)^region, tag = total + s.
+// OPEN (seal == 0): compare with the tag in the box; out_bytes[r] = message length, or 0 for a box that fails.
+// SEAL: store the tag, row_bytes_out[r] = message length + 48.
+__global__ __launch_bounds__(64) void sbox_final_kernel(const uint32_t* __restrict__ partial, size_t regions,
+                                                        const SboxState* __restrict__ states, uint8_t* __restrict__ boxes, size_t slot,
+                                                        const uint64_t* __restrict__ lens, uint64_t len_sub, size_t rows, int seal,
+                                                        uint64_t* __restrict__ out_bytes, uint32_t* __restrict__ ok,
+                                                        uint32_t* __restrict__ status) {
+    const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= rows) return;
+    const SboxState& st = states[r];
+    const uint64_t have = lens[r];
+    bool good = have >= len_sub && !st.bad;
+    const uint64_t mlen = have >= len_sub ? have - len_sub : 0;
+    uint32_t tag[4] = {0, 0, 0, 0};
+    if (good) {
+        const size_t used = (size_t)(((mlen + 15) / 16 + 64 * kPolySteps - 1) / (64 * kPolySteps));
+        P26 RS, acc;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { RS.v[j] = st.rS[j]; acc.v[j] = 0; }
+        for (size_t g = used; g-- > 0;) {
+            P26 t, p;
+            p26_mul(t, acc, RS);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) p.v[j] = partial[(r * regions + g) * 5 + j];
+            p26_carry(p);
+            p26_add(acc, t, p);
+        }
+        p26_finish(tag, acc, st.s);
+    }
+    uint32_t* box_tag = reinterpret_cast<uint32_t*>(boxes + r * slot + 32);
+    if (seal) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) box_tag[i] = tag[i];
+        out_bytes[r] = mlen + 48;
+        return;
+    }
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) diff |= tag[i] ^ box_tag[i];
+    good = good && diff == 0;
+    out_bytes[r] = good ? mlen : 0;
+    if (ok) ok[r] = good ? 1u : 0u;
+    if (!good) atomicOr(status, 16u);
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------
+static inline uint64_t cdiv64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+size_t sbox_regions(size_t max_msg_bytes) { return (size_t)cdiv64(cdiv64(max_msg_bytes, 16), 64 * kPolySteps) + (max_msg_bytes == 0 ? 1 : 0); }
+
+static SboxKeyArg key_arg(const uint8_t k[32]) {
+    SboxKeyArg a;
+    for (int i = 0; i < 8; ++i) a.w[i] = (uint32_t)k[4 * i] | ((uint32_t)k[4 * i + 1] << 8) | ((uint32_t)k[4 * i + 2] << 16) | ((uint32_t)k[4 * i + 3] << 24);
+    return a;
+}
+
+static hipError_t bulk(const uint8_t* d_in, size_t in_slot, size_t in_off, uint8_t* d_out, size_t out_slot, size_t out_off,
+                       const uint8_t* d_ct, size_t ct_slot, size_t ct_off, const uint64_t* d_lens, uint64_t len_sub, size_t rows,
+                       size_t max_msg, const SboxState* d_states, uint32_t* d_partial, bool stream_first, hipStream_t s) {
+    const size_t regions = sbox_regions(max_msg);
+    const uint64_t sblocks = cdiv64(cdiv64(max_msg + 32, 64), kSbThreads);
+    const uint64_t pblocks = cdiv64(regions, kSbThreads / 64);
+    if (sblocks > 0x7FFFFFFFull || pblocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    for (size_t r0 = 0; r0 < rows; r0 += 65535) {
+        const unsigned nr = (unsigned)(rows - r0 < 65535 ? rows - r0 : 65535);
+        if (stream_first && max_msg)
+            sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), 0, s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
+                                                                                        d_lens, len_sub, d_states, r0);
+        sbox_poly_kernel<<<dim3((unsigned)pblocks, nr), dim3(kSbThreads), 0, s>>>(d_ct, ct_slot, ct_off, d_lens, len_sub, d_states,
+                                                                                  d_partial, regions, r0);
+        if (!stream_first && max_msg)
+            sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), 0, s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
+                                                                                        d_lens, len_sub, d_states, r0);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_sealedbox_open(const uint8_t pk[32], const uint8_t sk[32], const uint8_t* d_boxes, size_t slot,
+                                 const uint64_t* d_row_bytes, size_t rows, size_t max_box_bytes, uint8_t* d_out, size_t out_slot,
+                                 uint64_t* d_out_bytes, uint32_t* d_ok, uint32_t* d_status, SboxState* d_states,
+                                 uint32_t* d_partial, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    const size_t max_msg = max_box_bytes > 48 ? max_box_bytes - 48 : 0;
+    SboxKeyArg apk = key_arg(pk), ask = key_arg(sk);
+    sbox_setup_open_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_boxes, slot, d_row_bytes, rows, apk, ask, d_states);
+    volatile uint32_t* wipe = ask.w;
+    for (int i = 0; i < 8; ++i) wipe[i] = 0;
+    if (hipError_t e = hipGetLastError()) return e;
+    // tag first, then the keystream xor (both read the ciphertext; the plaintext of a failing box is reported with length 0)
+    if (hipError_t e = bulk(d_boxes, slot, 48, d_out, out_slot, 0, d_boxes, slot, 48, d_row_bytes, 48, rows, max_msg, d_states,
+                            d_partial, false, s))
+        return e;
+    sbox_final_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_partial, sbox_regions(max_msg), d_states,
+                                                                           const_cast<uint8_t*>(d_boxes), slot, d_row_bytes, 48, rows, 0,
+                                                                           d_out_bytes, d_ok, d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_sealedbox_seal(const uint8_t* d_esk, const uint8_t* d_pks, size_t n_pks, size_t rows_per_key,
+                                 const uint8_t* d_msgs, size_t msg_slot, const uint64_t* d_msg_bytes, size_t rows,
+                                 size_t max_msg_bytes, uint8_t* d_boxes, size_t slot, uint64_t* d_row_bytes, SboxState* d_states,
+                                 uint32_t* d_partial, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    sbox_setup_seal_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_esk, d_pks, n_pks, rows_per_key, d_boxes, slot, rows,
+                                                                                d_states);
+    if (hipError_t e = hipGetLastError()) return e;
+    // encrypt into the box, then authenticate the ciphertext
+    if (hipError_t e = bulk(d_msgs, msg_slot, 0, d_boxes, slot, 48, d_boxes, slot, 48, d_msg_bytes, 0, rows, max_msg_bytes, d_states,
+                            d_partial, true, s))
+        return e;
+    sbox_final_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_partial, sbox_regions(max_msg_bytes), d_states, d_boxes, slot,
+                                                                           d_msg_bytes, 0, rows, 1, d_row_bytes, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+}  // namespace sda
