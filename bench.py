@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 P62 = 4611686006577364993
-OMEGA = {8: 631229665360524489, 9: 3451275676410824977, 16: 2589100645267092065, 27: 365137883145458390}
+OMEGA = {8: 631229665360524489, 9: 3451275676410824977, 16: 2589100645267092065, 27: 365137883145458390,
+         256: 3916993753559330817, 729: 4527470848155349462}          # 5^((p-1)/order) mod p
 SEED = 0x5DA5DA5DA5DA5DA5
 KEY = bytes((i * 7 + 1) & 0xFF for i in range(32))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -49,6 +50,8 @@ WORKLOADS = {
                         desc="tss-valid shape t=3 k=4 n=8 through the run-time (k, t) dual-role kernel, dim 1048576"),
     "additive": dict(kind="additive", n=3, k=1, t=2, o2=8, o3=9, participants=10_000,
                      desc="BASELINE config 2: additive 3-way, dim 1048576, 62-bit modulus, 10k participants"),
+    "packed_pss728": dict(kind="packed", n=728, k=100, t=155, o2=256, o3=729, participants=10_000, tile_max=500,
+                          desc="tss's shipped shape PSS_155_728_100 (k=100, t=155, n=728; transform kernel), dim 1048576, 62-bit prime"),
     # config 5 on ONE GPU: its 100k participants are spread over 8 GPUs (12.5k each); the dimension is what differs, and
     # the reveal over 16 Mi secrets is part of it.  --dim defaults to 16777216 for this workload.
     "packed_dim16m": dict(kind="packed", n=8, k=3, t=1, o2=8, o3=9, participants=12_500, dim=1 << 24, tile_max=125,
@@ -357,7 +360,8 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     gen_b, comb_b = algorithmic_bytes_per_element(n, k)
     per_launch_bytes = P * dim * (gen_b + comb_b)
     gbs = tiles * per_launch_bytes / (sum(launch_ms) * 1e-3) / 1e9
-    kern = "fused_packed_l31_kernel" if w["kind"] == "packed" else "fused_additive_kernel"
+    kern = ("fused_additive_kernel" if w["kind"] != "packed" else
+            "fused_packed_l31_kernel" if w["k"] + w["t"] <= 16 else "packed_gen_fft_kernel + combine_update_kernel (no dual-role form)")
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
                 "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid (shares "
                 "materialised in HBM by one launch, read back by the next); K+1 launches for K tiles")

@@ -442,6 +442,9 @@ struct sda_share_generator {
     bool fast = false;
     bool l31 = false;                    // balanced-31-bit-limb kernel, matrix in the kernarg segment
     bool l31g = false;                   // the same with run-time (k, t) and the matrix in global memory (d_M)
+    bool fft = false;                    // transform form (tss's own algorithm) for large tss-valid shapes
+    FftPlan fplan{};
+    DevBuf d_fft;
     L31Params lp{};
     Drbg drbg;
     Ctx ctx;
@@ -514,6 +517,67 @@ static int build_l31(sda_share_generator* g) {
     return SDA_OK;
 }
 
+// l31 constants without the matrix (shared by the limb-31 and the transform paths)
+static int l31_params(uint64_t p, L31Params& lp) {
+    const uint64_t B = 1ull << 31;
+    uint64_t inv;
+    if (!h_invmod(p % B, B, inv)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not invertible mod 2^31");
+    lp.p = p; lp.p2 = 2 * p; lp.h = (p + 1) / 2;
+    lp.p0 = (int32_t)(p % B); lp.p1 = (int32_t)(p >> 31);
+    lp.pinvB = (uint32_t)((B - inv) % B); lp.pad = 0;
+    return SDA_OK;
+}
+
+// x -> x * 2^62 mod p, centred, as balanced limbs (lo32 = m0 in [-2^30, 2^30), hi32 = m1)
+static uint64_t pack_l31(uint64_t x, uint64_t p) {
+    const uint64_t B = 1ull << 31;
+    const uint64_t mr = (uint64_t)((((u128)x) << 62) % p);
+    const int64_t c = mr > (p - 1) / 2 ? (int64_t)mr - (int64_t)p : (int64_t)mr;
+    int64_t m0 = (int64_t)((uint64_t)c & (B - 1));
+    if (m0 >= (int64_t)(B >> 1)) m0 -= (int64_t)B;
+    const int64_t m1 = (c - m0) / (int64_t)B;
+    return (uint64_t)(uint32_t)(int32_t)m0 | ((uint64_t)(uint32_t)(int32_t)m1 << 32);
+}
+
+// tss's transform structure applies when k + t + 1 = 2^a = ord(omega_secrets) and n + 1 = 3^b = ord(omega_shares)
+// (SURVEY.md App. B); the kernel also needs p < 2^62 - 2^31 and the group's values in LDS.
+static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, uint32_t& G) {
+    const uint64_t p = g->mod.m, m2 = (uint64_t)g->k + g->t + 1, m3 = (uint64_t)g->n + 1;
+    if (p >= (1ull << 62) - (1ull << 31)) return false;
+    a = 0; while ((1ull << a) < m2) ++a;
+    if ((1ull << a) != m2) return false;
+    uint64_t q = 1; b = 0; while (q < m3) { q *= 3; ++b; }
+    if (q != m3 || m3 > 19683 || m2 > 4096 || m2 > m3) return false;
+    const uint64_t w2 = h_canon(g->scheme.omega_secrets, p), w3 = h_canon(g->scheme.omega_shares, p);
+    if (h_powmod(w2, m2, p) != 1 || h_powmod(w2, m2 / 2, p) == 1) return false;      // order exactly 2^a
+    if (h_powmod(w3, m3, p) != 1 || h_powmod(w3, m3 / 3, p) == 1) return false;      // order exactly 3^b
+    if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 8) <= 64 * 1024) G = 8;
+    else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1) <= 160 * 1024) G = 1;
+    else return false;
+    return true;
+}
+
+static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G) {
+    const uint64_t p = g->mod.m, m2 = (uint64_t)g->k + g->t + 1, m3 = (uint64_t)g->n + 1;
+    SDA_TRY(l31_params(p, g->lp));
+    const uint64_t w2 = h_canon(g->scheme.omega_secrets, p), w3 = h_canon(g->scheme.omega_shares, p);
+    uint64_t w2i, m2i;
+    if (!h_invmod(w2, p, w2i) || !h_invmod(m2 % p, p, m2i)) return fail(SDA_ERR_INVALID_ARGUMENT, "omega_secrets is not invertible");
+    std::vector<uint64_t> tab(m2 / 2 + m3);
+    uint64_t x = 1;
+    for (uint64_t j = 0; j < m2 / 2; ++j) { tab[j] = pack_l31(x, p); x = h_mulmod(x, w2i, p); }
+    x = 1;
+    for (uint64_t j = 0; j < m3; ++j) { tab[m2 / 2 + j] = pack_l31(x, p); x = h_mulmod(x, w3, p); }
+    SDA_TRY(g->d_fft.reserve(tab.size() * 8));
+    HIP_TRY(hipMemcpy(g->d_fft.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    FftPlan& F = g->fplan;
+    F.k = g->k; F.t = g->t; F.n = g->n; F.m2 = (uint32_t)m2; F.a = a; F.m3 = (uint32_t)m3; F.b = b; F.G = G;
+    F.tw2 = g->d_fft.as<uint64_t>(); F.tw3 = g->d_fft.as<uint64_t>() + m2 / 2;
+    F.omega = pack_l31(h_powmod(w3, m3 / 3, p), p);
+    F.scale = pack_l31(m2i, p);
+    return SDA_OK;
+}
+
 extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_share_generator_t** out) {
     if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -546,7 +610,14 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
         g->fast = !g->l31 && packed_fast_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC");
         g->l31g = !g->l31 && !g->fast && packed_l31_global_path_available(g->k, g->t) && !getenv("SDA_FORCE_GENERIC") &&
                   !getenv("SDA_FORCE_MONT64");
-        if (g->l31 || g->l31g) {
+        // the transform form: every tss-valid shape beyond the limb-31 matrix kernels (k + t > 32); SDA_FORCE_FFT=1 selects
+        // it for any tss-valid shape (A/B runs, parity tests of small shapes)
+        uint32_t fa = 0, fb = 0, fG = 0;
+        if (!getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64") && ((!g->l31 && !g->fast && !g->l31g) || getenv("SDA_FORCE_FFT")) &&
+            fft_shape(g, fa, fb, fG)) {
+            g->fft = true; g->l31 = g->l31g = g->fast = false;
+            st = build_fft(g, fa, fb, fG);
+        } else if (g->l31 || g->l31g) {
             st = build_l31(g);
         } else if (g->fast) {
             g->matarg = new (std::nothrow) MatArg();
@@ -569,7 +640,7 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
 extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
     if (!g) return;
     if (g->ctx.device >= 0) (void)hipSetDevice(g->ctx.device);
-    g->d_M.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
+    g->d_M.release(); g->d_fft.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
     g->ctx.destroy();
     g->drbg.wipe();
     delete g->matarg;
@@ -630,6 +701,10 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
     if (g->l31g) {
         HIP_TRY(launch_packed_generate_l31_global(L, g->n, g->k, g->t, g->mod, g->lp, g->d_M.as<uint64_t>(), key,
                                                   g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->fft) {
+        HIP_TRY(launch_packed_generate_fft(L, g->mod, g->lp, key, g->fplan, g->drbg.rounds, s));
         return SDA_OK;
     }
     // any-shape path: materialise the CSPRNG draws first (identical values to the fused path)

@@ -148,6 +148,61 @@ def test_packed_generic_path_equals_fast_path(gpu, monkeypatch):
     assert np.array_equal(a, b)
 
 
+TSS_P1, TSS_P2 = 746497, 5038849                      # tss's shipped parameter sets [recalled, SURVEY.md App. B]: orders verified below
+
+
+def _root(p, order):
+    g = next(g for g in range(2, 500) if all(pow(g, (p - 1) // f, p) != 1 for f in (2, 3)))
+    return pow(g, (p - 1) // order, p)
+
+
+@pytest.mark.parametrize("p,k,t,n,w2,w3,dim,force", [
+    (TSS_P1, 100, 155, 728, 95660, 610121, 100 * 29 + 37, False),        # PSS_155_728_100: groups of 8 batches + a ragged group
+    (P62, 100, 155, 728, None, None, 100 * 17 + 1, False),               # the same shape over the 62-bit prime
+    (P62, 40, 23, 242, None, None, 40 * 40, False),                      # k + t + 1 = 64, n + 1 = 243
+    (TSS_P2, 100, 155, 19682, 4318906, 1814687, 250, False),             # PSS_155_19682_100: one batch fills the LDS (G = 1)
+    (P62, 3, 4, 8, W[8], W[9], 1000, True), (P62, 8, 7, 26, W[16], W[27], 6151, True),   # small tss-valid shapes, forced
+    (433, 3, 4, 8, 354, 150, 7, True)])
+def test_transform_share_generation_vs_oracle(gpu, monkeypatch, p, k, t, n, w2, w3, dim, force):
+    """tss's own algorithm on the device (radix-2 inverse transform, zero-extension, radix-3 forward transform;
+    packed_shamir.rs:42 -> tss share) for the large tss-valid shapes the matrix kernels do not cover, bit-exact against
+    the oracle's matrix form: injected randomness, any-i64 secrets, and the device CSPRNG streams (sda-drbg-v1)."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    if force:
+        monkeypatch.setenv("SDA_FORCE_FFT", "1")
+    w2 = w2 or _root(p, k + t + 1)
+    w3 = w3 or _root(p, n + 1)
+    assert pow(w2, k + t + 1, p) == 1 and pow(w2, (k + t + 1) // 2, p) != 1
+    assert pow(w3, n + 1, p) == 1 and pow(w3, (n + 1) // 3, p) != 1
+    rng = np.random.default_rng(k * 7 + n)
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    B = gen.batch_count(dim)
+    secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
+    rand = rng.integers(-(1 << 62), 1 << 62, size=B * t, dtype=np.int64)
+    got = gen.generate(secrets, rand)
+    want = coracle.packed_generate(p, k, t, n, w2, w3, secrets, rand)
+    assert np.array_equal(got, want)
+    # device CSPRNG: two participants, streams 70 and 71
+    gen.set_drbg_key(KEY)
+    P = 2
+    sec2 = rng.integers(0, p, size=(P, dim), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec2)
+    Bs = B + (B & 1)
+    d_out = DeviceBuffer(P * n * Bs).zero()
+    gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=70)
+    out = d_out.to_numpy().reshape(P, n, Bs)
+    for q in range(P):
+        w = coracle.packed_generate(p, k, t, n, w2, w3, sec2[q], coracle.drbg_fill(KEY, 70 + q, B, t, p))
+        assert np.array_equal(out[q, :, :B], w), f"participant {q}"
+    # and the round trip: reconstruct from t + k clerks == the secrets
+    idx = sorted(rng.choice(n, size=t + k, replace=False).tolist())
+    rec = crypto.SecretReconstructor(sch, dim).reconstruct([(i, out[0, i, :B]) for i in idx])
+    assert np.array_equal(rec, sec2[0])
+
+
 def test_small_prime_packed_matches_tss_fft_path(gpu):
     """p = 433 (full_loop.rs:57-64): the matrix form on the GPU equals the recalled tss FFT path."""
     from sda_amd import crypto
