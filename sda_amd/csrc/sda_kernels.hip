@@ -325,25 +325,60 @@ __device__ __forceinline__ int64_t l31_group(const uint64_t* __restrict__ row, c
     return mad_sv(P.p1, q1, C2) + (C1 >> 31) + ((E + 0x7FFFFFFF) >> 31);
 }
 
+// Five terms in one group: the two cross columns m0*v1 and m1*v0 are kept apart (a shared column would hold ten products
+// of up to 2^60: past 2^63), every column stays below 1.25 * 2^62 and the result in (-1.75p, 1.75p) still fits 64 bits -
+// six or more terms would not (each term adds up to p/4 to the result).  One reduction per five terms instead of per
+// four: (8,2,26) takes 2 groups instead of 3, (8,7,26) 3 instead of 4.  Model: tests/test_limb31_model.py.
+__device__ __forceinline__ int64_t l31_group5(const uint64_t* __restrict__ row, const int32_t* v0, const int32_t* v1,
+                                              const L31Params& P) {
+    int64_t C0, C1a, C1b, C2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int32_t m0 = (int32_t)(uint32_t)row[i];
+        const int32_t m1 = (int32_t)(uint32_t)(row[i] >> 32);
+        if (i == 0) {
+            C0 = mul_sv(m0, v0[i]); C1a = mul_sv(m0, v1[i]); C1b = mul_sv(m1, v0[i]); C2 = mul_sv(m1, v1[i]);
+        } else {
+            C0 = mad_sv(m0, v0[i], C0); C1a = mad_sv(m0, v1[i], C1a); C1b = mad_sv(m1, v0[i], C1b); C2 = mad_sv(m1, v1[i], C2);
+        }
+    }
+    const int32_t q0 = sext31((uint32_t)C0 * P.pinvB);
+    C0 = mad_sv(P.p0, q0, C0);                                  // == 0 mod B
+    int64_t E = mad_sv(P.p1, q0, C0 >> 31);
+    const int32_t q1 = sext31(((uint32_t)C1a + (uint32_t)C1b + (uint32_t)E) * P.pinvB);
+    E = mad_sv(P.p0, q1, E);                                    // C1a + C1b + E == 0 mod B
+    // (C1a + C1b + E) / B without forming the sum (it can pass 2^63): floors of the two columns + the exact quotient of
+    // E plus their low limbs
+    const uint32_t lows = ((uint32_t)C1a & 0x7FFFFFFFu) + ((uint32_t)C1b & 0x7FFFFFFFu);
+    return mad_sv(P.p1, q1, C2) + (C1a >> 31) + (C1b >> 31) + ((E + (int64_t)(uint64_t)lows) >> 31);
+}
+
 // x in [0, 4p) -> [0, 2p)
 // (a borrow-based select was measured 2 % slower than hipcc's compare + select form)
 __device__ __forceinline__ uint64_t condsub(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
 
-// sum_i M_i * v_i mod p for any KT: groups of <= 4 terms, partial results kept lazily in [0, 2p)
+// sum_i M_i * v_i mod p for any KT: groups of <= 4 terms - or of 5 where that saves a group (KT = 5, 9, 10, 13, 14, 15,
+// ...) - partial results kept lazily in [0, 2p)
 template <int KT>
 __device__ __forceinline__ uint64_t l31_dot(const uint64_t* __restrict__ row, const int32_t (&v0)[KT],
                                             const int32_t (&v1)[KT], const L31Params& P) {
+    constexpr int G4 = (KT + 3) / 4, G5 = (KT + 4) / 5;
+    constexpr int FIVES = G5 < G4 ? KT - 4 * G5 : 0;           // that many groups of five, the rest of four (or fewer)
     uint64_t r = 0;
+    int g = 0;
 #pragma unroll
-    for (int g = 0; g < KT; g += 4) {
+    for (int grp = 0; grp < (G5 < G4 ? G5 : G4); ++grp) {
         int64_t top;
         const int left = KT - g;
-        if (left >= 4) top = l31_group<4>(row + g, v0 + g, v1 + g, P);
-        else if (left == 3) top = l31_group<3>(row + g, v0 + g, v1 + g, P);
-        else if (left == 2) top = l31_group<2>(row + g, v0 + g, v1 + g, P);
-        else top = l31_group<1>(row + g, v0 + g, v1 + g, P);
-        const uint64_t u = condsub((uint64_t)top + P.p2, P.p2);           // [0, 2p)
-        r = g == 0 ? u : condsub(r + u, P.p2);                            // [0, 2p)
+        int used;
+        if (grp < FIVES) { top = l31_group5(row + g, v0 + g, v1 + g, P); used = 5; }
+        else if (left >= 4) { top = l31_group<4>(row + g, v0 + g, v1 + g, P); used = 4; }
+        else if (left == 3) { top = l31_group<3>(row + g, v0 + g, v1 + g, P); used = 3; }
+        else if (left == 2) { top = l31_group<2>(row + g, v0 + g, v1 + g, P); used = 2; }
+        else { top = l31_group<1>(row + g, v0 + g, v1 + g, P); used = 1; }
+        const uint64_t u = condsub((uint64_t)top + P.p2, P.p2);           // (0.25p, 3.75p) -> [0, 2p)
+        r = grp == 0 ? u : condsub(r + u, P.p2);                          // [0, 2p)
+        g += used;
     }
     return condsub(r, P.p);
 }
@@ -415,8 +450,16 @@ __device__ __forceinline__ void packed_gen_l31_body(const GenLayout& L, uint32_t
     }
 }
 
+// Register caps: one more wave per SIMD than hipcc's free allocation gives (k + t >= 12: 128 VGPRs = 4 waves instead of
+// 137 = 3; k + t >= 6: 96 = 5 waves instead of 101-113 = 4).  Measured, interleaved A/B on one box (tools/r02_ab_lb.sh):
+// (3,4,8) +3.4 %, (8,7,26) +3.6 %, (8,2,26) +2.5 % on the dual-role launch - the kernels are VALU-bound and the extra
+// wave hides more of the s_load / dependent-issue latency; the few spilled dwords it costs (32-64 B per lane) do not show.
+#ifndef SDA_LB_FOUR_FROM
+#define SDA_LB_FOUR_FROM 12
+#endif
+#define SDA_LB(K_, T_) __launch_bounds__(kThreads, ((K_) + (T_) >= SDA_LB_FOUR_FROM ? 4 : ((K_) + (T_) >= 6 ? 5 : 1)))
 template <int K, int T, int ROUNDS, bool VEC>
-__global__ __launch_bounds__(kThreads) void packed_gen_l31_kernel(GenLayout L, uint32_t n, ModParams mod,
+__global__ SDA_LB(K, T) void packed_gen_l31_kernel(GenLayout L, uint32_t n, ModParams mod,
                                                                   L31Params lp, MatArg M, DrbgKey key,
                                                                   uint64_t chunks, uint64_t batches) {
     packed_gen_l31_body<K, T, ROUNDS, VEC>(L, n, mod, lp, M, key, chunks, batches, blockIdx.x);
@@ -671,7 +714,7 @@ __device__ __forceinline__ bool fuse_dispatch(const FuseArgs& F, uint64_t b, uin
 }
 
 template <int K, int T, int ROUNDS>
-__global__ __launch_bounds__(kThreads) void fused_packed_l31_kernel(GenLayout L, uint32_t n, ModParams mod, L31Params lp,
+__global__ SDA_LB(K, T) void fused_packed_l31_kernel(GenLayout L, uint32_t n, ModParams mod, L31Params lp,
                                                                     MatArg M, DrbgKey key, uint64_t chunks,
                                                                     uint64_t batches, FuseArgs F) {
     uint64_t idx;
