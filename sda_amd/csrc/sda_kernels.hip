@@ -771,6 +771,58 @@ __global__ __launch_bounds__(kThreads) void packed_reconstruct_kernel(const int6
     }
 }
 
+// The same for small (k, n'): one lane = two adjacent batches, the n' share pairs fetched ONCE with 16-byte loads and
+// kept in registers, the 2k secrets of a workgroup's 512 batches staged in LDS and written as 16-byte coalesced stores
+// (the naive form stores with stride k).  R (k x n', Montgomery form) is wave-uniform: scalar loads.
+template <int NMAX>
+__global__ __launch_bounds__(kThreads) void packed_reconstruct_vec_kernel(const int64_t* __restrict__ shares, size_t row_stride,
+                                                                          uint32_t n_rows, uint32_t k, size_t batches,
+                                                                          size_t dimension, ModParams mod, MontParams mont,
+                                                                          const uint64_t* __restrict__ Rm,
+                                                                          int64_t* __restrict__ out) {
+    extern __shared__ int64_t stage[];                    // [2 * kThreads][k] = the block's secrets in output order
+    const size_t b0 = 2 * ((size_t)blockIdx.x * kThreads + threadIdx.x);
+    uint64_t v0[NMAX], v1[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+        v0[c] = v1[c] = 0;
+        if ((uint32_t)c < n_rows && b0 < batches) {
+            if (b0 + 1 < batches) {
+                const ll2 v = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(shares + (size_t)c * row_stride + b0));
+                v0[c] = canon_i64(v.x, mod.m, mod.mu); v1[c] = canon_i64(v.y, mod.m, mod.mu);
+            } else {
+                v0[c] = canon_i64(shares[(size_t)c * row_stride + b0], mod.m, mod.mu);
+            }
+        }
+    }
+    for (uint32_t e = 0; e < k; ++e) {
+        U128 a0{0, 0}, a1{0, 0};
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) {
+            if ((uint32_t)c < n_rows) {                   // wave-uniform
+                const uint64_t r = Rm[(size_t)e * n_rows + c];
+                mac128(a0, r, v0[c]); mac128(a1, r, v1[c]);
+                if ((c & 3) == 3) { mont_acc_condsub(a0, mont.p); mont_acc_condsub(a1, mont.p); }
+            }
+        }
+        mont_acc_condsub(a0, mont.p); mont_acc_condsub(a1, mont.p);
+        stage[(size_t)(2 * threadIdx.x) * k + e] = (int64_t)mont_redc(a0, mont.p, mont.pinv);
+        stage[(size_t)(2 * threadIdx.x + 1) * k + e] = (int64_t)mont_redc(a1, mont.p, mont.pinv);
+    }
+    __syncthreads();
+    // the block's 2 * kThreads * k secrets are contiguous in `out`, from element base (a multiple of 2: 16-byte aligned)
+    const size_t base = (size_t)blockIdx.x * 2 * kThreads * k;
+    const size_t total = (size_t)2 * kThreads * k;
+    for (size_t i = 2 * (size_t)threadIdx.x; i < total; i += 2 * kThreads) {
+        if (base + i + 1 < dimension) {                   // truncate padding (batched.rs:94)
+            ll2 v; v.x = stage[i]; v.y = stage[i + 1];
+            *reinterpret_cast<ll2*>(out + base + i) = v;
+        } else if (base + i < dimension) {
+            out[base + i] = stage[i];
+        }
+    }
+}
+
 // =================================================================================================
 // K6  element-wise (a +- b) mod m
 // =================================================================================================
@@ -1483,6 +1535,20 @@ hipError_t launch_packed_reconstruct(const int64_t* d_shares, size_t row_stride,
                                      size_t batches, size_t dimension, const ModParams& mod, const MontParams& mont,
                                      const uint64_t* d_Rmont, int64_t* d_out, hipStream_t s) {
     if (batches == 0) return hipSuccess;
+    // small shapes (the BASELINE ones): vector loads, registers, LDS-staged coalesced stores
+    const bool vec = n_rows <= 16 && k <= 16 && aligned16(d_shares) && aligned16(d_out) && row_stride % 2 == 0;
+    if (vec) {
+        const uint64_t vblocks = ceil_div(ceil_div(batches, 2), kThreads);
+        if (hipError_t e = grid_check(vblocks)) return e;
+        const size_t lds = (size_t)2 * kThreads * k * 8;
+        if (n_rows <= 4)
+            packed_reconstruct_vec_kernel<4><<<dim3((unsigned)vblocks), dim3(kThreads), lds, s>>>(d_shares, row_stride, n_rows, k, batches, dimension, mod, mont, d_Rmont, d_out);
+        else if (n_rows <= 8)
+            packed_reconstruct_vec_kernel<8><<<dim3((unsigned)vblocks), dim3(kThreads), lds, s>>>(d_shares, row_stride, n_rows, k, batches, dimension, mod, mont, d_Rmont, d_out);
+        else
+            packed_reconstruct_vec_kernel<16><<<dim3((unsigned)vblocks), dim3(kThreads), lds, s>>>(d_shares, row_stride, n_rows, k, batches, dimension, mod, mont, d_Rmont, d_out);
+        return hipGetLastError();
+    }
     const uint64_t blocks = ceil_div(batches, kThreads);
     if (hipError_t e = grid_check(blocks)) return e;
     packed_reconstruct_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, s>>>(d_shares, row_stride, n_rows, k, batches,
