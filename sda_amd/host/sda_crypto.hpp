@@ -168,6 +168,72 @@ struct StreamingShareCombiner {
     }
 };
 
+// client/src/crypto/encryption/sodium.rs:33-46, :72-92: ShareEncryptor::encrypt = varint encode +
+// sealedbox::seal (:43); ShareDecryptor::decrypt = sealedbox::open (:78; Err("Sodium decryption failure") :80) + decode
+using EncryptionKey = std::vector<uint8_t>;         // 32 bytes, EncryptionKey::Sodium
+using DecryptionKey = std::vector<uint8_t>;         // 32 bytes, DecryptionKey::Sodium
+using Encryption = std::vector<uint8_t>;            // Encryption::Sodium(Binary)
+struct SealedBox {
+    sda_sealedbox_t* h = nullptr;
+    SealedBox() { detail::check(sda_sealedbox_new(&h)); }
+    ~SealedBox() { sda_sealedbox_free(h); }
+    SealedBox(const SealedBox&) = delete;
+    SealedBox& operator=(const SealedBox&) = delete;
+    Encryption seal(const std::vector<uint8_t>& m, const EncryptionKey& pk, const uint8_t* esk = nullptr) {
+        Encryption out(m.size() + SDA_SEALBYTES);
+        detail::check(sda_sealedbox_seal(h, pk.data(), esk, m.data(), m.size(), out.data(), out.size()));
+        return out;
+    }
+    std::vector<uint8_t> open(const Encryption& c, const EncryptionKey& pk, const DecryptionKey& sk) {
+        std::vector<uint8_t> out(c.size() + 1);
+        size_t n = 0;
+        detail::check(sda_sealedbox_open(h, pk.data(), sk.data(), c.data(), c.size(), out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+};
+struct ShareEncryptor {
+    EncryptionKey pk; SealedBox box; ShareCodec codec;
+    explicit ShareEncryptor(EncryptionKey k) : pk(std::move(k)) {}
+    Encryption encrypt(const std::vector<Share>& shares) { return box.seal(codec.encode(shares), pk); }
+};
+struct ShareDecryptor {
+    EncryptionKey pk; DecryptionKey sk; SealedBox box; ShareCodec codec;
+    ShareDecryptor(EncryptionKey p, DecryptionKey s) : pk(std::move(p)), sk(std::move(s)) {}
+    std::vector<Share> decrypt(const Encryption& e) { return codec.decode(box.open(e, pk, sk)); }
+};
+
+// The clerking job as one binary blob: what server/src/stores.rs:86-101 would emit instead of
+// Vec<Vec<Encryption>>; layout in sda_hip.h ("SDAJOBv1").
+struct JobContainer {
+    std::vector<uint8_t> blob;
+    sda_job_layout_t layout{};
+    static JobContainer build(uint32_t kind, const std::vector<std::vector<uint8_t>>& payloads) {
+        size_t longest = 0;
+        for (const auto& p : payloads) longest = p.size() > longest ? p.size() : longest;
+        JobContainer j;
+        const size_t slot = sda_job_slot_size(longest);
+        const size_t size = sda_job_container_size(payloads.size(), slot);
+        j.blob.resize(size < 64 ? 64 : size);
+        detail::check(sda_job_container_init(j.blob.data(), j.blob.size(), kind, payloads.size(), slot, &j.layout));
+        for (size_t r = 0; r < payloads.size(); ++r)
+            detail::check(sda_job_container_set_row(j.blob.data(), r, payloads[r].data(), payloads[r].size()));
+        return j;
+    }
+    static JobContainer parse(std::vector<uint8_t> bytes) {
+        JobContainer j;
+        j.blob = std::move(bytes);
+        detail::check(sda_job_container_parse(j.blob.data(), j.blob.size(), &j.layout));
+        return j;
+    }
+    std::vector<uint8_t> row(size_t r) const {
+        const uint8_t* p = nullptr;
+        size_t n = 0;
+        detail::check(sda_job_container_get_row(blob.data(), blob.size(), r, &p, &n));
+        return std::vector<uint8_t>(p, p + n);
+    }
+};
+
 struct SecretReconstructor {
     sda_secret_reconstructor_t* h = nullptr;
     size_t dimension;

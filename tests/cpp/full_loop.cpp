@@ -93,6 +93,41 @@ int main() {
             EXPECT(false, "a payload of the wrong length must fail");
         } catch (const SdaClientError& e) { EXPECT(std::string(e.what()) == "Wrong dimension", "combiner.rs:21 on the wire form"); }
     }
+    // the reference's full path for a clerk: participants seal their varint-encoded share vectors to the clerk's key
+    // (participate.rs:82-101, sodium.rs:33-46), the server hands the clerk ONE job (here an SDAJOBv1 blob instead of a
+    // JSON array, stores.rs:86-101), the clerk decrypts and combines (clerk.rs:78-86, sodium.rs:72-92)
+    {
+        // a key pair: the public key is X25519(sk, 9) = the first 32 bytes of a box sealed with esk = sk
+        DecryptionKey sk(32);
+        for (int i = 0; i < 32; ++i) sk[i] = (uint8_t)(7 * i + 1);
+        SealedBox kb;
+        const Encryption probe = kb.seal({}, EncryptionKey(32, 0), sk.data());
+        const EncryptionKey pk(probe.begin(), probe.begin() + 32);
+        ShareGenerator gen(add);
+        ShareEncryptor enc(pk);
+        ShareDecryptor dec(pk, sk);
+        std::vector<std::vector<uint8_t>> job_rows;
+        std::vector<std::vector<int64_t>> clear;
+        for (const auto& secrets : two) {
+            const auto shares = gen.generate(secrets);
+            clear.push_back(shares[0]);
+            job_rows.push_back(enc.encrypt(shares[0]));                 // clerk 0's encryption of this participation
+            EXPECT(job_rows.back().size() > SDA_SEALBYTES, "sealed payload");
+        }
+        const JobContainer sent = JobContainer::build(SDA_JOB_SEALED, job_rows);
+        const JobContainer got = JobContainer::parse(sent.blob);
+        EXPECT(got.layout.rows == 2 && got.layout.payload_kind == SDA_JOB_SEALED, "job container header");
+        std::vector<std::vector<int64_t>> opened;
+        for (size_t r = 0; r < got.layout.rows; ++r) opened.push_back(dec.decrypt(got.row(r)));
+        EXPECT(opened == clear, "seal -> SDAJOBv1 -> open -> decode round trip");
+        EXPECT(ShareCombiner(add).combine(opened) == ShareCombiner(add).combine(clear), "clerk sums over decrypted shares");
+        Encryption bad = job_rows[0];
+        bad[40] ^= 1;
+        try {
+            dec.decrypt(bad);
+            EXPECT(false, "a tampered encryption must fail");
+        } catch (const SdaClientError& e) { EXPECT(std::string(e.what()) == "Sodium decryption failure", "sodium.rs:80"); }
+    }
     // error behaviour mirrors the reference's strings
     try {
         ShareCombiner(add).combine({{1, 2, 3}, {1, 2}});
