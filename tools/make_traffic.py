@@ -26,7 +26,7 @@ for w in sorted(os.listdir(root)):
     entry = {}
     for kern, grids in per.items():
         # the steady-state grid: the largest one (both roles for the dual-role kernels: n_gen + n_comb workgroups)
-        grid, c = max(grids.items(), key=lambda kv: int(kv[0]))
+        grid, c = max(grids.items(), key=lambda kv: int(kv[0].split()[-1]))
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             continue
         fetch = c["FETCH_SIZE"]["mean_KiB"] * 1024 * 2
