@@ -463,7 +463,8 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     gen_gbs = per_launch * gen_b / (gen_ms * 1e-3) / 1e9
     comb_gbs = per_launch * comb_b / (comb_ms * 1e-3) / 1e9
     dominant_gen = gen_ms >= comb_ms
-    gen_kernel = ("packed_gen_l31_kernel" if w["kind"] == "packed" else "additive_gen_kernel")
+    gen_kernel = ("additive_gen_kernel" if w["kind"] != "packed" else
+                  "packed_gen_l31_kernel" if w["k"] + w["t"] <= 32 else "packed_gen_fft_kernel")
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
                 "share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares" if overlap
                 else "one stream, serial")
