@@ -29,6 +29,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC; must be in the environment before the HIP runtime starts (RCCL across processes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 P62 = 4611686006577364993
 OMEGA = {8: 631229665360524489, 9: 3451275676410824977, 16: 2589100645267092065, 27: 365137883145458390,
@@ -153,28 +155,50 @@ class Env:
         self.lib = capi.load()
         capi.check(self.lib.sda_set_device(device_index))
         self.comm = C.c_void_p()
+        self.exchange = "none (one rank)" if self.world == 1 else "host-staged over gloo (ranks share one GPU)"
         if not self.share_gpu:
-            ident = (C.c_uint8 * 128)()
-            if self.rank == 0:
-                capi.check(self.lib.sda_comm_unique_id(ident))
-            box = [bytes(ident)]
-            if self.use_dist:
-                dist.broadcast_object_list(box, src=0)
             # RCCL prints its version banner to the C stdout at init: keep stdout for the ONE JSON line
             sys.stdout.flush()
             saved = os.dup(1)
             os.dup2(2, 1)
+            ok = 1
             try:
-                capi.check(self.lib.sda_comm_init((C.c_uint8 * 128)(*box[0]), self.rank, self.world, C.byref(self.comm)))
+                ident = (C.c_uint8 * 128)()
+                if self.rank == 0 and self.lib.sda_comm_unique_id(ident) != capi.OK:
+                    ok = 0
+                box = [bytes(ident)]
+                if self.use_dist:
+                    dist.broadcast_object_list(box, src=0)
+                if self.lib.sda_comm_init((C.c_uint8 * 128)(*box[0]), self.rank, self.world, C.byref(self.comm)) != capi.OK:
+                    ok = 0
                 C.CDLL(None).fflush(None)
             finally:
                 os.dup2(saved, 1)
                 os.close(saved)
+            if self.use_dist:                                        # every rank takes the same path
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                if self.world > 1:
+                    self.exchange = "RCCL send/recv reduce-scatter + modular-sum kernel + all-gather, behind the C ABI"
+            else:
+                # the library's RCCL communicator could not be set up on this node: say so loudly and keep the run alive with
+                # the exchange staged through host memory (the modular sum of the slices still runs on the device)
+                msg = self.lib.sda_last_error().decode()
+                print(f"[bench] rank {self.rank}: sda_comm_init failed ({msg}); exchange falls back to host staging over gloo",
+                      file=sys.stderr, flush=True)
+                if self.comm:
+                    self.lib.sda_comm_free(self.comm)
+                self.comm = C.c_void_p()
+                self.exchange = "host-staged over gloo (RCCL communicator unavailable: " + msg[:80] + ")"
+                if not self.use_dist:
+                    raise SystemExit("sda_comm_init failed: " + msg)
 
     def modular_allreduce(self, t):
         """sum over ranks mod P62 of the int64 device tensor `t`, on every rank (new tensor)"""
         torch = self.torch
-        if self.share_gpu and self.use_dist:
+        if self.use_dist and not self.comm:
             from sda_amd.distributed import modular_allreduce
             return modular_allreduce(t, P62)
         out = torch.empty_like(t)
@@ -279,8 +303,8 @@ def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, s
                    "share_count": n, "secret_count": k, "privacy_threshold": t, "modulus": P62,
                    "randomness": f"on-device ChaCha{rounds} (sda-drbg-v1, deterministic bench key)",
                    "row_stride_elements": Bs, "schedule": schedule,
-                   "parallelism": f"participants sharded x{world}, one modular reduce (RCCL all-to-all + exact modular "
-                                  f"sum + all-gather, behind the C ABI) at the end"},
+                   "parallelism": f"participants sharded x{world}, one modular reduce of the clerk sums at the end",
+                   "exchange": env.exchange},
         "path_roofline": {"bytes_per_element": gen_b + comb_b,
                           "achieved_GBps": value / world * (gen_b + comb_b) / 1e9,
                           "frac_of_hbm_peak": value / world * (gen_b + comb_b) / 1e9 / HBM_PEAK_GBS},
@@ -343,7 +367,11 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     for i in range(tiles + 1):
         launch(i, tiles, evs[2 * i:2 * i + 2])
     comb.finish_dev(sums.data_ptr())
+    torch.cuda.synchronize(dev)
+    tx = time.perf_counter()
     total = env.modular_allreduce(sums)                      # X1: the only exchange step
+    torch.cuda.synchronize(dev)
+    exchange_ms = (time.perf_counter() - tx) * 1e3
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
     ms = C.c_float()
@@ -375,6 +403,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
                                "sums), achieved = K x algorithmic_bytes_per_launch / sum of the K+1 launch durations"}
     res["verified_reconstruct_equals_sum"] = verified
     res["reveal"] = reveal
+    res["exchange_ms"] = env.max_over_ranks(exchange_ms)      # the cross-GPU modular reduce, inside the timed region
     del secrets, shares, sums, total
     torch.cuda.empty_cache()
     return res
@@ -445,7 +474,10 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
         step(i, i % nbuf, evs[4 * i:4 * i + 4])
     comb.finish_dev(sums.data_ptr(), h_comb or 0)
     torch.cuda.synchronize(dev)
+    tx = time.perf_counter()
     total = env.modular_allreduce(sums)
+    torch.cuda.synchronize(dev)
+    exchange_ms = (time.perf_counter() - tx) * 1e3
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
     gen_ms = comb_ms = 0.0
@@ -481,6 +513,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
                                     "frac_of_hbm_peak": comb_gbs / HBM_PEAK_GBS}}
     res["verified_reconstruct_equals_sum"] = verified
     res["reveal"] = reveal
+    res["exchange_ms"] = env.max_over_ranks(exchange_ms)      # the cross-GPU modular reduce, inside the timed region
     del secrets, shares, sums, total
     torch.cuda.empty_cache()
     return res
