@@ -99,10 +99,10 @@ __global__ __launch_bounds__(64) void sbox_setup_seal_kernel(const uint8_t* __re
 __global__ __launch_bounds__(kSbThreads) void sbox_stream_kernel(const uint8_t* __restrict__ in, size_t in_slot, size_t in_off,
                                                                  uint8_t* __restrict__ out, size_t out_slot, size_t out_off,
                                                                  const uint64_t* __restrict__ lens, uint64_t len_sub,
-                                                                 const SboxState* __restrict__ states, size_t row0) {
+                                                                 uint64_t max_msg, const SboxState* __restrict__ states, size_t row0) {
     const size_t r = row0 + blockIdx.y;
     const uint64_t have = lens[r];
-    if (have < len_sub) return;
+    if (have < len_sub || have - len_sub > max_msg) return;        // a row longer than the caller's bound is refused, never read
     const uint64_t mlen = have - len_sub;
     const uint64_t J = (uint64_t)blockIdx.x * kSbThreads + threadIdx.x;     // Salsa20 block: message bytes [64 J - 32, 64 J + 32)
     const uint64_t a = J ? 64 * J - 32 : 0;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kSbThreads) void sbox_stream_kernel(const uint8_t* 
 
 // Poly1305 partial sums over the ciphertext (row r at ct + r * slot + off, lens[r] - len_sub bytes)
 __global__ __launch_bounds__(kSbThreads) void sbox_poly_kernel(const uint8_t* __restrict__ ct, size_t slot, size_t off,
-                                                               const uint64_t* __restrict__ lens, uint64_t len_sub,
+                                                               const uint64_t* __restrict__ lens, uint64_t len_sub, uint64_t max_msg,
                                                                const SboxState* __restrict__ states, uint32_t* __restrict__ partial,
                                                                size_t regions, size_t row0) {
     const size_t r = row0 + blockIdx.y;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kSbThreads) void sbox_poly_kernel(const uint8_t* __
     const size_t region = (size_t)blockIdx.x * (kSbThreads / 64) + (threadIdx.x >> 6);
     if (region >= regions) return;
     const uint64_t have = lens[r];
-    const uint64_t mlen = have >= len_sub ? have - len_sub : 0;
+    const uint64_t mlen = (have >= len_sub && have - len_sub <= max_msg) ? have - len_sub : 0;   // over-long rows: refused in final
     const uint64_t npieces = (mlen + 15) / 16;
     const uint32_t tail = (uint32_t)(mlen & 15);                             // bytes of the last piece (0 = full)
     const SboxState& st = states[r];
@@ -203,15 +203,15 @@ __global__ __launch_bounds__(kSbThreads) void sbox_poly_kernel(const uint8_t* __
 // SEAL: store the tag, row_bytes_out[r] = message length + 48.
 __global__ __launch_bounds__(64) void sbox_final_kernel(const uint32_t* __restrict__ partial, size_t regions,
                                                         const SboxState* __restrict__ states, uint8_t* __restrict__ boxes, size_t slot,
-                                                        const uint64_t* __restrict__ lens, uint64_t len_sub, size_t rows, int seal,
+                                                        const uint64_t* __restrict__ lens, uint64_t len_sub, uint64_t max_msg, size_t rows, int seal,
                                                         uint64_t* __restrict__ out_bytes, uint32_t* __restrict__ ok,
                                                         uint32_t* __restrict__ status) {
     const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (r >= rows) return;
     const SboxState& st = states[r];
     const uint64_t have = lens[r];
-    bool good = have >= len_sub && !st.bad;
-    const uint64_t mlen = have >= len_sub ? have - len_sub : 0;
+    bool good = have >= len_sub && have - len_sub <= max_msg && !st.bad;    // longer than the launch was sized for: refused
+    const uint64_t mlen = good ? have - len_sub : 0;
     uint32_t tag[4] = {0, 0, 0, 0};
     if (good) {
         const size_t used = (size_t)(((mlen + 15) / 16 + 64 * kPolySteps - 1) / (64 * kPolySteps));
@@ -230,15 +230,19 @@ __global__ __launch_bounds__(64) void sbox_final_kernel(const uint32_t* __restri
     }
     uint32_t* box_tag = reinterpret_cast<uint32_t*>(boxes + r * slot + 32);
     if (seal) {
+        if (good) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) box_tag[i] = tag[i];
-        out_bytes[r] = mlen + 48;
+            for (int i = 0; i < 4; ++i) box_tag[i] = tag[i];
+        }
+        out_bytes[r] = good ? mlen + 48 : 0;                   // a message longer than the launch was sized for is not sealed
         return;
     }
-    uint32_t diff = 0;
+    if (good) {                                                // the tag is only read from a box that has one
+        uint32_t diff = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) diff |= tag[i] ^ box_tag[i];
-    good = good && diff == 0;
+        for (int i = 0; i < 4; ++i) diff |= tag[i] ^ box_tag[i];
+        good = diff == 0;
+    }
     out_bytes[r] = good ? mlen : 0;
     if (ok) ok[r] = good ? 1u : 0u;
     if (!good) atomicOr(status, 16u);
@@ -265,12 +269,12 @@ static hipError_t bulk(const uint8_t* d_in, size_t in_slot, size_t in_off, uint8
         const unsigned nr = (unsigned)(rows - r0 < 65535 ? rows - r0 : 65535);
         if (stream_first && max_msg)
             sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), 0, s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
-                                                                                        d_lens, len_sub, d_states, r0);
-        sbox_poly_kernel<<<dim3((unsigned)pblocks, nr), dim3(kSbThreads), 0, s>>>(d_ct, ct_slot, ct_off, d_lens, len_sub, d_states,
+                                                                                        d_lens, len_sub, max_msg, d_states, r0);
+        sbox_poly_kernel<<<dim3((unsigned)pblocks, nr), dim3(kSbThreads), 0, s>>>(d_ct, ct_slot, ct_off, d_lens, len_sub, max_msg, d_states,
                                                                                   d_partial, regions, r0);
         if (!stream_first && max_msg)
             sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), 0, s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
-                                                                                        d_lens, len_sub, d_states, r0);
+                                                                                        d_lens, len_sub, max_msg, d_states, r0);
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
@@ -292,7 +296,7 @@ hipError_t launch_sealedbox_open(const uint8_t pk[32], const uint8_t sk[32], con
                             d_partial, false, s))
         return e;
     sbox_final_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_partial, sbox_regions(max_msg), d_states,
-                                                                           const_cast<uint8_t*>(d_boxes), slot, d_row_bytes, 48, rows, 0,
+                                                                           const_cast<uint8_t*>(d_boxes), slot, d_row_bytes, 48, max_msg, rows, 0,
                                                                            d_out_bytes, d_ok, d_status);
     return hipGetLastError();
 }
@@ -310,7 +314,7 @@ hipError_t launch_sealedbox_seal(const uint8_t* d_esk, const uint8_t* d_pks, siz
                             d_partial, true, s))
         return e;
     sbox_final_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_partial, sbox_regions(max_msg_bytes), d_states, d_boxes, slot,
-                                                                           d_msg_bytes, 0, rows, 1, d_row_bytes, nullptr, nullptr);
+                                                                           d_msg_bytes, 0, max_msg_bytes, rows, 1, d_row_bytes, nullptr, nullptr);
     return hipGetLastError();
 }
 

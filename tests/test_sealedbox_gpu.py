@@ -137,6 +137,33 @@ def test_rows_tamper_and_short_rows(gpu):
             assert ob[r * out_slot:r * out_slot + len(msgs[r])] == msgs[r]
 
 
+def test_rows_longer_than_the_declared_bound_are_refused_not_read(gpu):
+    """a row whose length field exceeds max_box_bytes (a lying job header) fails closed: flagged, length 0, and the
+    kernels never touch bytes past the bound (the rows behind it stay intact and still open)"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBytes
+    from oracle import sealedbox_oracle as so
+    rng = random.Random(12)
+    rb = lambda n: bytes(rng.getrandbits(8) for _ in range(n))
+    sk = rb(32); pk = so.x25519_base(sk)
+    msgs = [rb(100), rb(200), rb(50)]
+    boxes = [so.seal(m, pk, rb(32)) for m in msgs]
+    slot = 256
+    blob = bytearray(3 * slot)
+    for r, b in enumerate(boxes):
+        blob[r * slot:r * slot + len(b)] = b
+    lens = np.array([len(boxes[0]), 1 << 40, len(boxes[2])], dtype="<u8")          # row 1 claims a terabyte
+    d_boxes, d_lens = DeviceBytes.from_bytes(blob), DeviceBytes.from_bytes(lens.tobytes())
+    d_out, d_nb = DeviceBytes(3 * 256).zero(), DeviceBytes(24).zero()
+    d_ok, d_status = DeviceBytes(12).zero(), DeviceBytes(4).zero()
+    crypto.SealedBox().open_rows_dev(pk, sk, d_boxes.ptr, slot, d_lens.ptr, 3, 248, d_out.ptr, 256, d_nb.ptr, d_status.ptr, d_ok.ptr)
+    assert list(np.frombuffer(d_ok.to_bytes(), dtype="<u4")) == [1, 0, 1]
+    assert list(np.frombuffer(d_nb.to_bytes(), dtype="<u8")) == [100, 0, 50]
+    ob = d_out.to_bytes()
+    assert ob[:100] == msgs[0] and ob[512:562] == msgs[2] and ob[256:512] == bytes(256)
+    assert np.frombuffer(d_status.to_bytes(), dtype="<u4")[0] == 16
+
+
 def test_clerking_job_open_decode_sum_on_the_device(gpu):
     """clerk.rs:78-86 with the job resident in HBM: P sealed share vectors (participate.rs:82-101: varint + seal per
     clerk) -> batch open -> streaming varint clerk sums; equals the oracle's combine of the plaintext shares.  The
