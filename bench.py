@@ -577,8 +577,19 @@ def main():
             line["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.dim or WORKLOADS[args.workload].get("dim", 1 << 20))
         else:
             line["cpu_baseline"] = None
+    # tear the communicator down with the C stdout pointed at stderr (RCCL may print there), so that the JSON line is
+    # the one and LAST thing on stdout
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        env.close()
+        C.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    if env.rank == 0:
         print(json.dumps(line), flush=True)
-    env.close()
 
 
 if __name__ == "__main__":

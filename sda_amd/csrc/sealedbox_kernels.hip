@@ -95,40 +95,59 @@ __global__ __launch_bounds__(64) void sbox_setup_seal_kernel(const uint8_t* __re
     derive_state(states[r], shared, nonce);
 }
 
-// XSalsa20 xor: in row r at in + r * in_slot + in_off, out likewise; the message of row r has lens[r] - len_sub bytes
+// XSalsa20 xor: in row r at in + r * in_slot + in_off, out likewise; the message of row r has lens[r] - len_sub bytes.
+// One lane computes one 64-byte Salsa20 block (block J covers message bytes [64 J - 32, 64 J + 32): four whole 16-byte
+// pieces); the wave's 64 blocks go through a transposed LDS tile so that the global loads and stores are lane-contiguous
+// 16-byte pieces (1 KiB per wave-instruction) instead of 64-byte-strided ones.
 __global__ __launch_bounds__(kSbThreads) void sbox_stream_kernel(const uint8_t* __restrict__ in, size_t in_slot, size_t in_off,
                                                                  uint8_t* __restrict__ out, size_t out_slot, size_t out_off,
                                                                  const uint64_t* __restrict__ lens, uint64_t len_sub,
                                                                  uint64_t max_msg, const SboxState* __restrict__ states, size_t row0) {
+    __shared__ uint32_t tile[kSbThreads / 64][16][65];                      // [wave][word][block], padded rows
     const size_t r = row0 + blockIdx.y;
     const uint64_t have = lens[r];
-    if (have < len_sub || have - len_sub > max_msg) return;        // a row longer than the caller's bound is refused, never read
-    const uint64_t mlen = have - len_sub;
-    const uint64_t J = (uint64_t)blockIdx.x * kSbThreads + threadIdx.x;     // Salsa20 block: message bytes [64 J - 32, 64 J + 32)
+    const bool live = have >= len_sub && have - len_sub <= max_msg;         // a row longer than the caller's bound is refused, never read
+    const uint64_t mlen = live ? have - len_sub : 0;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t J0 = (uint64_t)blockIdx.x * kSbThreads + (uint64_t)wave * 64;   // first Salsa20 block of this wave
+    const uint64_t J = J0 + lane;
     const uint64_t a = J ? 64 * J - 32 : 0;
-    if (a >= mlen) return;
-    const SboxState& st = states[r];
-    uint32_t key[8];
+    if (a < mlen) {
+        const SboxState& st = states[r];
+        uint32_t key[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) key[i] = st.subkey[i];                      // wave-uniform: scalar loads
-    uint32_t ks[16];
-    salsa20_block(ks, key, st.n0, st.n1, J);
-    const uint8_t* src = in + r * in_slot + in_off + a;
-    uint8_t* dst = out + r * out_slot + out_off + a;
-    const int first = J ? 0 : 2;                                            // block 0: its first 32 bytes are the Poly1305 key
+        for (int i = 0; i < 8; ++i) key[i] = st.subkey[i];                  // wave-uniform: scalar loads
+        uint32_t ks[16];
+        salsa20_block(ks, key, st.n0, st.n1, J);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tile[wave][w][lane] = ks[w];
+    }
+    __syncthreads();
+    if (mlen == 0) return;
+    const uint8_t* src = in + r * in_slot + in_off;
+    uint8_t* dst = out + r * out_slot + out_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (i < first) continue;
-        const uint64_t p = (uint64_t)16 * (i - first);
-        if (a + p >= mlen) break;
-        const uint64_t n = mlen - a - p;
+        const uint32_t sp = lane + 64 * i;                                  // 16-byte piece of the wave's 4 KiB of key stream
+        const uint64_t spos = 64 * J0 + 16 * (uint64_t)sp;                  // its stream offset; message offset = stream offset - 32
+        if (spos < 32) continue;                                            // stream bytes 0..31 are the Poly1305 key
+        const uint64_t m = spos - 32;
+        if (m >= mlen) continue;
+        const uint32_t blk = sp >> 2, w0 = (sp & 3) * 4;
+        const uint32_t k0 = tile[wave][w0][blk], k1 = tile[wave][w0 + 1][blk], k2 = tile[wave][w0 + 2][blk], k3 = tile[wave][w0 + 3][blk];
+        const uint64_t n = mlen - m;
         if (n >= 16) {
-            uint4 v = *reinterpret_cast<const uint4*>(src + p);
-            v.x ^= ks[4 * i]; v.y ^= ks[4 * i + 1]; v.z ^= ks[4 * i + 2]; v.w ^= ks[4 * i + 3];
-            *reinterpret_cast<uint4*>(dst + p) = v;
+            uint4 v = *reinterpret_cast<const uint4*>(src + m);
+            v.x ^= k0; v.y ^= k1; v.z ^= k2; v.w ^= k3;
+            *reinterpret_cast<uint4*>(dst + m) = v;
         } else {
-            for (uint32_t b = 0; b < (uint32_t)n; ++b)
-                dst[p + b] = src[p + b] ^ (uint8_t)(ks[4 * i + (b >> 2)] >> (8 * (b & 3)));
+            const uint32_t kk[4] = {k0, k1, k2, k3};
+            for (uint32_t bb = 0; bb < (uint32_t)n; ++bb) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) word = (bb >> 2) == (uint32_t)q ? kk[q] : word;
+                dst[m + bb] = src[m + bb] ^ (uint8_t)(word >> (8 * (bb & 3)));
+            }
         }
     }
 }

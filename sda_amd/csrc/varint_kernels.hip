@@ -530,8 +530,10 @@ __device__ __forceinline__ bool stream_row_range(const uint8_t* __restrict__ byt
                                                  const RowRanges& rr, uint64_t r, uint64_t len,
                                                  uint32_t* __restrict__ status, uint64_t& a, uint64_t& b) {
     const bool lead = (threadIdx.x & 63) == 0;
-    if (rr.lengths) { a = r * rr.slot; b = a + rr.lengths[r]; }
-    else { a = rr.offsets ? rr.offsets[r] : 0; b = rr.offsets ? rr.offsets[r + 1] : n_bytes; }
+    if (rr.lengths) {
+        a = r * rr.slot; b = a + rr.lengths[r];
+        if (rr.lengths[r] > rr.slot) { if (lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return false; }   // a row never leaves its slot
+    } else { a = rr.offsets ? rr.offsets[r] : 0; b = rr.offsets ? rr.offsets[r + 1] : n_bytes; }
     if (b < a || b > n_bytes) { if (lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return false; }
     if (len == 0) { if (a != b && lead) atomicOr(status, SDA_VARINT_ROW_COUNT); return false; }
     if (a == b || (bytes[b - 1] & 0x80u)) { if (lead) atomicOr(status, SDA_VARINT_UNTERMINATED); return false; }

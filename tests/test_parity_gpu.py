@@ -203,6 +203,33 @@ def test_transform_share_generation_vs_oracle(gpu, monkeypatch, p, k, t, n, w2, 
     assert np.array_equal(rec, sec2[0])
 
 
+@pytest.mark.parametrize("dim", [1, 39, 40, 40 * 7 + 3, 40 * 8, 40 * 9 - 1, 40 * 16 + 5])
+def test_transform_group_boundaries(gpu, dim):
+    """the transform kernel's groups of 8 batches (one CSPRNG block per draw serves a group): 1 batch, 7, 8, 9, 17 - ragged
+    groups, zero padding of the last batch (batched.rs:37-43), several participants with distinct streams, large stream ids"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    k, t, n = 40, 23, 242
+    w2, w3 = _root(P62, k + t + 1), _root(P62, n + 1)
+    gen = crypto.ShareGenerator(crypto.PackedShamir(k, n, t, P62, w2, w3))
+    gen.set_drbg_key(KEY)
+    rng = np.random.default_rng(dim)
+    P, first = 3, (1 << 40) + 12345
+    B = gen.batch_count(dim)
+    stride = dim + 3                                               # odd participant stride, unaligned rows
+    sec = rng.integers(-(1 << 62), 1 << 62, size=(P, stride), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec)
+    Bs = B + 5
+    d_out = DeviceBuffer(P * n * Bs).zero()
+    gen.generate_batch_dev(d_sec.ptr, P, dim, stride, d_out.ptr, n * Bs, Bs, first_participant=first)
+    out = d_out.to_numpy().reshape(P, n, Bs)
+    for q in range(P):
+        want = coracle.packed_generate(P62, k, t, n, w2, w3, sec[q, :dim], coracle.drbg_fill(KEY, first + q, B, t, P62))
+        assert np.array_equal(out[q, :, :B], want), f"participant {q}"
+    assert not out[:, :, B:].any()
+
+
 def test_small_prime_packed_matches_tss_fft_path(gpu):
     """p = 433 (full_loop.rs:57-64): the matrix form on the GPU equals the recalled tss FFT path."""
     from sda_amd import crypto
