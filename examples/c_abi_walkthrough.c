@@ -1,7 +1,8 @@
 /* The reference's README walkthrough (README.md:86-157: dimension 10, modulus 433, additive sharing over 3 clerks,
  * three participants submitting 0..9, zeros and 0 1 0 1 ..., expected result 0 2 2 4 4 6 6 8 8 10) and its
  * packed-Shamir integration vector (full_loop.rs:54-67,148) through nothing but the C ABI of include/sda_hip.h -
- * the calls a Rust `extern "C"` shim, cgo or any other FFI would make.  Plain C99.
+ * the calls a Rust `extern "C"` shim, cgo or any other FFI would make - and a clerk's job with sealed payloads
+ * (varint + sealed box per participant, one SDAJOBv1 blob, open -> streaming clerk sum).  Plain C99.
  *
  *   gcc -std=c99 -I include examples/c_abi_walkthrough.c -L sda_amd/lib -lsda_hip -Wl,-rpath,$PWD/sda_amd/lib -o walkthrough
  */
@@ -107,6 +108,65 @@ int main(void) {
         const int64_t want[4] = {2, 4, 6, 8};
         if (run(&pss, &chacha, 4, &inputs[0][0], 2, answered, 7, out)) return 1;
         if (memcmp(out, want, sizeof want)) { printf("FAIL: packed Shamir + ChaCha mask\n"); ++failures; }
+    }
+    {   /* a clerk's job with the payloads sealed (participate.rs:82-101 -> stores.rs:86-101 -> clerk.rs:78-86): every
+         * participant varint-encodes and seals its share vector for clerk 0, the "server" packs the encryptions into one
+         * SDAJOBv1 blob, the clerk parses it, opens every box and streams the payloads into its running sum */
+        sda_sharing_scheme_t additive;
+        memset(&additive, 0, sizeof additive);
+        additive.kind = SDA_SHARING_ADDITIVE; additive.share_count = 3; additive.modulus = 433;
+        sda_share_generator_t* gen; sda_share_combiner_t* comb; sda_varint_codec_t* codec; sda_sealedbox_t* sbox;
+        CHECK(sda_share_generator_new(&additive, &gen));
+        CHECK(sda_share_combiner_new(&additive, &comb));
+        CHECK(sda_varint_codec_new(&codec));
+        CHECK(sda_sealedbox_new(&sbox));
+        uint8_t sk[32], pk[32], probe[SDA_SEALBYTES], zero_pk[32] = {0};
+        for (int i = 0; i < 32; ++i) sk[i] = (uint8_t)(3 * i + 7);
+        /* the public key X25519(sk, 9) is the first 32 bytes of a box sealed with the ephemeral secret sk (key generation
+         * itself stays with the reference's keystore) */
+        CHECK(sda_sealedbox_seal(sbox, zero_pk, sk, NULL, 0, probe, sizeof probe));
+        memcpy(pk, probe, 32);
+        const int64_t inputs[3][10] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9}, {0}, {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}};
+        int64_t shares[3][10], clear_sum[10];
+        uint8_t wire[128], boxes[3][128 + SDA_SEALBYTES];
+        size_t box_len[3];
+        const size_t slot = sda_job_slot_size(128 + SDA_SEALBYTES);
+        uint8_t* job = malloc(sda_job_container_size(3, slot));
+        sda_job_layout_t layout;
+        CHECK(sda_job_container_init(job, sda_job_container_size(3, slot), SDA_JOB_SEALED, 3, slot, &layout));
+        for (size_t p = 0; p < 3; ++p) {
+            int64_t all_shares[3 * 10];
+            size_t n_wire = 0;
+            CHECK(sda_share_generator_generate(gen, inputs[p], 10, NULL, 0, all_shares, 30));
+            memcpy(shares[p], all_shares, sizeof shares[p]);                                  /* clerk 0's vector */
+            CHECK(sda_varint_encode(codec, shares[p], 10, wire, sizeof wire, &n_wire));       /* sodium.rs:36-41 */
+            CHECK(sda_sealedbox_seal(sbox, pk, NULL, wire, n_wire, boxes[p], sizeof boxes[p]));   /* sodium.rs:43 */
+            box_len[p] = n_wire + SDA_SEALBYTES;
+            CHECK(sda_job_container_set_row(job, p, boxes[p], box_len[p]));
+        }
+        sda_job_layout_t got;
+        CHECK(sda_job_container_parse(job, layout.total_bytes, &got));
+        CHECK(sda_share_combiner_begin(comb, 10));
+        for (size_t p = 0; p < got.rows; ++p) {
+            const uint8_t* enc; size_t enc_len = 0, n_plain = 0;
+            uint8_t plain[128];
+            CHECK(sda_job_container_get_row(job, layout.total_bytes, p, &enc, &enc_len));
+            CHECK(sda_sealedbox_open(sbox, pk, sk, enc, enc_len, plain, sizeof plain, &n_plain));   /* sodium.rs:78 */
+            CHECK(sda_share_combiner_update_varint(comb, codec, plain, n_plain));              /* decode -> add -> discard */
+        }
+        int64_t sum[10];
+        CHECK(sda_share_combiner_finish(comb, sum));
+        {   const int64_t* rows[3] = {shares[0], shares[1], shares[2]};
+            const size_t lens[3] = {10, 10, 10};
+            size_t n_out = 0;
+            CHECK(sda_share_combiner_combine(comb, rows, lens, 3, clear_sum, 10, &n_out)); }
+        if (memcmp(sum, clear_sum, sizeof sum)) { printf("FAIL: sealed clerking job\n"); ++failures; }
+        boxes[1][40] ^= 1;                                                                     /* a tampered encryption */
+        {   uint8_t plain[128]; size_t n_plain = 0;
+            if (sda_sealedbox_open(sbox, pk, sk, boxes[1], box_len[1], plain, sizeof plain, &n_plain) != SDA_ERR_SODIUM_DECRYPTION ||
+                strcmp(sda_last_error(), "Sodium decryption failure") != 0) { printf("FAIL: tamper not detected\n"); ++failures; } }
+        free(job);
+        sda_share_generator_free(gen); sda_share_combiner_free(comb); sda_varint_codec_free(codec); sda_sealedbox_free(sbox);
     }
     if (!failures) printf("c_abi_walkthrough: OK\n");
     return failures ? 1 : 0;
