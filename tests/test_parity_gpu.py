@@ -230,6 +230,37 @@ def test_transform_group_boundaries(gpu, dim):
     assert not out[:, :, B:].any()
 
 
+@pytest.mark.parametrize("above", [False, True])
+def test_transform_path_modulus_bound(gpu, above):
+    """the transform kernel needs p < 2^62 - 2^31 (the high limb of a value in [-p, p] must fit a signed 32-bit register);
+    a prime just below the bound runs it, one just above takes the generic kernel - both bit-exact"""
+    from sda_amd import crypto
+    from oracle import coracle
+    k, t, n = 40, 23, 242
+    step = 64 * 243
+    bound = (1 << 62) - (1 << 31)
+    p = (bound // step) * step + 1 + (step if above else 0)            # the nearest p = 1 mod step on either side of the bound
+    for _ in range(100000):                                             # (the window above the bound holds 138k candidates)
+        if _is_prime(p):
+            break
+        p += step if above else -step
+    assert _is_prime(p) and (p >= bound) == above and p < (1 << 62) and (p - 1) % step == 0
+    g = next(g for g in range(2, 500) if pow(g, (p - 1) // 2, p) != 1 and pow(g, (p - 1) // 3, p) != 1)
+    w2, w3 = pow(g, (p - 1) // 64, p), pow(g, (p - 1) // 243, p)
+    assert pow(w2, 32, p) != 1 and pow(w3, 81, p) != 1
+    rng = np.random.default_rng(5)
+    dim = 40 * 11 + 7
+    gen = crypto.ShareGenerator(crypto.PackedShamir(k, n, t, p, w2, w3))
+    B = gen.batch_count(dim)
+    special = np.array([0, 1, p - 1, (p - 1) // 2, (p + 1) // 2, -p, p, -(1 << 62), (1 << 62) - 1], dtype=np.int64)
+    secrets = rng.choice(special, size=dim)
+    rand = rng.choice(special, size=B * t)
+    assert np.array_equal(gen.generate(secrets, rand), coracle.packed_generate(p, k, t, n, w2, w3, secrets, rand))
+    secrets = rng.integers(0, p, size=dim, dtype=np.int64)
+    rand = rng.integers(0, p, size=B * t, dtype=np.int64)
+    assert np.array_equal(gen.generate(secrets, rand), coracle.packed_generate(p, k, t, n, w2, w3, secrets, rand))
+
+
 def test_small_prime_packed_matches_tss_fft_path(gpu):
     """p = 433 (full_loop.rs:57-64): the matrix form on the GPU equals the recalled tss FFT path."""
     from sda_amd import crypto
