@@ -390,9 +390,12 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     gbs = tiles * per_launch_bytes / (sum(launch_ms) * 1e-3) / 1e9
     kern = ("fused_additive_kernel" if w["kind"] != "packed" else
             "fused_packed_l31_kernel" if w["k"] + w["t"] <= 16 else "packed_gen_fft_kernel + combine_update_kernel (no dual-role form)")
+    has_dual = w["kind"] != "packed" or w["k"] + w["t"] <= 16
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
                 "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid (shares "
-                "materialised in HBM by one launch, read back by the next); K+1 launches for K tiles")
+                "materialised in HBM by one launch, read back by the next); K+1 launches for K tiles" if has_dual else
+                "sda_share_generator_generate_combine_dev without a dual-role kernel for this shape: clerk-sum of tile i-1, then "
+                "share-gen of tile i, two launches per call")
     res["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic(name, P, dim, "fused_bytes_per_launch"),
                        "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": all_ms,
