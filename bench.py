@@ -144,7 +144,10 @@ class Env:
         # RCCL refuses two ranks on one device, so there the exchange is staged through host memory over gloo
         # (sda_amd.distributed); the modular sum of the slices still runs on the device.
         self.share_gpu = os.environ.get("SDA_SHARE_GPU") == "1"
-        device_index = 0 if self.share_gpu else self.local_rank
+        # SDA_SHARE_GPU=try: ranks share device 0 but the RCCL communicator is still attempted (it refuses duplicate devices):
+        # exercises the labelled fall-back to host staging
+        share_try = os.environ.get("SDA_SHARE_GPU") == "try"
+        device_index = 0 if (self.share_gpu or share_try) else self.local_rank
         torch.cuda.set_device(device_index)
         self.dev = torch.device("cuda", device_index)
         self.use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run
@@ -552,6 +555,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # stdout carries ONE JSON line and nothing else: gloo and RCCL print banners to the C stdout of every rank, so the
+    # process's fd 1 points at stderr for the whole run and the line is written to the real stdout at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     env = Env()
 
     def run(name, steps, warmup, participants=0, dim=0, tile=0):
@@ -591,8 +599,11 @@ def main():
     finally:
         os.dup2(saved, 1)
         os.close(saved)
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)
     if env.rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

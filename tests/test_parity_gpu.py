@@ -1175,6 +1175,30 @@ def test_device_entry_points_refuse_bad_arguments(gpu):
     assert gen.generate(secrets).shape == (8, 4)
 
 
+def test_bench_two_ranks_rccl_refusal_falls_back_loudly(gpu):
+    """two ranks on ONE device with the library's RCCL communicator attempted: the 128-byte id travels over gloo, both
+    ranks reach ncclCommInitRank, RCCL refuses the duplicate device ("invalid usage"), every rank takes the labelled
+    host-staged exchange together, and the cross-rank result still verifies.  (On a node with one GPU per rank the same
+    code path keeps the communicator.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDA_SHARE_GPU="try")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--participants", "120", "--dim", "65536", "--no-additional", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must be the ONE JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified_reconstruct_equals_sum"] is True
+    assert "RCCL" in line["config"]["exchange"]
+    if "unavailable" in line["config"]["exchange"]:
+        assert "sda_comm_init failed" in out.stderr
+
+
 @pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--schedule", "serial", "--workload", "additive"]),
                                          (2, ["--workload", "packed26"])])          # config 4's shape (k=8, t=2, n=26)
 def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
