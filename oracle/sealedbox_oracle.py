@@ -204,7 +204,12 @@ def secretbox_open(boxed: bytes, nonce24: bytes, key: bytes) -> bytes:
 
 
 def box_beforenm(pk: bytes, sk: bytes) -> bytes:
-    return hsalsa20(x25519(sk, pk), bytes(16))
+    shared = x25519(sk, pk)
+    if shared == bytes(32):
+        # libsodium's crypto_scalarmult_curve25519 returns -1 for an all-zero result (a small-order point), and
+        # crypto_box_beforenm / crypto_box_seal_open fail with it
+        raise ValueError("Sodium decryption failure")
+    return hsalsa20(shared, bytes(16))
 
 
 def box(m: bytes, nonce24: bytes, pk: bytes, sk: bytes) -> bytes:

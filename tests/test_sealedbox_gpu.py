@@ -137,6 +137,24 @@ def test_rows_tamper_and_short_rows(gpu):
             assert ob[r * out_slot:r * out_slot + len(msgs[r])] == msgs[r]
 
 
+def test_small_order_ephemeral_keys_are_refused(gpu):
+    """an ephemeral public key of small order makes the X25519 result all-zero, i.e. a key anybody can compute; libsodium's
+    scalar multiplication reports that and the box does not open - here too, even though its tag verifies under that key"""
+    from sda_amd import capi, crypto
+    from oracle import sealedbox_oracle as so
+    sk = bytes(range(7, 39)); pk = so.x25519_base(sk)
+    m = b"forged without knowing sk"
+    for epk in (bytes(32), (1).to_bytes(32, "little"),
+                bytes.fromhex("e0eb7a7c3b41b8ae1656e3faf19fc46ada098deb9c32b1fd866205165f49b800")):   # orders 4, 1, 8
+        assert so.x25519(sk, epk) == bytes(32)
+        forged = epk + so.secretbox(m, so.seal_nonce(epk, pk), so.hsalsa20(bytes(32), bytes(16)))
+        with pytest.raises(ValueError):
+            so.seal_open(forged, pk, sk)
+        with pytest.raises(capi.SdaError) as e:
+            crypto.SealedBox().open(forged, pk, sk)
+        assert e.value.code == capi.ERR_SODIUM_DECRYPTION
+
+
 def test_rows_longer_than_the_declared_bound_are_refused_not_read(gpu):
     """a row whose length field exceeds max_box_bytes (a lying job header) fails closed: flagged, length 0, and the
     kernels never touch bytes past the bound (the rows behind it stay intact and still open)"""
