@@ -68,7 +68,7 @@ hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k
                                       const ModParams& mod, const L31Params& lp, const MatArg& Ml31,
                                       const DrbgKey& key, int rounds, hipStream_t s);
 
-// the limb-31 kernel with run-time (k, t) and the matrix in global memory: any n, k + t <= 32
+// the limb-31 kernel with run-time (k, t) and the matrix in global memory: any n, k + t <= 64
 bool packed_l31_global_path_available(uint32_t k, uint32_t t);
 hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
                                              const L31Params& lp, const uint64_t* d_Ml31 /* n (k+t) entries + 3 zeros */,

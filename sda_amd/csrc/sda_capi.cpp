@@ -610,10 +610,10 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
         g->fast = !g->l31 && packed_fast_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC");
         g->l31g = !g->l31 && !g->fast && packed_l31_global_path_available(g->k, g->t) && !getenv("SDA_FORCE_GENERIC") &&
                   !getenv("SDA_FORCE_MONT64");
-        // the transform form: every tss-valid shape beyond the limb-31 matrix kernels (k + t > 32); SDA_FORCE_FFT=1 selects
-        // it for any tss-valid shape (A/B runs, parity tests of small shapes)
+        // the transform form: every tss-valid shape with k + t > 32 (beyond that the matrix kernels run at one wave per SIMD
+        // or not at all); SDA_FORCE_FFT=1 selects it for any tss-valid shape (A/B runs, parity tests of small shapes)
         uint32_t fa = 0, fb = 0, fG = 0;
-        if (!getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64") && ((!g->l31 && !g->fast && !g->l31g) || getenv("SDA_FORCE_FFT")) &&
+        if (!getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64") && ((uint64_t)g->k + g->t > 32 || getenv("SDA_FORCE_FFT")) &&
             fft_shape(g, fa, fb, fG)) {
             g->fft = true; g->l31 = g->l31g = g->fast = false;
             st = build_fft(g, fa, fb, fG);

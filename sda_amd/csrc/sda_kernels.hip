@@ -1335,7 +1335,7 @@ static hipError_t packed_l31_launch_rtg(const GenLayout& L, uint32_t n, uint32_t
     return hipSuccess;
 }
 
-bool packed_l31_global_path_available(uint32_t k, uint32_t t) { return k >= 1 && k + t <= 32; }
+bool packed_l31_global_path_available(uint32_t k, uint32_t t) { return k >= 1 && k + t <= 64; }
 
 // d_M: n (k + t) limb-31 packed entries followed by three zero entries (device memory)
 hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
@@ -1349,6 +1349,7 @@ hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uin
     if (kt <= 8) return RTG(8);
     if (kt <= 16) return RTG(16);
     if (kt <= 32) return RTG(32);
+    if (kt <= 64) return RTG(64);      // 256 limb registers per lane: one wave per SIMD, still far ahead of the generic kernel
 #undef RTG
     return hipErrorInvalidValue;
 }

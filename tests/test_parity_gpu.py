@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 P62 = 4611686006577364993
 W = {8: 631229665360524489, 9: 3451275676410824977, 16: 2589100645267092065, 27: 365137883145458390,
-     32: 1942624553499164220, 64: 2724396144719537715, 3: 3}   # 32 / 64: elements of that order; 3: of large order
+     32: 1942624553499164220, 64: 2724396144719537715, 128: 4438016560451165920, 3: 3}   # 32 / 64 / 128: elements of that order; 3: of large order
 KEY = bytes(range(32))
 
 
@@ -113,7 +113,8 @@ PACKED_SHAPES = [(3, 1, 8, 8, 9), (3, 4, 8, 8, 9), (8, 2, 26, 16, 27), (8, 7, 26
                  (12, 3, 26, 16, 27), (10, 5, 26, 16, 27), (4, 11, 26, 16, 27),          # splits of k + t = 15
                  (6, 2, 8, 16, 9), (9, 6, 26, 16, 27), (2, 9, 26, 16, 27), (1, 4, 26, 8, 27),  # run-time (k, t) kernel
                  (10, 7, 26, 32, 27), (3, 2, 100, 8, 3), (3, 4, 80, 8, 3), (20, 11, 40, 32, 3),   # run-time (k, t), matrix in global memory
-                 (20, 13, 80, 64, 3)]                                                     # k + t > 32
+                 (20, 13, 80, 64, 3), (40, 23, 80, 64, 3),                                # the same with k + t up to 64 (one wave per SIMD)
+                 (50, 20, 80, 128, 3)]                                                    # generic kernel (k + t > 64, not a tss shape)
 
 
 @pytest.mark.parametrize("k,t,n,o2,o3", PACKED_SHAPES)
