@@ -208,8 +208,7 @@ hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, 
     // 512 threads = 4 waves per SIMD with the two workgroups a CU's LDS holds (PSS_155_728_100: 58 ms per 500 x 1 Mi tile
     // against 66 with 256 threads, 79 with 1024, 120 with 128); a zero-input shortcut in the first radix-3 level, where
     // two of three inputs are zero-extension zeros, was measured 7 % SLOWER (divergence) and dropped
-    unsigned threads = F.G == 1 && F.m3 > 2187 ? 1024u : 512u;
-    if (const char* e = getenv("SDA_FFT_THREADS")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024) threads = (unsigned)v; }
+    const unsigned threads = F.G == 1 && F.m3 > 2187 ? 1024u : 512u;
     auto kern = rounds == 20 ? packed_gen_fft_kernel<20> : rounds == 12 ? packed_gen_fft_kernel<12> : packed_gen_fft_kernel<8>;
     if (rounds != 20 && rounds != 12 && rounds != 8) return hipErrorInvalidValue;
     if (lds > 64 * 1024)
