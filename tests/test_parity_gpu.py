@@ -919,8 +919,9 @@ def test_bench_under_torchrun_single_rank_rccl(gpu):
            "--warmup", "1", "--participants", "128", "--dim", "65536", "--no-cpu-baseline", "--no-additional"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must be the ONE JSON line (banners of gloo / RCCL belong on stderr)"
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["verified_reconstruct_equals_sum"] is True
     assert d["roofline"]["bound"] == "hbm" and d["value"] > 0
 
