@@ -137,6 +137,36 @@ def test_rows_tamper_and_short_rows(gpu):
             assert ob[r * out_slot:r * out_slot + len(msgs[r])] == msgs[r]
 
 
+def test_more_rows_than_one_launch_slice(gpu):
+    """70,000 small boxes: the bulk kernels are issued in slices of 65,535 rows (grid.y); every row must still open, and
+    rows on both sides of the slice boundary match the oracle"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBytes
+    from oracle import sealedbox_oracle as so
+    rows, mlen = 70_000, 100
+    rng = np.random.default_rng(70)
+    sk = bytes(rng.integers(0, 256, 32, dtype=np.uint8)); pk = so.x25519_base(sk)
+    msgs = rng.integers(0, 256, size=(rows, mlen), dtype=np.uint8)
+    mslot, bslot = 112, 160
+    blob = np.zeros((rows, mslot), dtype=np.uint8); blob[:, :mlen] = msgs
+    d_msgs = DeviceBytes.from_bytes(blob.tobytes())
+    d_mlen = DeviceBytes.from_bytes(np.full(rows, mlen, dtype="<u8").tobytes())
+    d_boxes, d_blen = DeviceBytes(rows * bslot).zero(), DeviceBytes(rows * 8).zero()
+    box = crypto.SealedBox()
+    esk = rng.integers(0, 256, size=(rows, 32), dtype=np.uint8)
+    box.seal_rows_dev([pk], rows, d_msgs.ptr, mslot, d_mlen.ptr, rows, mlen, d_boxes.ptr, bslot, d_blen.ptr, esk=esk.tobytes())
+    bb = d_boxes.to_bytes()
+    for r in (0, 1, 65534, 65535, 65536, rows - 1):
+        assert bb[r * bslot:r * bslot + mlen + 48] == so.seal(msgs[r].tobytes(), pk, esk[r].tobytes()), r
+    d_out, d_nb = DeviceBytes(rows * mslot).zero(), DeviceBytes(rows * 8).zero()
+    d_ok, d_status = DeviceBytes(rows * 4).zero(), DeviceBytes(4).zero()
+    box.open_rows_dev(pk, sk, d_boxes.ptr, bslot, d_blen.ptr, rows, mlen + 48, d_out.ptr, mslot, d_nb.ptr, d_status.ptr, d_ok.ptr)
+    assert d_status.to_bytes() == bytes(4)
+    assert np.frombuffer(d_ok.to_bytes(), dtype="<u4").all()
+    out = np.frombuffer(d_out.to_bytes(), dtype=np.uint8).reshape(rows, mslot)
+    assert np.array_equal(out[:, :mlen], msgs)
+
+
 def test_small_order_ephemeral_keys_are_refused(gpu):
     """an ephemeral public key of small order makes the X25519 result all-zero, i.e. a key anybody can compute; libsodium's
     scalar multiplication reports that and the box does not open - here too, even though its tag verifies under that key"""

@@ -57,6 +57,33 @@ def test_base64_rows_roundtrip_vs_oracle(gpu, lens):
         assert ob[r * in_slot + lens[r]:(r + 1) * in_slot] == bytes(in_slot - lens[r])        # nothing written past a row
 
 
+def test_base64_more_rows_than_one_launch_slice(gpu):
+    """70,000 short rows: the kernels are issued in slices of 65,535 rows; encode and decode round-trip for all of them"""
+    import base64
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBytes
+    rows, n = 70_000, 50
+    rng = np.random.default_rng(1)
+    raw = rng.integers(0, 256, size=(rows, n), dtype=np.uint8)
+    in_slot, text_slot = 64, 80
+    blob = np.zeros((rows, in_slot), dtype=np.uint8); blob[:, :n] = raw
+    d_in = DeviceBytes.from_bytes(blob.tobytes())
+    d_len = DeviceBytes.from_bytes(np.full(rows, n, dtype="<u8").tobytes())
+    d_text, d_tlen = DeviceBytes(rows * text_slot).zero(), DeviceBytes(rows * 8).zero()
+    crypto.base64_encode_rows_dev(d_in.ptr, in_slot, d_len.ptr, rows, n, d_text.ptr, text_slot, d_tlen.ptr)
+    text = np.frombuffer(d_text.to_bytes(), dtype=np.uint8).reshape(rows, text_slot)
+    tl = len(base64.b64encode(bytes(n)))
+    assert (_u64(d_tlen, rows) == tl).all()
+    for r in (0, 65534, 65535, 65536, rows - 1):
+        assert text[r, :tl].tobytes() == base64.b64encode(raw[r].tobytes())
+    d_out, d_olen = DeviceBytes(rows * in_slot).zero(), DeviceBytes(rows * 8).zero()
+    d_status = DeviceBytes(4).zero()
+    crypto.base64_decode_rows_dev(d_text.ptr, text_slot, d_tlen.ptr, rows, tl, d_out.ptr, in_slot, d_olen.ptr, d_status.ptr)
+    assert d_status.to_bytes() == bytes(4) and (_u64(d_olen, rows) == n).all()
+    out = np.frombuffer(d_out.to_bytes(), dtype=np.uint8).reshape(rows, in_slot)
+    assert np.array_equal(out[:, :n], raw)
+
+
 def test_base64_decode_inside_a_json_document_and_malformed_rows(gpu):
     """rows addressed by (offset, length) straight into the JSON text of a ClerkingJob - any alignment - and the strict
     decoder's verdicts (helpers.rs:183 "Base64 decoding error") row by row, equal to the oracle's"""
