@@ -2,7 +2,8 @@
 // time through sodiumoxide - `sealedbox::seal` per clerk in participate.rs:82-101 via encryption/sodium.rs:43,
 // `sealedbox::open` for each of the P encryptions of a clerking job in clerk.rs:79-82 via sodium.rs:78.
 //
-//   sbox_setup_kernel   one lane = one box: BLAKE2b nonce, X25519, two HSalsa20, the Poly1305 key and its powers
+//   sbox_setup_kernel   one DPP quad = one X25519 ladder (open: one per box, seal: two side by side); its first lane then
+//                       derives the BLAKE2b nonce, two HSalsa20, the Poly1305 key and its powers
 //   sbox_stream_kernel  one lane = one 64-byte Salsa20 block: XSalsa20 keystream xor (VALU-bound: 20 rounds per 64 B)
 //   sbox_poly_kernel    one wave = one 16 KiB region of ciphertext: lane-strided Horner with the uniform multiplier
 //                       r^64 (one 130-bit multiply per 16-byte piece, 1 KiB coalesced loads), lane weights r^(l+1)
@@ -61,38 +62,118 @@ __device__ __forceinline__ void derive_state(SboxState& st, const uint32_t share
     st.bad = any == 0 ? 1u : 0u;                              // all-zero shared secret (small-order point): crypto_box refuses it
 }
 
-// OPEN: box r at boxes + r * slot (epk || tag || ciphertext), recipient key pair in the kernel arguments
+// ---- X25519 across the four lanes of a DPP quad ---------------------------------------------------------------------
+// A box's setup is one lane's worth of strictly sequential work (255 ladder steps of 5 multiplications + 4 squarings in
+// GF(2^255 - 19)) and a job has only thousands of boxes, so the ladder's LATENCY is what the caller waits for.  A ladder
+// step (RFC 7748 section 5) is three levels of mutually independent products:
+//     level 1:  AA = A * A      BB = B * B      DA = D * A      CB = C * B
+//     level 2:  x3 = (DA+CB)^2  t = (DA-CB)^2   x2 = AA * BB    u = a24 * E          (E = AA - BB)
+//     level 3:  z3 = x1 * t                     z2 = E * (AA + u)
+// Lane c of the quad computes the c-th product of each level - one uniform fe_mul(P, Q) with lane-selected operands -
+// and the products are handed round with v_mov_b32_dpp quad_perm broadcasts; every lane keeps the whole ladder state
+// (x2, z2, x3, z3), so additions, the conditional swap and the final inversion need no exchange.  Three multiplications
+// per step on the critical path instead of ten.  All four lanes of the quad must be active and pass the same k and u;
+// all four return the same result.
+template <int SRC>
+__device__ __forceinline__ void fe_quad_bcast(Fe& h, const Fe& f) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) h.v[i] = __builtin_amdgcn_mov_dpp(f.v[i], SRC * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void fe_select(Fe& h, bool c, const Fe& a, const Fe& b) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) h.v[i] = c ? a.v[i] : b.v[i];
+}
+
+__device__ __noinline__ void x25519_quad(uint32_t out[8], const uint32_t k_in[8], const uint32_t u[8]) {
+    const uint32_t c = threadIdx.x & 3u;
+    const bool c0 = c == 0, c1 = c == 1, c2 = c == 2, lo = c < 2;
+    uint32_t k[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = k_in[i];
+    k[0] &= 0xFFFFFFF8u;
+    k[7] = (k[7] & 0x7FFFFFFFu) | 0x40000000u;
+    Fe x1, x2, z2, x3, z3, a24;
+    fe_from_words(x1, u);
+    fe_set(x2, 1); fe_set(z2, 0); x3 = x1; fe_set(z3, 1);
+    fe_set(a24, 121665);
+    uint32_t swap = 0;
+    for (int t = 254; t >= 0; --t) {
+        const uint32_t kt = (k[t >> 5] >> (t & 31)) & 1u;
+        swap ^= kt;
+        fe_cswap(x2, x3, swap);
+        fe_cswap(z2, z3, swap);
+        swap = kt;
+        Fe A, B, C, D, P, Q, T, r;
+        fe_add(A, x2, z2); fe_sub(B, x2, z2); fe_add(C, x3, z3); fe_sub(D, x3, z3);
+        fe_select(T, c2, D, C); fe_select(P, c1, B, T); fe_select(P, c0, A, P);      // A | B | D | C
+        fe_select(Q, (c & 1u) != 0, B, A);                                           // A | B | A | B
+        fe_mul(r, P, Q);
+        Fe AA, BB, DA, CB, E, S, Df;
+        fe_quad_bcast<0>(AA, r); fe_quad_bcast<1>(BB, r); fe_quad_bcast<2>(DA, r); fe_quad_bcast<3>(CB, r);
+        fe_sub(E, AA, BB); fe_add(S, DA, CB); fe_sub(Df, DA, CB);
+        fe_select(T, c2, AA, E); fe_select(P, c1, Df, T); fe_select(P, c0, S, P);    // S | Df | AA | E
+        fe_select(T, c2, BB, a24); fe_select(Q, lo, P, T);                           // S | Df | BB | a24
+        fe_mul(r, P, Q);
+        Fe tt, uu, W;
+        fe_quad_bcast<0>(x3, r); fe_quad_bcast<1>(tt, r); fe_quad_bcast<2>(x2, r); fe_quad_bcast<3>(uu, r);
+        fe_add(W, AA, uu);
+        fe_select(P, lo, x1, E);
+        fe_select(Q, lo, tt, W);
+        fe_mul(r, P, Q);
+        fe_quad_bcast<0>(z3, r); fe_quad_bcast<2>(z2, r);
+    }
+    fe_cswap(x2, x3, swap);
+    fe_cswap(z2, z3, swap);
+    Fe zi;
+    fe_invert(zi, z2);
+    fe_mul(x2, x2, zi);
+    fe_to_words(out, x2);
+}
+
+// OPEN: box r at boxes + r * slot (epk || tag || ciphertext), recipient key pair in the kernel arguments; four lanes per box
 __global__ __launch_bounds__(64) void sbox_setup_open_kernel(const uint8_t* __restrict__ boxes, size_t slot,
                                                              const uint64_t* __restrict__ row_bytes, size_t rows, SboxKeyArg pk,
                                                              SboxKeyArg sk, SboxState* __restrict__ states) {
-    const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (r >= rows) return;
+    const size_t r = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 2;
+    if (r >= rows) return;                                    // whole quads leave together
+    const bool lead = (threadIdx.x & 3u) == 0;
     SboxState& st = states[r];
-    if (row_bytes[r] < 48) { st.bad = 1; return; }
-    uint32_t epk[8], nonce[6], shared[8];
+    if (row_bytes[r] < 48) { if (lead) st.bad = 1; return; }
+    uint32_t epk[8], shared[8];
     load_words(epk, boxes + r * slot, 8);
-    seal_nonce(nonce, epk, pk.w);
-    x25519(shared, sk.w, epk);
-    derive_state(st, shared, nonce);
+    x25519_quad(shared, sk.w, epk);
+    if (lead) {
+        uint32_t nonce[6];
+        seal_nonce(nonce, epk, pk.w);
+        derive_state(st, shared, nonce);
+    }
 }
 
-// SEAL: ephemeral secret r at esk + 32 r; recipient key of row r = pks[(r / rows_per_key) % n_pks]; writes epk to the box
+// SEAL: ephemeral secret r at esk + 32 r; recipient key of row r = pks[(r / rows_per_key) % n_pks]; writes epk to the box.
+// Eight lanes per box: the two ladders of a seal (esk * base point -> epk, esk * pk -> shared secret) share the scalar and
+// run side by side in the two quads.
 __global__ __launch_bounds__(64) void sbox_setup_seal_kernel(const uint8_t* __restrict__ esk, const uint8_t* __restrict__ pks,
                                                              size_t n_pks, size_t rows_per_key, uint8_t* __restrict__ boxes,
                                                              size_t slot, size_t rows, SboxState* __restrict__ states) {
-    const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (r >= rows) return;
-    uint32_t e[8], pk[8], epk[8], nonce[6], shared[8];
+    const size_t r = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 3;
+    if (r >= rows) return;                                    // whole groups of eight leave together
+    const bool second = (threadIdx.x & 4u) != 0;
+    uint32_t e[8], pk[8], point[8], res[8], other[8];
     load_words(e, esk + 32 * r, 8);
     load_words(pk, pks + 32 * ((r / rows_per_key) % n_pks), 8);
-    const uint32_t base[8] = {9, 0, 0, 0, 0, 0, 0, 0};
-    x25519(epk, e, base);
-    uint32_t* o = reinterpret_cast<uint32_t*>(boxes + r * slot);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = epk[i];
-    seal_nonce(nonce, epk, pk);
-    x25519(shared, e, pk);
-    derive_state(states[r], shared, nonce);
+    for (int i = 0; i < 8; ++i) point[i] = second ? pk[i] : (i == 0 ? 9u : 0u);
+    x25519_quad(res, e, point);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) other[i] = (uint32_t)__shfl_down((int)res[i], 4);   // the second quad's result: the shared secret
+    if ((threadIdx.x & 7u) == 0) {
+        uint32_t* o = reinterpret_cast<uint32_t*>(boxes + r * slot);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = res[i];                                  // epk
+        uint32_t nonce[6];
+        seal_nonce(nonce, res, pk);
+        derive_state(states[r], other, nonce);
+    }
 }
 
 // XSalsa20 xor: in row r at in + r * in_slot + in_off, out likewise; the message of row r has lens[r] - len_sub bytes.
@@ -306,7 +387,7 @@ hipError_t launch_sealedbox_open(const uint8_t pk[32], const uint8_t sk[32], con
     if (rows == 0) return hipSuccess;
     const size_t max_msg = max_box_bytes > 48 ? max_box_bytes - 48 : 0;
     SboxKeyArg apk = key_arg(pk), ask = key_arg(sk);
-    sbox_setup_open_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_boxes, slot, d_row_bytes, rows, apk, ask, d_states);
+    sbox_setup_open_kernel<<<dim3((unsigned)cdiv64(4 * rows, 64)), dim3(64), 0, s>>>(d_boxes, slot, d_row_bytes, rows, apk, ask, d_states);
     volatile uint32_t* wipe = ask.w;
     for (int i = 0; i < 8; ++i) wipe[i] = 0;
     if (hipError_t e = hipGetLastError()) return e;
@@ -325,7 +406,7 @@ hipError_t launch_sealedbox_seal(const uint8_t* d_esk, const uint8_t* d_pks, siz
                                  size_t max_msg_bytes, uint8_t* d_boxes, size_t slot, uint64_t* d_row_bytes, SboxState* d_states,
                                  uint32_t* d_partial, hipStream_t s) {
     if (rows == 0) return hipSuccess;
-    sbox_setup_seal_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_esk, d_pks, n_pks, rows_per_key, d_boxes, slot, rows,
+    sbox_setup_seal_kernel<<<dim3((unsigned)cdiv64(8 * rows, 64)), dim3(64), 0, s>>>(d_esk, d_pks, n_pks, rows_per_key, d_boxes, slot, rows,
                                                                                 d_states);
     if (hipError_t e = hipGetLastError()) return e;
     // encrypt into the box, then authenticate the ciphertext
