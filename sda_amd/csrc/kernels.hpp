@@ -230,7 +230,7 @@ hipError_t launch_base64_encode_rows(const uint8_t* d_in, size_t in_slot, const 
                                      hipStream_t s);
 
 // ---- libsodium sealed boxes, batched (sodium.rs:43, :78) - sealedbox_kernels.hip ----------------------------
-// per-box state written by the setup kernel (one lane per box) and read, wave-uniformly, by the bulk kernels
+// per-box state written by the setup kernel (first lane of the box's DPP quad) and read, wave-uniformly, by the bulk kernels
 struct SboxState {
     uint32_t subkey[8];      // XSalsa20 subkey = HSalsa20(HSalsa20(X25519, 0), nonce[0:16])
     uint32_t n0, n1;         // nonce[16:24]

@@ -5,7 +5,8 @@
 // XSalsa20 papers, RFC 8439 section 2.5 (Poly1305), RFC 7693 (BLAKE2b), libsodium's crypto_box_seal construction.
 //
 // Everything is straight-line integer code on 32-bit limbs with 64-bit products (v_mad_i64_i32 / v_mad_u64_u32 on
-// gfx950): one lane = one box for the public-key part, one lane = one 64-byte block / one 16-byte piece for the bulk.
+// gfx950): one lane = one 64-byte block / one 16-byte piece for the bulk; the device runs the X25519 ladder across a
+// DPP quad (x25519_quad in sealedbox_kernels.hip, same field arithmetic), x25519() below is its one-lane form (host test).
 #pragma once
 #include <stdint.h>
 
