@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""A whole aggregation with everything the reference puts on the wire, device resident (config-3 shape: packed Shamir
+k=3, t=1, n=8 over the 62-bit prime, dim 1 Mi).  Per tile of P participants:
+
+  participant side (participate.rs:52-113)   share-gen -> zig-zag varint encode of the n x P share vectors -> one sealed
+                                             box per (clerk, participant), sealed to that clerk's public key
+  server (snapshot.rs:4-47)                  nothing to do: the boxes are written clerk-major, clerk c's job is rows c*P..
+  clerk side (clerk.rs:63-107), per clerk    open the P boxes with the clerk's key -> clerk sums straight from the varint
+                                             bytes (no decoded tile)
+and at the end (receive.rs:80-157) finish -> reveal from t + k clerks, checked against the sum of the secrets.
+Prints one JSON object; run on the GPU box.  TILE / TILES override the job size."""
+import ctypes as C
+import json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sda_amd import capi, crypto  # noqa: E402
+from sda_amd.device import DeviceBuffer, DeviceBytes, synchronize  # noqa: E402
+
+P62 = 4611686006577364993
+W8, W9 = 631229665360524489, 3451275676410824977
+lib = capi.load()
+k, t, n, dim = 3, 1, 8, 1 << 20
+P, tiles = int(os.environ.get("TILE", "1000")), int(os.environ.get("TILES", "4"))
+sch = crypto.PackedShamir(k, n, t, P62, W8, W9)
+B = (dim + k - 1) // k
+Bs = (B + 15) // 16 * 16
+rows = n * P
+secrets = DeviceBuffer(P * dim)
+capi.check(lib.sda_fill_synthetic_dev(secrets.ptr, P, dim, dim, 0, 0x5DA5DA5DA5DA5DA5, P62, None))
+shares = DeviceBuffer(rows * Bs)
+codec, box = crypto.VarintCodec(), crypto.SealedBox()
+vslot = codec.slot_size(B)
+bslot = vslot + 48
+wire, wlen = DeviceBytes(rows * vslot), DeviceBytes(rows * 8)
+boxes, blen = DeviceBytes(rows * bslot), DeviceBytes(rows * 8)
+plain, plen = DeviceBytes(rows * vslot), DeviceBytes(rows * 8)
+status = DeviceBytes(4).zero()
+gen = crypto.ShareGenerator(sch)
+comb = crypto.ShareCombiner(sch)
+sks = [bytes([c + 1]) * 32 for c in range(n)]
+pks = [box.seal(b"", bytes(32), sk)[:32] for sk in sks]        # a box's first 32 bytes are X25519(esk, 9): the clerks' public keys
+
+
+def ev():
+    e = C.c_void_p()
+    capi.check(lib.sda_event_create(C.byref(e)))
+    return e
+
+
+stage_ms = {"share_gen": 0.0, "varint_encode": 0.0, "seal": 0.0, "open": 0.0, "decode_and_clerk_sum": 0.0}
+
+
+def stage(name, fn):
+    a, b = ev(), ev()
+    capi.check(lib.sda_event_record(a, None))
+    fn()
+    capi.check(lib.sda_event_record(b, None))
+    synchronize()
+    ms = C.c_float()
+    capi.check(lib.sda_event_elapsed_ms(a, b, C.byref(ms)))
+    stage_ms[name] += ms.value
+
+
+# every clerk is its own party: own handle (scratch) and own HIP stream, so the clerks' short latency-bound setup kernels
+# overlap instead of queueing behind each other (the ABI takes any hipStream_t; the tool makes them with the HIP runtime)
+hip = C.CDLL("libamdhip64.so")
+clerk_boxes = [crypto.SealedBox() for _ in range(n)]
+clerk_streams = []
+for _ in range(n):
+    sp = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(sp)) == 0
+    clerk_streams.append(sp)
+
+
+def open_all():
+    synchronize()                                               # the boxes were sealed on the default stream
+    for c in range(n):
+        clerk_boxes[c].open_rows_dev(pks[c], sks[c], boxes.ptr + c * P * bslot, bslot, blen.ptr + c * P * 8, P, bslot,
+                                     plain.ptr + c * P * vslot, vslot, plen.ptr + c * P * 8, status.ptr,
+                                     stream=clerk_streams[c].value)
+    for sp in clerk_streams:
+        assert hip.hipStreamSynchronize(sp) == 0
+
+
+def tile(i, timed):
+    run = stage if timed else (lambda _n, fn: fn())
+    run("share_gen", lambda: gen.generate_batch_dev(secrets.ptr, P, dim, dim, shares.ptr, Bs, P * Bs, first_participant=i * P))
+    run("varint_encode", lambda: codec.encode_rows_dev(shares.ptr, rows, B, Bs, wire.ptr, vslot, wlen.ptr))
+    run("seal", lambda: box.seal_rows_dev(pks, P, wire.ptr, vslot, wlen.ptr, rows, vslot, boxes.ptr, bslot, blen.ptr))
+    run("open", open_all)
+    run("decode_and_clerk_sum", lambda: comb.update_encoded_rows_dev(codec, plain.ptr, vslot, plen.ptr, rows, status.ptr))
+
+
+comb.begin_dev(n, B)
+tile(0, False)                                                  # warm-up (allocations), its sums are discarded
+synchronize()
+comb.begin_dev(n, B)
+t0, t1 = ev(), ev()
+capi.check(lib.sda_event_record(t0, None))
+for i in range(tiles):
+    tile(i, True)
+capi.check(lib.sda_event_record(t1, None))
+synchronize()
+ms = C.c_float()
+capi.check(lib.sda_event_elapsed_ms(t0, t1, C.byref(ms)))
+box_bytes = int(np.frombuffer(blen.to_bytes(), dtype="<u8").sum())
+
+sums = DeviceBuffer(n * B)
+comb.finish_dev(sums.ptr)
+rec = crypto.SecretReconstructor(sch, dim)
+out = DeviceBuffer(dim)
+idx = [7, 0, 3, 5]                                              # any t + k clerks
+picked = DeviceBuffer.from_numpy(np.stack([sums.to_numpy(B, c * B) for c in idx]))
+rec.reconstruct_dev(idx, picked.ptr, B, B, out.ptr, dim)
+# truth: tiles x (column sums of the resident secrets) mod p - every tile re-shares the same secrets with fresh randomness
+col = crypto.ShareCombiner(crypto.Additive(3, P62))
+col.begin_dev(1, dim)
+col.update_dev(secrets.ptr, 0, P, dim)
+colsum = DeviceBuffer(dim)
+col.finish_dev(colsum.ptr)
+want = (colsum.to_numpy().astype(object) * tiles) % P62
+ok = bool(np.array_equal(out.to_numpy().astype(object), want)) and status.to_bytes() == bytes(4)
+elements = tiles * P * dim
+print(json.dumps({
+    "job": f"{tiles} tiles x {P} participants x dim {dim}, packed Shamir k={k} t={t} n={n}, 62-bit prime; {rows} sealed boxes per tile",
+    "box_bytes_per_tile": box_bytes, "box_bytes_per_secret": box_bytes / (P * dim),
+    "ms_per_tile": ms.value / tiles, "elements_per_s": elements / (ms.value * 1e-3),
+    "stage_ms_per_tile": {s: v / tiles for s, v in stage_ms.items()},
+    "whole_config3_job_s": 100_000 * dim / (elements / (ms.value * 1e-3)),
+    "verified_reveal_equals_sum_of_secrets": ok}, indent=1))
