@@ -68,6 +68,17 @@ hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k
                                       const ModParams& mod, const L31Params& lp, const MatArg& Ml31,
                                       const DrbgKey& key, int rounds, hipStream_t s);
 
+// packed Shamir as a limb GEMM on the matrix cores (v_mfma_i32_16x16x64_i8 on balanced base-256 digits), compiled shapes
+bool packed_mfma_path_available(uint32_t k, uint32_t t, uint32_t n);
+hipError_t launch_packed_generate_mfma(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                       const MontParams& mont, const uint64_t* d_Mbal /* [n][8 ceil((k+t)/8)] */,
+                                       const DrbgKey& key, int rounds, hipStream_t s);
+
+hipError_t launch_fused_packed_mfma(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                    const MontParams& mont, const uint64_t* d_Mbal, const DrbgKey& key, int rounds, uint64_t* acc_lo,
+                                    int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs, size_t dimension,
+                                    hipStream_t s, bool* fused);
+
 // the limb-31 kernel with run-time (k, t) and the matrix in global memory: any n, k + t <= 64
 bool packed_l31_global_path_available(uint32_t k, uint32_t t);
 hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,

@@ -443,6 +443,7 @@ struct sda_share_generator {
     bool l31 = false;                    // balanced-31-bit-limb kernel, matrix in the kernarg segment
     bool l31g = false;                   // the same with run-time (k, t) and the matrix in global memory (d_M)
     bool fft = false;                    // transform form (tss's own algorithm) for large tss-valid shapes
+    bool mfma = false;                   // limb GEMM on the matrix cores (d_M holds the byte-reversed balanced constants)
     FftPlan fplan{};
     DevBuf d_fft;
     L31Params lp{};
@@ -557,6 +558,23 @@ static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, ui
     return true;
 }
 
+// the limb-GEMM kernel's constants: centred Montgomery-form (R = 2^64) entries in balanced base-256 digits (the kernel cuts its
+// Toeplitz rows out of them), [n][8 * ceil((k + t) / 8)] zero padded
+static int build_mfma(sda_share_generator* g) {
+    const uint32_t kt = g->k + g->t, width = 8 * ((kt + 7) / 8);
+    std::vector<uint64_t> tab((size_t)g->n * width, 0);
+    for (uint32_t j = 0; j < g->n; ++j)
+        for (uint32_t i = 0; i < kt; ++i) {
+            uint64_t m = g->Mmont[(size_t)j * kt + i];
+            if (m > (g->mod.m >> 1)) m -= g->mod.m;                          // centred representative, two's complement
+            const uint64_t bal = (m + 0x8080808080808080ull) ^ 0x8080808080808080ull;
+            tab[(size_t)j * width + i] = bal;
+        }
+    SDA_TRY(g->d_M.reserve(tab.size() * 8));
+    HIP_TRY(hipMemcpy(g->d_M.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    return SDA_OK;
+}
+
 static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G) {
     const uint64_t p = g->mod.m, m2 = (uint64_t)g->k + g->t + 1, m3 = (uint64_t)g->n + 1;
     SDA_TRY(l31_params(p, g->lp));
@@ -617,6 +635,12 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
             fft_shape(g, fa, fb, fG)) {
             g->fft = true; g->l31 = g->l31g = g->fast = false;
             st = build_fft(g, fa, fb, fG);
+        } else if (packed_mfma_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64") &&
+                   !getenv("SDA_NO_MFMA") && (g->k + g->t >= 12 || getenv("SDA_FORCE_MFMA"))) {
+            // the limb GEMM on the matrix cores: measured ahead of the limb-31 kernel from k + t = 15 with n = 26 (+12 %),
+            // behind it for k + t = 10 and below (SDA_FORCE_MFMA=1 takes it for every compiled shape, SDA_NO_MFMA=1 never)
+            g->mfma = true; g->l31 = g->l31g = g->fast = false;
+            st = build_mfma(g);
         } else if (g->l31 || g->l31g) {
             st = build_l31(g);
         } else if (g->fast) {
@@ -705,6 +729,10 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
     }
     if (g->fft) {
         HIP_TRY(launch_packed_generate_fft(L, g->mod, g->lp, key, g->fplan, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->mfma) {
+        HIP_TRY(launch_packed_generate_mfma(L, g->n, g->k, g->t, g->mod, g->mont, g->d_M.as<uint64_t>(), key, g->drbg.rounds, s));
         return SDA_OK;
     }
     // any-shape path: materialise the CSPRNG draws first (identical values to the fused path)
@@ -874,6 +902,10 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
         he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, key, g->drbg.rounds,
                                      c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
                                      c->dimension, s, &fused);
+    } else if (g->mfma) {
+        he = launch_fused_packed_mfma(L, g->n, g->k, g->t, g->mod, g->mont, g->d_M.as<uint64_t>(), key, g->drbg.rounds,
+                                      c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
+                                      c->dimension, s, &fused);
     }
     int st = SDA_OK;
     if (he != hipSuccess) st = fail(SDA_ERR_HIP, "dual-role launch failed: %s", hipGetErrorString(he));

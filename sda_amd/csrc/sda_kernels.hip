@@ -465,6 +465,201 @@ __global__ SDA_LB(K, T) void packed_gen_l31_kernel(GenLayout L, uint32_t n, ModP
     packed_gen_l31_body<K, T, ROUNDS, VEC>(L, n, mod, lp, M, key, chunks, batches, blockIdx.x);
 }
 
+// -------------------------------------------------------------------------------------------------
+// K2''  packed-Shamir share generation as a LIMB GEMM on the matrix cores.
+//
+// For the shapes whose n x (k + t) mat-vec is VALU-bound (k + t ~ 10..16, n = 26: 60..80 VALU wave-instructions per
+// batch in the limb-31 kernel, four v_mad_i64_i32 per term) the products are moved to v_mfma_i32_16x16x64_i8:
+//   * every residue x in [0, p) is written in BALANCED base-256 digits, x = sum d_i 256^i with d_i in [-128, 127]:
+//     the bytes of (x + 0x8080..80) xor 0x8080..80 - two 64-bit instructions, and the eight digits of a value ARE the
+//     eight bytes of a register pair; the matrix constants (Montgomery form, R = 2^64) likewise, on the host;
+//   * column c = sum over terms and i + l = c of dM_i dV_l is one row of a 16 x 64 times 64 x 16 integer product: the B
+//     operand of lane (batch = lane & 15, g = lane >> 4) is simply the 16 bytes of the values of terms 2g, 2g + 1 of that
+//     batch; the A operand of lane (c = lane & 15, g) is a Toeplitz row - byte l' = constant byte c - l' - cut out of the
+//     8-byte constant with two v_perm_b32 under per-lane selectors (no 1 KiB fragment table per clerk);  |column| < 2^21;
+//   * the 15 columns of an output land four per lane on the four lanes (batch, g = 0..3).  A wave works on 64 batches =
+//     four 16-batch tiles, so after three v_mad_i64_i32 per tile a 4 x 4 transpose across the wave's four 16-lane rows
+//     (v_permlane32_swap / v_permlane16_swap, eight instructions) hands every lane the four partial sums of ONE batch:
+//     a 128-bit assemble, two conditional subtractions and one Montgomery reduction later it stores one share per
+//     clerk, lane-contiguous.
+// Values reach the operand layout through a wave-private LDS tile [batch][term] (rows padded to 144 B: both the 8-byte
+// writes and the 16-byte operand reads spread over all banks).  The draws are the same sda-drbg-v1 quad blocks.
+// -------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+static constexpr uint64_t kBalancedBias = 0x8080808080808080ull;
+__device__ __forceinline__ uint64_t balanced_bytes(uint64_t x) { return (x + kBalancedBias) ^ kBalancedBias; }   // x: two's complement
+// canonical residue -> its representative in (-p/2, p/2] (two's complement): halves the magnitude of every product
+__device__ __forceinline__ uint64_t centred(uint64_t v, uint64_t p) { return v > (p >> 1) ? v - p : v; }
+__device__ __forceinline__ void rows_swap32(uint32_t& a, uint32_t& b) {     // a rows 2,3 <-> b rows 0,1 (rows of 16 lanes)
+    const v2u r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r.x; b = r.y;
+}
+__device__ __forceinline__ void rows_swap16(uint32_t& a, uint32_t& b) {     // a rows 1,3 <-> b rows 0,2
+    const v2u r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r.x; b = r.y;
+}
+
+__device__ __forceinline__ int64_t vmad_i64(int32_t a, int32_t b, int64_t c) {      // a * b + c: one v_mad_i64_i32
+    int64_t d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+}
+
+static constexpr int kMfmaMaxClerks = 32;
+static constexpr int kMfmaWaveBatches = 64;
+
+// COUNT consecutive values per batch from src[first + e], e < 64 * COUNT (lane-contiguous 8-byte loads) -> tile[batch][term0 + ..]
+template <int COUNT, int ROWDW>
+__device__ __forceinline__ void mfma_stage_values(uint32_t* tile, const int64_t* __restrict__ src, uint64_t first, uint64_t src_len,
+                                                  int term0, const ModParams& mod) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int q = 0; q < COUNT; ++q) {
+        const uint32_t e = lane + 64u * q;
+        const uint64_t idx = first + e;
+        const uint64_t v = idx < src_len ? canon_i64(src[idx], mod.m, mod.mu) : 0;       // zero padding (batched.rs:37-43)
+        const uint32_t bl = e / COUNT, tm = e - bl * COUNT;
+        *reinterpret_cast<uint64_t*>(tile + bl * ROWDW + 2 * (term0 + tm)) = balanced_bytes(centred(v, mod.m));
+    }
+}
+
+// the 16 x 64 x 16 products of clerk j with the four batch tiles: d[tile] = 4 of the 15 columns (rows 4 g .. 4 g + 3).
+// A operand of lane (c = lane & 15, g): byte l' of term 2 g (+ 1) = byte c - l' of that constant, 0 outside 0..7 - a Toeplitz
+// row, cut out of the 8-byte constant with two v_perm_b32 under per-lane selectors.
+template <int KS>
+__device__ __forceinline__ void mfma_clerk_products(v4i (&d)[4], const uint64_t* mconst, uint32_t j, uint32_t g, uint32_t sel_lo,
+                                                    uint32_t sel_hi, const v4i (&bfrag)[4][KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const ull2 m2 = *reinterpret_cast<const ull2*>(&mconst[(j * KS + ks) * 8 + 2 * g]);
+        v4i a;
+        a.x = (int)__builtin_amdgcn_perm((uint32_t)(m2.x >> 32), (uint32_t)m2.x, sel_lo);
+        a.y = (int)__builtin_amdgcn_perm((uint32_t)(m2.x >> 32), (uint32_t)m2.x, sel_hi);
+        a.z = (int)__builtin_amdgcn_perm((uint32_t)(m2.y >> 32), (uint32_t)m2.y, sel_lo);
+        a.w = (int)__builtin_amdgcn_perm((uint32_t)(m2.y >> 32), (uint32_t)m2.y, sel_hi);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const v4i zero = {0, 0, 0, 0};
+            d[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bfrag[nt][ks], ks == 0 ? zero : d[nt], 0, 0, 0);
+        }
+    }
+}
+
+// the four tiles' columns of one clerk -> one share per lane (batch = lane of the wave's 64), stored at `o`
+__device__ __forceinline__ void mfma_clerk_finish(const v4i (&d)[4], int32_t mul3, const MontParams& mont, bool live, int64_t* o) {
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        int64_t pa = vmad_i64(d[nt].y, 1 << 8, (int64_t)d[nt].x);
+        pa = vmad_i64(d[nt].z, 1 << 16, pa);
+        pa = vmad_i64(d[nt].w, mul3, pa);
+        lo[nt] = (uint32_t)pa; hi[nt] = (uint32_t)((uint64_t)pa >> 32);
+    }
+    // 4 x 4 transpose (register index = tile, lane row = column group): lane row g ends up with tile g's four partial sums
+    rows_swap32(lo[0], lo[2]); rows_swap32(lo[1], lo[3]); rows_swap16(lo[0], lo[1]); rows_swap16(lo[2], lo[3]);
+    rows_swap32(hi[0], hi[2]); rows_swap32(hi[1], hi[3]); rows_swap16(hi[0], hi[1]); rows_swap16(hi[2], hi[3]);
+    // X = q0 + q1 2^32 + q2 2^64 + q3 2^96 = sum over <= 16 terms of constant * value, both centred: exact, |X| <= 4 p^2 < p 2^64
+    const uint64_t q0 = ((uint64_t)hi[0] << 32) | lo[0];
+    const uint64_t xlo = q0 + ((uint64_t)lo[1] << 32);
+    const int64_t xhi = (int64_t)((int32_t)hi[0] >> 31) + (int64_t)(int32_t)hi[1] + (xlo < q0 ? 1 : 0) +
+                        (int64_t)(((uint64_t)hi[2] << 32) | lo[2]) + (int64_t)((uint64_t)lo[3] << 32);
+    // signed REDC (R = 2^64): X + (X.lo * -p^-1 mod 2^64) p is a multiple of 2^64; the quotient lies in [-p, 2p)
+    const uint64_t m = xlo * mont.pinv;
+    int64_t t = xhi + (int64_t)mulhi64(m, mont.p) + (xlo != 0 ? 1 : 0);
+    t += (t >> 63) & (int64_t)mont.p;
+    const uint64_t share = (uint64_t)t >= mont.p ? (uint64_t)t - mont.p : (uint64_t)t;
+    if (live) __builtin_nontemporal_store((long long)share, reinterpret_cast<long long*>(o));
+}
+
+template <int K, int T, int ROUNDS>
+__device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_t n, const ModParams& mod, const MontParams& mont,
+                                                     const uint64_t* __restrict__ Mbal, const DrbgKey& key, uint64_t chunks,
+                                                     uint64_t batches, uint32_t iters, uint64_t item) {
+    constexpr int KT = K + T, KS = (KT + 7) / 8, ROWDW = KS * 16 + 4;
+    static_assert(KT <= 16, "two 64-slot MFMA steps hold 16 terms");
+    __shared__ __attribute__((aligned(16))) uint64_t mconst[kMfmaMaxClerks * KS * 8];
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kThreads / 64][kMfmaWaveBatches * ROWDW];
+    uint64_t p, chunk;
+    split_item(item, chunks, p, chunk);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, col = lane & 15u, g = lane >> 4;
+    uint32_t* tile = tiles[wave];
+    for (uint32_t i = threadIdx.x; i < n * KS * 8; i += kThreads) mconst[i] = Mbal[i];
+    for (uint32_t i = lane; i < (uint32_t)(kMfmaWaveBatches * ROWDW); i += 64) tile[i] = 0;       // unused terms stay zero
+    __syncthreads();
+
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
+    int64_t* op = L.out + p * L.out_stride_participant;
+    const uint64_t stream = L.first_participant + p;
+    const QuadCol qc = quad_col(key);
+    // v_perm_b32 selectors of this lane's Toeplitz row c = col: output byte l' takes constant byte c - l' (0x0c = zero)
+    uint32_t sel_lo = 0, sel_hi = 0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const int src = (int)col - l;
+        const uint32_t sb = (src >= 0 && src <= 7) ? (uint32_t)src : 0x0cu;
+        if (l < 4) sel_lo |= sb << (8 * l); else sel_hi |= sb << (8 * (l - 4));
+    }
+    const int32_t mul3 = g == 3 ? 0 : (1 << 24);                                                 // column 15 does not exist
+
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t b0 = ((chunk * iters + it) * (kThreads / 64) + wave) * kMfmaWaveBatches;   // wave-uniform
+        if (b0 >= batches) break;
+        // ---- stage [secrets ; draws] of 64 batches in the operand layout -----------------------------------------
+        mfma_stage_values<K, ROWDW>(tile, sp, b0 * K, L.len, 0, mod);
+        if (rp) {
+            mfma_stage_values<T, ROWDW>(tile, rp, b0 * T, batches * T, K, mod);
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < (8 * T + 15) / 16; ++pass) {
+                const uint32_t blk = 16u * pass + (lane >> 2);          // block of (draw i, group G of 8 batches)
+                const uint32_t G = blk & 7u, i = blk >> 3;
+                uint64_t r0, r1;
+                drbg_pair<ROUNDS>(key, qc, stream, (b0 >> 1) + 4 * G + (lane & 3u), T, i < (uint32_t)T ? i : 0, mod, r0, r1);
+                if (i < (uint32_t)T) {
+                    uint32_t* row = tile + (8 * G + 2 * (lane & 3u)) * ROWDW + 2 * (K + i);
+                    *reinterpret_cast<uint64_t*>(row) = balanced_bytes(centred(r0, mod.m));
+                    *reinterpret_cast<uint64_t*>(row + ROWDW) = balanced_bytes(centred(r1, mod.m));
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        v4i bfrag[4][KS];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                bfrag[nt][ks] = *reinterpret_cast<const v4i*>(tile + (16 * nt + col) * ROWDW + 16 * ks + 4 * g);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next iteration's staging stays behind these reads
+        __builtin_amdgcn_wave_barrier();
+
+        const bool live = b0 + lane < batches;
+        int64_t* orow = op + b0 + lane;
+        // two accumulator sets in turn: the next clerk's products are issued before this clerk's are consumed, so the matrix
+        // cores work under the VALU tail
+        v4i dA[4], dB[4];
+        mfma_clerk_products<KS>(dA, mconst, 0, g, sel_lo, sel_hi, bfrag);
+        for (uint32_t j = 0; j < n; j += 2) {
+            if (j + 1 < n) mfma_clerk_products<KS>(dB, mconst, j + 1, g, sel_lo, sel_hi, bfrag);
+            mfma_clerk_finish(dA, mul3, mont, live, orow + (size_t)j * L.out_stride_clerk);
+            if (j + 1 < n) {
+                if (j + 2 < n) mfma_clerk_products<KS>(dA, mconst, j + 2, g, sel_lo, sel_hi, bfrag);
+                mfma_clerk_finish(dB, mul3, mont, live, orow + (size_t)(j + 1) * L.out_stride_clerk);
+            }
+        }
+    }
+}
+
+template <int K, int T, int ROUNDS>
+__global__ __launch_bounds__(kThreads, 3) void packed_gen_mfma_kernel(GenLayout L, uint32_t n, ModParams mod, MontParams mont,
+                                                                      const uint64_t* __restrict__ Mbal, DrbgKey key,
+                                                                      uint64_t chunks, uint64_t batches, uint32_t iters) {
+    packed_gen_mfma_body<K, T, ROUNDS>(L, n, mod, mont, Mbal, key, chunks, batches, iters, blockIdx.x);
+}
+
 // ---- run-time (k, t): the same arithmetic for shapes that have no compiled instance ---------------------------------
 // k and t are kernel arguments, KTMAX (4 / 8 / 12 / 16) bounds k + t.  The value limbs of the terms beyond k + t are
 // zero and every group of four terms is either done in full or skipped by a wave-uniform branch, so a dot product
@@ -728,6 +923,15 @@ __global__ __launch_bounds__(kThreads) void fused_packed_l31_rt_kernel(GenLayout
     uint64_t idx;
     if (!fuse_dispatch(F, blockIdx.x, idx))
         packed_gen_l31_rt_body<KTMAX, ROUNDS>(L, n, k, t, mod, lp, &M.e[0], key, chunks, batches, true, idx);
+}
+
+template <int K, int T, int ROUNDS>
+__global__ __launch_bounds__(kThreads, 3) void fused_packed_mfma_kernel(GenLayout L, uint32_t n, ModParams mod, MontParams mont,
+                                                                        const uint64_t* __restrict__ Mbal, DrbgKey key,
+                                                                        uint64_t chunks, uint64_t batches, uint32_t iters,
+                                                                        FuseArgs F) {
+    uint64_t idx;
+    if (!fuse_dispatch(F, blockIdx.x, idx)) packed_gen_mfma_body<K, T, ROUNDS>(L, n, mod, mont, Mbal, key, chunks, batches, iters, idx);
 }
 
 template <int ROUNDS>
@@ -1354,6 +1558,50 @@ hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uin
     return hipErrorInvalidValue;
 }
 
+// ---- limb GEMM on the matrix cores (packed_gen_mfma_kernel) ----------------------------------------------------------
+#define SDA_MFMA_SHAPES(X) X(8, 7) X(8, 2) X(3, 4) X(3, 1)
+static constexpr uint32_t kMfmaIters = 8;                      // 64-batch steps per wave: one workgroup = 2048 batches
+
+bool packed_mfma_path_available(uint32_t k, uint32_t t, uint32_t n) {
+    if (n > (uint32_t)kMfmaMaxClerks) return false;
+#define X(K_, T_) if (k == K_ && t == T_) return true;
+    SDA_MFMA_SHAPES(X)
+#undef X
+    return false;
+}
+
+template <int K, int T, int ROUNDS>
+static hipError_t packed_mfma_launch_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const MontParams& mont,
+                                        const uint64_t* d_Mbal, const DrbgKey& key, hipStream_t s) {
+    const uint64_t batches = ceil_div(L.len, K);
+    const uint64_t chunks = ceil_div(batches, (uint64_t)kThreads * kMfmaIters);
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        packed_gen_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(
+            S, n, mod, mont, d_Mbal, key, chunks, batches, kMfmaIters);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
+// d_Mbal: [n][8 * ceil((k + t) / 8)] balanced-byte forms of the Montgomery-form (R = 2^64) matrix, zero padded
+hipError_t launch_packed_generate_mfma(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                       const MontParams& mont, const uint64_t* d_Mbal, const DrbgKey& key, int rounds,
+                                       hipStream_t s) {
+#define X(K_, T_)                                                                                           \
+    if (k == K_ && t == T_)                                                                                 \
+        return rounds == 20   ? packed_mfma_launch_kt<K_, T_, 20>(L, n, mod, mont, d_Mbal, key, s)          \
+               : rounds == 12 ? packed_mfma_launch_kt<K_, T_, 12>(L, n, mod, mont, d_Mbal, key, s)          \
+               : rounds == 8  ? packed_mfma_launch_kt<K_, T_, 8>(L, n, mod, mont, d_Mbal, key, s)           \
+                              : hipErrorInvalidValue;
+    SDA_MFMA_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
                                           const ModParams& mod, const MontParams& mont, const uint64_t* d_Mmont,
                                           hipStream_t s) {
@@ -1505,6 +1753,38 @@ hipError_t launch_fused_packed_l31(const GenLayout& L, uint32_t n, uint32_t k, u
     if (kt <= 4) RT(4); else if (kt <= 8) RT(8); else if (kt <= 12) RT(12); else RT(16);
 #undef RT
     return hipGetLastError();
+}
+
+static constexpr uint32_t kMfmaFusedIters = 2;                 // 512 batches per share-gen item, as in the limb-31 dual-role launch
+
+template <int K, int T, int ROUNDS>
+static hipError_t fused_mfma_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const MontParams& mont, const uint64_t* d_Mbal,
+                                const DrbgKey& key, const FuseArgs& F, uint64_t chunks, uint64_t batches, hipStream_t s) {
+    fused_packed_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)F.grid), dim3(kThreads), 0, s>>>(L, n, mod, mont, d_Mbal, key, chunks, batches,
+                                                                                              kMfmaFusedIters, F);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_packed_mfma(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                    const MontParams& mont, const uint64_t* d_Mbal, const DrbgKey& key, int rounds, uint64_t* acc_lo,
+                                    int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs, size_t dimension,
+                                    hipStream_t s, bool* fused) {
+    *fused = false;
+    if ((rounds != 20 && rounds != 12 && rounds != 8) || L.rand || !packed_mfma_path_available(k, t, n)) return hipSuccess;
+    const uint64_t batches = ceil_div(L.len, k);
+    const uint64_t chunks = ceil_div(batches, (uint64_t)kThreads * kMfmaFusedIters);
+    FuseArgs F;
+    if (!fuse_plan(L, chunks, acc_lo, acc_hi, d_prev, prev_rows, jobs, dimension, F)) return hipSuccess;
+#define X(K_, T_)                                                                                                        \
+    if (k == K_ && t == T_) {                                                                                            \
+        *fused = true;                                                                                                   \
+        return rounds == 20 ? fused_mfma_kt<K_, T_, 20>(L, n, mod, mont, d_Mbal, key, F, chunks, batches, s)             \
+             : rounds == 12 ? fused_mfma_kt<K_, T_, 12>(L, n, mod, mont, d_Mbal, key, F, chunks, batches, s)             \
+                            : fused_mfma_kt<K_, T_, 8>(L, n, mod, mont, d_Mbal, key, F, chunks, batches, s);             \
+    }
+    SDA_MFMA_SHAPES(X)
+#undef X
+    return hipSuccess;
 }
 
 hipError_t launch_fused_additive(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,

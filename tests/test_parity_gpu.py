@@ -1069,7 +1069,8 @@ def test_odd_strides_and_unaligned_bases_dev(gpu):
 
 
 @pytest.mark.parametrize("kind", ["packed_k3_t1_n8", "packed_k8_t2_n26", "additive_n3", "packed_odd_strides",
-                                  "packed_k4_t3_n8", "packed_k6_t2_n8", "packed_k9_t6_n26"])    # the last three: run-time (k, t) form
+                                  "packed_k4_t3_n8", "packed_k6_t2_n8", "packed_k9_t6_n26",     # these three: run-time (k, t) form
+                                  "packed_k8_t7_n26"])                                          # limb GEMM on the matrix cores
 def test_dual_role_pipeline_equals_separate_launches(gpu, kind):
     """sda_share_generator_generate_combine_dev (tile i+1 generated while tile i is summed, one grid) must
     produce exactly the shares and clerk sums of generate_batch_dev + combiner update_dev."""
@@ -1082,6 +1083,9 @@ def test_dual_role_pipeline_equals_separate_launches(gpu, kind):
         sch, k, t, n = crypto.Additive(3, P62), 1, 2, 3
     elif kind == "packed_k8_t2_n26":
         k, t, n = 8, 2, 26
+        sch = crypto.PackedShamir(k, n, t, P62, W[16], W[27])
+    elif kind == "packed_k8_t7_n26":
+        k, t, n = 8, 7, 26
         sch = crypto.PackedShamir(k, n, t, P62, W[16], W[27])
     elif kind == "packed_k4_t3_n8":
         k, t, n = 4, 3, 8
@@ -1222,3 +1226,55 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
     assert line["n_gpus"] == ranks and line["verified_reconstruct_equals_sum"] is True
     assert line["config"]["participants_total"] == ranks * 3 * 40 and line["scaling"] == "weak"
     assert f"{ranks * 120} participants" in line["config"]["workload"]                 # the label is what was processed
+
+
+@pytest.mark.parametrize("k,t,n,dim", [(8, 7, 26, 8 * 64 * 5 + 3), (8, 7, 26, 1), (8, 7, 26, 8 * 2048 + 8 * 77), (8, 2, 26, 8 * 300 + 1),
+                                       (3, 4, 8, 3 * 1000 + 2), (3, 1, 8, 3 * 129), (8, 7, 26, 8 * 64)])
+def test_limb_gemm_share_generation_vs_oracle(gpu, monkeypatch, k, t, n, dim):
+    """packed_gen_mfma_kernel (the limb GEMM on the matrix cores; the default from k + t = 12, SDA_FORCE_MFMA=1 for every
+    compiled shape) against the oracle's matrix form: injected randomness with any-i64 secrets (ragged last batch, partial
+    64-batch steps, several workgroups per participant), then the device CSPRNG streams of three participants, and the
+    round trip through reconstruct."""
+    monkeypatch.setenv("SDA_FORCE_MFMA", "1")
+    _share_gen_vs_oracle(k, t, n, dim)
+
+
+def test_limb31_kernel_serves_8_7_26_when_the_limb_gemm_is_switched_off(gpu, monkeypatch):
+    monkeypatch.setenv("SDA_NO_MFMA", "1")
+    _share_gen_vs_oracle(8, 7, 26, 8 * 64 * 5 + 3)
+
+
+def _share_gen_vs_oracle(k, t, n, dim):
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    w2, w3 = _root(P62, k + t + 1) if (k + t + 1) & (k + t) == 0 else None, _root(P62, n + 1)
+    if w2 is None:                                     # k + t + 1 not a power of two: any root of a power-of-two order >= k + t + 1
+        m2 = 1
+        while m2 < k + t + 1:
+            m2 *= 2
+        w2 = _root(P62, m2)
+    rng = np.random.default_rng(k * 131 + t * 7 + dim)
+    sch = crypto.PackedShamir(k, n, t, P62, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    B = gen.batch_count(dim)
+    secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
+    rand = rng.integers(-(1 << 62), 1 << 62, size=B * t, dtype=np.int64)
+    got = gen.generate(secrets, rand)
+    want = coracle.packed_generate(P62, k, t, n, w2, w3, secrets, rand)
+    assert np.array_equal(got, want)
+    gen.set_drbg_key(KEY)
+    P = 3
+    sec2 = rng.integers(0, P62, size=(P, dim), dtype=np.int64)
+    sec2[0, : min(dim, 5)] = [0, P62 - 1, 1, P62 // 2, P62 // 2 + 1][: min(dim, 5)]
+    d_sec = DeviceBuffer.from_numpy(sec2)
+    Bs = B + (B & 1)
+    d_out = DeviceBuffer(P * n * Bs).zero()
+    gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=(1 << 40) + 5)
+    out = d_out.to_numpy().reshape(P, n, Bs)
+    for q in range(P):
+        w = coracle.packed_generate(P62, k, t, n, w2, w3, sec2[q], coracle.drbg_fill(KEY, (1 << 40) + 5 + q, B, t, P62))
+        assert np.array_equal(out[q, :, :B], w), f"participant {q}"
+    idx = sorted(rng.choice(n, size=t + k, replace=False).tolist())
+    rec = crypto.SecretReconstructor(sch, dim).reconstruct([(i, out[1, i, :B]) for i in idx])
+    assert np.array_equal(rec, sec2[1])
