@@ -314,6 +314,10 @@ def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, s
     }
 
 
+# shapes the library serves with the limb GEMM on the matrix cores by default (sda_capi.cpp: compiled MFMA shape, k + t >= 12)
+MFMA_DEFAULT_SHAPES = {(8, 7)}
+
+
 def _traffic(name, P, dim, key):
     """PMC HBM bytes per launch (profiles/traffic.json, measured at some tile size; bytes scale with the tile)"""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -392,6 +396,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     per_launch_bytes = P * dim * (gen_b + comb_b)
     gbs = tiles * per_launch_bytes / (sum(launch_ms) * 1e-3) / 1e9
     kern = ("fused_additive_kernel" if w["kind"] != "packed" else
+            "fused_packed_mfma_kernel" if (w["k"], w["t"]) in MFMA_DEFAULT_SHAPES else
             "fused_packed_l31_kernel" if w["k"] + w["t"] <= 16 else "packed_gen_fft_kernel + combine_update_kernel (no dual-role form)")
     has_dual = w["kind"] != "packed" or w["k"] + w["t"] <= 16
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
@@ -502,6 +507,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     comb_gbs = per_launch * comb_b / (comb_ms * 1e-3) / 1e9
     dominant_gen = gen_ms >= comb_ms
     gen_kernel = ("additive_gen_kernel" if w["kind"] != "packed" else
+                  "packed_gen_mfma_kernel" if (w["k"], w["t"]) in MFMA_DEFAULT_SHAPES else
                   "packed_gen_l31_kernel" if w["k"] + w["t"] <= 32 else "packed_gen_fft_kernel")
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
                 "share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares" if overlap
