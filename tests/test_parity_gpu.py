@@ -1244,11 +1244,18 @@ def test_limb31_kernel_serves_8_7_26_when_the_limb_gemm_is_switched_off(gpu, mon
     _share_gen_vs_oracle(8, 7, 26, 8 * 64 * 5 + 3)
 
 
-def _share_gen_vs_oracle(k, t, n, dim):
+@pytest.mark.parametrize("n", [15, 27, 31, 32])
+def test_limb_gemm_clerk_counts(gpu, n):
+    """odd and extreme clerk counts of the limb-GEMM kernel (its clerk loop alternates two accumulator sets; 32 clerks is
+    what its constant table holds): share points 3^1 .. 3^n"""
+    _share_gen_vs_oracle(8, 7, n, 8 * 200 + 5, w3=W[3])
+
+
+def _share_gen_vs_oracle(k, t, n, dim, w3=None):
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     from oracle import coracle
-    w2, w3 = _root(P62, k + t + 1) if (k + t + 1) & (k + t) == 0 else None, _root(P62, n + 1)
+    w2, w3 = _root(P62, k + t + 1) if (k + t + 1) & (k + t) == 0 else None, w3 or _root(P62, n + 1)
     if w2 is None:                                     # k + t + 1 not a power of two: any root of a power-of-two order >= k + t + 1
         m2 = 1
         while m2 < k + t + 1:
