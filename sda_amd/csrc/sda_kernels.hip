@@ -1559,7 +1559,7 @@ hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uin
 }
 
 // ---- limb GEMM on the matrix cores (packed_gen_mfma_kernel) ----------------------------------------------------------
-#define SDA_MFMA_SHAPES(X) X(8, 7) X(8, 2) X(3, 4) X(3, 1)
+#define SDA_MFMA_SHAPES(X) X(8, 7) X(8, 2) X(3, 4) X(3, 1) X(12, 3) X(10, 5) X(4, 11)
 static constexpr uint32_t kMfmaIters = 8;                      // 64-batch steps per wave: one workgroup = 2048 batches
 
 bool packed_mfma_path_available(uint32_t k, uint32_t t, uint32_t n) {
