@@ -524,6 +524,20 @@ __device__ __forceinline__ void mfma_stage_values(uint32_t* tile, const int64_t*
     }
 }
 
+// the same with a run-time count (shapes without a compiled instance)
+template <int ROWDW>
+__device__ __forceinline__ void mfma_stage_values_rt(uint32_t* tile, const int64_t* __restrict__ src, uint64_t first, uint64_t src_len,
+                                                     uint32_t count, uint32_t term0, const ModParams& mod) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t q = 0; q < count; ++q) {
+        const uint32_t e = lane + 64u * q;
+        const uint64_t idx = first + e;
+        const uint64_t v = idx < src_len ? canon_i64(src[idx], mod.m, mod.mu) : 0;
+        const uint32_t bl = e / count, tm = e - bl * count;
+        *reinterpret_cast<uint64_t*>(tile + bl * ROWDW + 2 * (term0 + tm)) = balanced_bytes(centred(v, mod.m));
+    }
+}
+
 // the 16 x 64 x 16 products of clerk j with the four batch tiles: d[tile] = 4 of the 15 columns (rows 4 g .. 4 g + 3).
 // A operand of lane (c = lane & 15, g): byte l' of term 2 g (+ 1) = byte c - l' of that constant, 0 outside 0..7 - a Toeplitz
 // row, cut out of the 8-byte constant with two v_perm_b32 under per-lane selectors.
@@ -575,9 +589,11 @@ __device__ __forceinline__ void mfma_clerk_finish(const v4i (&d)[4], int32_t mul
 template <int K, int T, int ROUNDS>
 __device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_t n, const ModParams& mod, const MontParams& mont,
                                                      const uint64_t* __restrict__ Mbal, const DrbgKey& key, uint64_t chunks,
-                                                     uint64_t batches, uint32_t iters, uint64_t item) {
-    constexpr int KT = K + T, KS = (KT + 7) / 8, ROWDW = KS * 16 + 4;
-    static_assert(KT <= 16, "two 64-slot MFMA steps hold 16 terms");
+                                                     uint64_t batches, uint32_t iters, uint64_t item, uint32_t k_rt, uint32_t t_rt) {
+    // K = 0: k and t are run-time arguments (k + t <= 16, two 64-slot MFMA steps)
+    constexpr int KS = K ? (K + T + 7) / 8 : 2, ROWDW = KS * 16 + 4;
+    static_assert(K + T <= 16, "two 64-slot MFMA steps hold 16 terms");
+    const uint32_t k = K ? (uint32_t)K : k_rt, t = K ? (uint32_t)T : t_rt;
     __shared__ __attribute__((aligned(16))) uint64_t mconst[kMfmaMaxClerks * KS * 8];
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kThreads / 64][kMfmaWaveBatches * ROWDW];
     uint64_t p, chunk;
@@ -607,21 +623,28 @@ __device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_
         const uint64_t b0 = ((chunk * iters + it) * (kThreads / 64) + wave) * kMfmaWaveBatches;   // wave-uniform
         if (b0 >= batches) break;
         // ---- stage [secrets ; draws] of 64 batches in the operand layout -----------------------------------------
-        mfma_stage_values<K, ROWDW>(tile, sp, b0 * K, L.len, 0, mod);
+        if constexpr (K != 0) mfma_stage_values<K, ROWDW>(tile, sp, b0 * K, L.len, 0, mod);
+        else mfma_stage_values_rt<ROWDW>(tile, sp, b0 * k, L.len, k, 0, mod);
         if (rp) {
-            mfma_stage_values<T, ROWDW>(tile, rp, b0 * T, batches * T, K, mod);
+            if constexpr (K != 0 && T != 0) mfma_stage_values<T, ROWDW>(tile, rp, b0 * T, batches * T, K, mod);
+            else mfma_stage_values_rt<ROWDW>(tile, rp, b0 * t, batches * t, t, k, mod);
         } else {
-#pragma unroll
-            for (int pass = 0; pass < (8 * T + 15) / 16; ++pass) {
+            auto draw_pass = [&](uint32_t pass) {
                 const uint32_t blk = 16u * pass + (lane >> 2);          // block of (draw i, group G of 8 batches)
                 const uint32_t G = blk & 7u, i = blk >> 3;
                 uint64_t r0, r1;
-                drbg_pair<ROUNDS>(key, qc, stream, (b0 >> 1) + 4 * G + (lane & 3u), T, i < (uint32_t)T ? i : 0, mod, r0, r1);
-                if (i < (uint32_t)T) {
-                    uint32_t* row = tile + (8 * G + 2 * (lane & 3u)) * ROWDW + 2 * (K + i);
+                drbg_pair<ROUNDS>(key, qc, stream, (b0 >> 1) + 4 * G + (lane & 3u), t, i < t ? i : 0, mod, r0, r1);
+                if (i < t) {
+                    uint32_t* row = tile + (8 * G + 2 * (lane & 3u)) * ROWDW + 2 * (k + i);
                     *reinterpret_cast<uint64_t*>(row) = balanced_bytes(centred(r0, mod.m));
                     *reinterpret_cast<uint64_t*>(row + ROWDW) = balanced_bytes(centred(r1, mod.m));
                 }
+            };
+            if constexpr (K != 0) {
+#pragma unroll
+                for (int pass = 0; pass < (8 * T + 15) / 16; ++pass) draw_pass((uint32_t)pass);
+            } else {
+                for (uint32_t pass = 0; pass < (8 * t + 15) / 16; ++pass) draw_pass(pass);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -656,8 +679,9 @@ __device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_
 template <int K, int T, int ROUNDS>
 __global__ __launch_bounds__(kThreads, 3) void packed_gen_mfma_kernel(GenLayout L, uint32_t n, ModParams mod, MontParams mont,
                                                                       const uint64_t* __restrict__ Mbal, DrbgKey key,
-                                                                      uint64_t chunks, uint64_t batches, uint32_t iters) {
-    packed_gen_mfma_body<K, T, ROUNDS>(L, n, mod, mont, Mbal, key, chunks, batches, iters, blockIdx.x);
+                                                                      uint64_t chunks, uint64_t batches, uint32_t iters,
+                                                                      uint32_t k_rt, uint32_t t_rt) {
+    packed_gen_mfma_body<K, T, ROUNDS>(L, n, mod, mont, Mbal, key, chunks, batches, iters, blockIdx.x, k_rt, t_rt);
 }
 
 // ---- run-time (k, t): the same arithmetic for shapes that have no compiled instance ---------------------------------
@@ -929,9 +953,10 @@ template <int K, int T, int ROUNDS>
 __global__ __launch_bounds__(kThreads, 3) void fused_packed_mfma_kernel(GenLayout L, uint32_t n, ModParams mod, MontParams mont,
                                                                         const uint64_t* __restrict__ Mbal, DrbgKey key,
                                                                         uint64_t chunks, uint64_t batches, uint32_t iters,
-                                                                        FuseArgs F) {
+                                                                        uint32_t k_rt, uint32_t t_rt, FuseArgs F) {
     uint64_t idx;
-    if (!fuse_dispatch(F, blockIdx.x, idx)) packed_gen_mfma_body<K, T, ROUNDS>(L, n, mod, mont, Mbal, key, chunks, batches, iters, idx);
+    if (!fuse_dispatch(F, blockIdx.x, idx))
+        packed_gen_mfma_body<K, T, ROUNDS>(L, n, mod, mont, Mbal, key, chunks, batches, iters, idx, k_rt, t_rt);
 }
 
 template <int ROUNDS>
@@ -1562,18 +1587,21 @@ hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uin
 #define SDA_MFMA_SHAPES(X) X(8, 7) X(8, 2) X(3, 4) X(3, 1) X(12, 3) X(10, 5) X(4, 11)
 static constexpr uint32_t kMfmaIters = 8;                      // 64-batch steps per wave: one workgroup = 2048 batches
 
-bool packed_mfma_path_available(uint32_t k, uint32_t t, uint32_t n) {
-    if (n > (uint32_t)kMfmaMaxClerks) return false;
+static bool packed_mfma_compiled(uint32_t k, uint32_t t) {
 #define X(K_, T_) if (k == K_ && t == T_) return true;
     SDA_MFMA_SHAPES(X)
 #undef X
     return false;
 }
+bool packed_mfma_path_available(uint32_t k, uint32_t t, uint32_t n) {
+    if (n > (uint32_t)kMfmaMaxClerks) return false;
+    return packed_mfma_compiled(k, t) || (k >= 1 && k + t > 8 && k + t <= 16);        // run-time (k, t) form: two MFMA steps
+}
 
 template <int K, int T, int ROUNDS>
-static hipError_t packed_mfma_launch_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const MontParams& mont,
-                                        const uint64_t* d_Mbal, const DrbgKey& key, hipStream_t s) {
-    const uint64_t batches = ceil_div(L.len, K);
+static hipError_t packed_mfma_launch_kt(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                        const MontParams& mont, const uint64_t* d_Mbal, const DrbgKey& key, hipStream_t s) {
+    const uint64_t batches = ceil_div(L.len, k);
     const uint64_t chunks = ceil_div(batches, (uint64_t)kThreads * kMfmaIters);
     if (chunks * L.participants == 0) return hipSuccess;
     const uint64_t per = participants_per_launch(chunks, L.participants);
@@ -1581,7 +1609,7 @@ static hipError_t packed_mfma_launch_kt(const GenLayout& L, uint32_t n, const Mo
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
         const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
         packed_gen_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(
-            S, n, mod, mont, d_Mbal, key, chunks, batches, kMfmaIters);
+            S, n, mod, mont, d_Mbal, key, chunks, batches, kMfmaIters, k, t);
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
@@ -1593,13 +1621,17 @@ hipError_t launch_packed_generate_mfma(const GenLayout& L, uint32_t n, uint32_t 
                                        hipStream_t s) {
 #define X(K_, T_)                                                                                           \
     if (k == K_ && t == T_)                                                                                 \
-        return rounds == 20   ? packed_mfma_launch_kt<K_, T_, 20>(L, n, mod, mont, d_Mbal, key, s)          \
-               : rounds == 12 ? packed_mfma_launch_kt<K_, T_, 12>(L, n, mod, mont, d_Mbal, key, s)          \
-               : rounds == 8  ? packed_mfma_launch_kt<K_, T_, 8>(L, n, mod, mont, d_Mbal, key, s)           \
+        return rounds == 20   ? packed_mfma_launch_kt<K_, T_, 20>(L, n, k, t, mod, mont, d_Mbal, key, s)    \
+               : rounds == 12 ? packed_mfma_launch_kt<K_, T_, 12>(L, n, k, t, mod, mont, d_Mbal, key, s)    \
+               : rounds == 8  ? packed_mfma_launch_kt<K_, T_, 8>(L, n, k, t, mod, mont, d_Mbal, key, s)     \
                               : hipErrorInvalidValue;
     SDA_MFMA_SHAPES(X)
 #undef X
-    return hipErrorInvalidValue;
+    if (!packed_mfma_path_available(k, t, n)) return hipErrorInvalidValue;
+    return rounds == 20   ? packed_mfma_launch_kt<0, 0, 20>(L, n, k, t, mod, mont, d_Mbal, key, s)
+           : rounds == 12 ? packed_mfma_launch_kt<0, 0, 12>(L, n, k, t, mod, mont, d_Mbal, key, s)
+           : rounds == 8  ? packed_mfma_launch_kt<0, 0, 8>(L, n, k, t, mod, mont, d_Mbal, key, s)
+                          : hipErrorInvalidValue;
 }
 
 hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
@@ -1758,10 +1790,11 @@ hipError_t launch_fused_packed_l31(const GenLayout& L, uint32_t n, uint32_t k, u
 static constexpr uint32_t kMfmaFusedIters = 2;                 // 512 batches per share-gen item, as in the limb-31 dual-role launch
 
 template <int K, int T, int ROUNDS>
-static hipError_t fused_mfma_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const MontParams& mont, const uint64_t* d_Mbal,
-                                const DrbgKey& key, const FuseArgs& F, uint64_t chunks, uint64_t batches, hipStream_t s) {
+static hipError_t fused_mfma_kt(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod, const MontParams& mont,
+                                const uint64_t* d_Mbal, const DrbgKey& key, const FuseArgs& F, uint64_t chunks, uint64_t batches,
+                                hipStream_t s) {
     fused_packed_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)F.grid), dim3(kThreads), 0, s>>>(L, n, mod, mont, d_Mbal, key, chunks, batches,
-                                                                                              kMfmaFusedIters, F);
+                                                                                              kMfmaFusedIters, k, t, F);
     return hipGetLastError();
 }
 
@@ -1778,13 +1811,16 @@ hipError_t launch_fused_packed_mfma(const GenLayout& L, uint32_t n, uint32_t k, 
 #define X(K_, T_)                                                                                                        \
     if (k == K_ && t == T_) {                                                                                            \
         *fused = true;                                                                                                   \
-        return rounds == 20 ? fused_mfma_kt<K_, T_, 20>(L, n, mod, mont, d_Mbal, key, F, chunks, batches, s)             \
-             : rounds == 12 ? fused_mfma_kt<K_, T_, 12>(L, n, mod, mont, d_Mbal, key, F, chunks, batches, s)             \
-                            : fused_mfma_kt<K_, T_, 8>(L, n, mod, mont, d_Mbal, key, F, chunks, batches, s);             \
+        return rounds == 20 ? fused_mfma_kt<K_, T_, 20>(L, n, k, t, mod, mont, d_Mbal, key, F, chunks, batches, s)       \
+             : rounds == 12 ? fused_mfma_kt<K_, T_, 12>(L, n, k, t, mod, mont, d_Mbal, key, F, chunks, batches, s)       \
+                            : fused_mfma_kt<K_, T_, 8>(L, n, k, t, mod, mont, d_Mbal, key, F, chunks, batches, s);       \
     }
     SDA_MFMA_SHAPES(X)
 #undef X
-    return hipSuccess;
+    *fused = true;                                                      // run-time (k, t) form
+    return rounds == 20 ? fused_mfma_kt<0, 0, 20>(L, n, k, t, mod, mont, d_Mbal, key, F, chunks, batches, s)
+         : rounds == 12 ? fused_mfma_kt<0, 0, 12>(L, n, k, t, mod, mont, d_Mbal, key, F, chunks, batches, s)
+                        : fused_mfma_kt<0, 0, 8>(L, n, k, t, mod, mont, d_Mbal, key, F, chunks, batches, s);
 }
 
 hipError_t launch_fused_additive(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,

@@ -1229,7 +1229,10 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
 
 
 @pytest.mark.parametrize("k,t,n,dim", [(8, 7, 26, 8 * 64 * 5 + 3), (8, 7, 26, 1), (8, 7, 26, 8 * 2048 + 8 * 77), (8, 2, 26, 8 * 300 + 1),
-                                       (3, 4, 8, 3 * 1000 + 2), (3, 1, 8, 3 * 129), (8, 7, 26, 8 * 64)])
+                                       (3, 4, 8, 3 * 1000 + 2), (3, 1, 8, 3 * 129), (8, 7, 26, 8 * 64),
+                                       # shapes without a compiled instance: the run-time (k, t) form
+                                       (9, 6, 26, 9 * 333 + 4), (13, 2, 26, 13 * 70), (1, 14, 26, 401), (2, 9, 26, 2 * 999 + 1),
+                                       (5, 4, 26, 5 * 123), (16, 0, 26, 16 * 65 + 3)])
 def test_limb_gemm_share_generation_vs_oracle(gpu, monkeypatch, k, t, n, dim):
     """packed_gen_mfma_kernel (the limb GEMM on the matrix cores; the default from k + t = 12, SDA_FORCE_MFMA=1 for every
     compiled shape) against the oracle's matrix form: injected randomness with any-i64 secrets (ragged last batch, partial
