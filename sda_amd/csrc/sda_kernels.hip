@@ -506,7 +506,7 @@ __device__ __forceinline__ int64_t vmad_i64(int32_t a, int32_t b, int64_t c) {  
     return d;
 }
 
-static constexpr int kMfmaMaxClerks = 32;
+static constexpr int kMfmaMaxClerks = 80;                    // LDS table of constants: 80 x 16 x 8 B = 10 KiB (n = 80: the next tss-valid clerk count)
 static constexpr int kMfmaWaveBatches = 64;
 
 // COUNT consecutive values per batch from src[first + e], e < 64 * COUNT (lane-contiguous 8-byte loads) -> tile[batch][term0 + ..]
