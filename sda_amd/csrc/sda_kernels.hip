@@ -506,7 +506,7 @@ __device__ __forceinline__ int64_t vmad_i64(int32_t a, int32_t b, int64_t c) {  
     return d;
 }
 
-static constexpr int kMfmaMaxClerks = 80;                    // LDS table of constants: 80 x 16 x 8 B = 10 KiB (n = 80: the next tss-valid clerk count)
+static constexpr int kMfmaMaxClerks = 242;                   // LDS table of constants: n x 8 KS x 8 B, dynamic (242 clerks x 128 B = 31 KiB beside the 37 KiB of tiles: two workgroups per CU)
 static constexpr int kMfmaWaveBatches = 64;
 
 // COUNT consecutive values per batch from src[first + e], e < 64 * COUNT (lane-contiguous 8-byte loads) -> tile[batch][term0 + ..]
@@ -594,7 +594,7 @@ __device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_
     constexpr int KS = K ? (K + T + 7) / 8 : 2, ROWDW = KS * 16 + 4;
     static_assert(K + T <= 16, "two 64-slot MFMA steps hold 16 terms");
     const uint32_t k = K ? (uint32_t)K : k_rt, t = K ? (uint32_t)T : t_rt;
-    __shared__ __attribute__((aligned(16))) uint64_t mconst[kMfmaMaxClerks * KS * 8];
+    extern __shared__ __attribute__((aligned(16))) uint64_t mconst[];       // n * KS * 8 constants (dynamic: sized by the clerk count)
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kThreads / 64][kMfmaWaveBatches * ROWDW];
     uint64_t p, chunk;
     split_item(item, chunks, p, chunk);
@@ -1598,6 +1598,9 @@ bool packed_mfma_path_available(uint32_t k, uint32_t t, uint32_t n) {
     return packed_mfma_compiled(k, t) || (k >= 1 && k + t > 8 && k + t <= 16);        // run-time (k, t) form: two MFMA steps
 }
 
+template <int K, int T>
+static size_t mfma_table_bytes(uint32_t n) { return (size_t)n * (K ? (K + T + 7) / 8 : 2) * 64; }
+
 template <int K, int T, int ROUNDS>
 static hipError_t packed_mfma_launch_kt(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
                                         const MontParams& mont, const uint64_t* d_Mbal, const DrbgKey& key, hipStream_t s) {
@@ -1608,7 +1611,11 @@ static hipError_t packed_mfma_launch_kt(const GenLayout& L, uint32_t n, uint32_t
     if (per == 0) return hipErrorInvalidConfiguration;
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
         const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
-        packed_gen_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(
+        if (mfma_table_bytes<K, T>(n) > 24 * 1024)                      // beyond the default 64 KiB of LDS per workgroup
+            if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&packed_gen_mfma_kernel<K, T, ROUNDS>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_table_bytes<K, T>(n)))
+                return e;
+        packed_gen_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), mfma_table_bytes<K, T>(n), s>>>(
             S, n, mod, mont, d_Mbal, key, chunks, batches, kMfmaIters, k, t);
         if (hipError_t e = hipGetLastError()) return e;
     }
@@ -1793,7 +1800,11 @@ template <int K, int T, int ROUNDS>
 static hipError_t fused_mfma_kt(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod, const MontParams& mont,
                                 const uint64_t* d_Mbal, const DrbgKey& key, const FuseArgs& F, uint64_t chunks, uint64_t batches,
                                 hipStream_t s) {
-    fused_packed_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)F.grid), dim3(kThreads), 0, s>>>(L, n, mod, mont, d_Mbal, key, chunks, batches,
+    if (mfma_table_bytes<K, T>(n) > 24 * 1024)
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_packed_mfma_kernel<K, T, ROUNDS>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_table_bytes<K, T>(n)))
+            return e;
+    fused_packed_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)F.grid), dim3(kThreads), mfma_table_bytes<K, T>(n), s>>>(L, n, mod, mont, d_Mbal, key, chunks, batches,
                                                                                               kMfmaFusedIters, k, t, F);
     return hipGetLastError();
 }

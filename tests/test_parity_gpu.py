@@ -1247,10 +1247,10 @@ def test_limb31_kernel_serves_8_7_26_when_the_limb_gemm_is_switched_off(gpu, mon
     _share_gen_vs_oracle(8, 7, 26, 8 * 64 * 5 + 3)
 
 
-@pytest.mark.parametrize("n", [15, 27, 31, 32, 79, 80])
+@pytest.mark.parametrize("n", [15, 27, 31, 32, 79, 80, 81, 242])
 def test_limb_gemm_clerk_counts(gpu, n):
-    """odd and extreme clerk counts of the limb-GEMM kernel (its clerk loop alternates two accumulator sets; 80 clerks is
-    what its constant table holds): share points 3^1 .. 3^n"""
+    """odd and extreme clerk counts of the limb-GEMM kernel (its clerk loop alternates two accumulator sets; 242 clerks is
+    what its constant table may hold): share points 3^1 .. 3^n"""
     _share_gen_vs_oracle(8, 7, n, 8 * 200 + 5, w3=W[3])
 
 

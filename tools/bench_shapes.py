@@ -15,7 +15,7 @@ capi.check(lib.sda_fill_synthetic_dev(sec.ptr, P, dim, dim, 0, 3, P62, None))
 W[16], W[27], W[32], W[64], W[3] = 2589100645267092065, 365137883145458390, 1942624553499164220, 2724396144719537715, 3
 for (k, t, n, o2, o3) in [(4, 3, 8, 8, 9), (5, 2, 8, 8, 9), (6, 1, 8, 8, 9), (7, 0, 8, 8, 9), (3, 4, 8, 8, 9), (8, 7, 26, 16, 27),
                           (6, 2, 8, 16, 9), (9, 6, 26, 16, 27),    # run-time (k, t) kernel
-                          (3, 4, 80, 8, 3), (8, 7, 80, 16, 3), (10, 7, 26, 32, 27), (20, 11, 40, 32, 3),   # the same, matrix in global memory
+                          (3, 4, 80, 8, 3), (8, 7, 80, 16, 3), (8, 7, 242, 16, 3), (10, 7, 26, 32, 27), (20, 11, 40, 32, 3),   # the same, matrix in global memory
                           (12, 3, 26, 16, 27), (10, 5, 26, 16, 27), (8, 2, 26, 16, 27), (3, 1, 8, 8, 9),    # compiled, 5-term groups where they help
                           (20, 13, 80, 64, 3)]:                    # generic kernel (k + t > 32, not a tss shape)
     sch = crypto.PackedShamir(k, n, t, P62, W[o2], W[o3])
