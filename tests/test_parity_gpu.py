@@ -1251,10 +1251,10 @@ def test_limb31_kernel_serves_8_7_26_when_the_limb_gemm_is_switched_off(gpu, mon
 def test_limb_gemm_clerk_counts(gpu, n):
     """odd and extreme clerk counts of the limb-GEMM kernel (its clerk loop alternates two accumulator sets; 242 clerks is
     what its constant table may hold): share points 3^1 .. 3^n"""
-    _share_gen_vs_oracle(8, 7, n, 8 * 200 + 5, w3=W[3])
+    _share_gen_vs_oracle(8, 7, n, 8 * 200 + 5, w3=W[3], odd_stride=n in (27, 80))
 
 
-def _share_gen_vs_oracle(k, t, n, dim, w3=None):
+def _share_gen_vs_oracle(k, t, n, dim, w3=None, odd_stride=False):
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     from oracle import coracle
@@ -1278,7 +1278,7 @@ def _share_gen_vs_oracle(k, t, n, dim, w3=None):
     sec2 = rng.integers(0, P62, size=(P, dim), dtype=np.int64)
     sec2[0, : min(dim, 5)] = [0, P62 - 1, 1, P62 // 2, P62 // 2 + 1][: min(dim, 5)]
     d_sec = DeviceBuffer.from_numpy(sec2)
-    Bs = B + (B & 1)
+    Bs = (B | 1) if odd_stride else B + (B & 1)        # odd row stride: 8-byte aligned rows only
     d_out = DeviceBuffer(P * n * Bs).zero()
     gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=(1 << 40) + 5)
     out = d_out.to_numpy().reshape(P, n, Bs)
