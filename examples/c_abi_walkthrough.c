@@ -142,7 +142,7 @@ int main(void) {
             CHECK(sda_varint_encode(codec, shares[p], 10, wire, sizeof wire, &n_wire));       /* sodium.rs:36-41 */
             CHECK(sda_sealedbox_seal(sbox, pk, NULL, wire, n_wire, boxes[p], sizeof boxes[p]));   /* sodium.rs:43 */
             box_len[p] = n_wire + SDA_SEALBYTES;
-            CHECK(sda_job_container_set_row(job, p, boxes[p], box_len[p]));
+            CHECK(sda_job_container_set_row(job, layout.total_bytes, p, boxes[p], box_len[p]));
         }
         sda_job_layout_t got;
         CHECK(sda_job_container_parse(job, layout.total_bytes, &got));

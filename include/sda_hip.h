@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SDA_HIP_ABI_VERSION 2
+#define SDA_HIP_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum sda_status {
@@ -124,6 +124,8 @@ int         sda_abi_version(void);
 const char* sda_version(void);
 int         sda_device_count(void);          /* number of visible HIP devices, 0 if none      */
 int         sda_set_device(int ordinal);     /* device used by handles created afterwards     */
+int         sda_device_pci_bus_id(int ordinal, char* out, size_t cap);   /* "0000:05:00.0"; cap >= 16; identifies the
+                                                 physical GPU (bench.py counts the distinct devices of the ranks) */
 const char* sda_strerror(int status);
 const char* sda_last_error(void);            /* thread-local; "" if none                      */
 
@@ -467,9 +469,12 @@ size_t sda_job_container_size(size_t rows, size_t slot_bytes);        /* 0 if sl
 /* writes the header and a zeroed length table into buf[cap] */
 int sda_job_container_init(uint8_t* buf, size_t cap, uint32_t payload_kind, size_t rows, size_t slot_bytes,
                            sda_job_layout_t* out /* may be NULL */);
-int sda_job_container_set_row(uint8_t* buf, size_t row, const uint8_t* payload, size_t len);
+/* cap = size of the caller's buffer: the header is re-validated against it before anything is written (the buffer may
+ * be a parsed, untrusted blob) */
+int sda_job_container_set_row(uint8_t* buf, size_t cap, size_t row, const uint8_t* payload, size_t len);
 /* validates magic, geometry and every row length (a job is network input) */
 int sda_job_container_parse(const uint8_t* buf, size_t n_bytes, sda_job_layout_t* out);
+/* O(1): validates the header and THIS row's length (not the whole length table) */
 int sda_job_container_get_row(const uint8_t* buf, size_t n_bytes, size_t row, const uint8_t** payload, size_t* len);
 
 /* RFC 4648 base64 (standard alphabet, '=' padding, strict like data_encoding::base64::decode) of P payloads at once,
@@ -478,9 +483,12 @@ int sda_job_container_get_row(const uint8_t* buf, size_t n_bytes, size_t row, co
  *           into a JSON document - d_text_bytes[r] characters; raw bytes to d_out + r * out_slot (4-byte aligned rows),
  *           their count to d_out_bytes[r].  max_chars >= the longest row.  A malformed row (length not a multiple of
  *           4, foreign character, misplaced '=', stray bits under the padding: "Base64 decoding error",
- *           helpers.rs:183) ORs 8 into *d_status and sets d_row_status[r] (optional, zero it beforehand).
+ *           helpers.rs:183) ORs 8 into *d_status and sets d_row_status[r] (optional, zero it beforehand).  A row whose
+ *           d_text_bytes[r] exceeds max_chars is malformed as well (the lengths are network input): d_out_bytes[r] = 0,
+ *           the same status bits, and not one byte of it is read or written.
  *   encode: raw row r at d_in + r * in_slot (4-byte aligned rows) -> text row at d_text + r * text_slot (16-byte
- *           aligned rows, text_slot >= sda_base64_encoded_size(max_bytes)), its length to d_text_bytes[r]. */
+ *           aligned rows, text_slot >= sda_base64_encoded_size(max_bytes)), its length to d_text_bytes[r].  A row
+ *           with d_in_bytes[r] > max_bytes is refused: d_text_bytes[r] = 0, nothing read or written. */
 size_t sda_base64_encoded_size(size_t n_bytes);
 size_t sda_base64_decoded_max(size_t n_chars);
 int sda_base64_decode_rows_dev(const uint8_t* d_text, const uint64_t* d_text_offsets, size_t text_slot,
@@ -501,13 +509,20 @@ int sda_base64_encode_rows_dev(const uint8_t* d_in, size_t in_slot, const uint64
  *                   sda_share_combiner_update_varint_rows_dev consumes, so a job is opened, decoded and summed
  *                   without leaving HBM.  A box that does not authenticate (or is shorter than 48 bytes) gets length
  *                   0, d_ok[r] = 0 (optional array) and ORs 16 into *d_status: the reference fails the whole job with
- *                   "Sodium decryption failure" (sodium.rs:80) - check *d_status before using the sums.
+ *                   "Sodium decryption failure" (sodium.rs:80) - check *d_status before using the sums.  The tags are
+ *                   verified BEFORE the keystream pass and that pass skips the failing rows: the output slot of a box
+ *                   that fails is left exactly as the caller passed it - no unauthenticated plaintext reaches d_out.
  *   seal_rows_dev : message r at d_msgs + r * msg_slot (d_msg_bytes[r] bytes) is sealed to
  *                   pks[(r / rows_per_key) % n_pks] (host array of n_pks 32-byte keys; job-major rows [n][P]:
  *                   rows_per_key = P; participant-major [P][n]: rows_per_key = 1) into d_boxes + r * slot_bytes, its
  *                   length to d_row_bytes[r].  esk: NULL = a fresh ephemeral key pair per box from OS entropy, as
  *                   crypto_box_seal draws it; else `rows` injected 32-byte ephemeral secrets (host) - TESTS ONLY, the
- *                   one way to compare a sealed box bit for bit.
+ *                   one way to compare a sealed box bit for bit.  A recipient key of small order (all-zero shared
+ *                   secret - crypto_box_seal returns -1) is refused per row: d_row_bytes[r] = 0, the epk is written but
+ *                   nothing is encrypted and no tag is stored; the host form returns SDA_ERR_INVALID_ARGUMENT and wipes
+ *                   `out`.  A message longer than max_msg_bytes is refused the same way (length 0).
+ *   A sealed-box handle serves ONE stream at a time: its device scratch (per-row key state, Poly1305 partials, staged
+ *   keys) is shared by all calls, so two calls through one handle on different streams race - use one handle per stream.
  *   All rows and slots 16-byte aligned; max_* bound the longest row (they size the launch).  The host forms stage one
  *   payload through the device (ShareEncryptor::encrypt / ShareDecryptor::decrypt minus the varint codec).
  * ============================================================================================= */
@@ -551,6 +566,7 @@ int  sda_comm_init(const uint8_t id[SDA_COMM_ID_BYTES], int rank, int world, sda
 void sda_comm_free(sda_comm_t* c);
 int  sda_comm_rank(const sda_comm_t* c);
 int  sda_comm_world(const sda_comm_t* c);
+int  sda_comm_device(const sda_comm_t* c);   /* HIP ordinal the communicator was bound to at init; -1 for NULL */
 int  sda_modular_allreduce_dev(sda_comm_t* c, int64_t modulus, const int64_t* d_partial, size_t len, int64_t* d_out,
                                void* stream);
 int  sda_modsum_parts_dev(int64_t modulus, const int64_t* d_parts, size_t parts, size_t part_stride,

@@ -74,6 +74,7 @@ SIGNATURES = {
     "sda_version": (C.c_char_p, []),
     "sda_device_count": (C.c_int, []),
     "sda_set_device": (C.c_int, [C.c_int]),
+    "sda_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "sda_strerror": (C.c_char_p, [C.c_int]),
     "sda_last_error": (C.c_char_p, []),
     "sda_dev_malloc": (C.c_int, [c_voidpp, C.c_size_t]),
@@ -154,7 +155,7 @@ SIGNATURES = {
     "sda_job_slot_size": (C.c_size_t, [C.c_size_t]),
     "sda_job_container_size": (C.c_size_t, [C.c_size_t, C.c_size_t]),
     "sda_job_container_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_size_t, C.POINTER(JobLayout)]),
-    "sda_job_container_set_row": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "sda_job_container_set_row": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]),
     "sda_job_container_parse": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(JobLayout)]),
     "sda_job_container_get_row": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), c_sizep]),
     "sda_base64_encoded_size": (C.c_size_t, [C.c_size_t]),
@@ -176,6 +177,7 @@ SIGNATURES = {
     "sda_comm_free": (None, [_H]),
     "sda_comm_rank": (C.c_int, [_H]),
     "sda_comm_world": (C.c_int, [_H]),
+    "sda_comm_device": (C.c_int, [_H]),
     "sda_modular_allreduce_dev": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "sda_modsum_parts_dev": (C.c_int, [C.c_int64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                        C.c_void_p]),

@@ -543,7 +543,7 @@ class JobContainer:
         lay = capi.JobLayout()
         check(lib.sda_job_container_init(buf, len(blob), kind, rows, slot, C.byref(lay)))
         for r, p in enumerate(payloads):
-            check(lib.sda_job_container_set_row(buf, r, bytes(p), len(p)))
+            check(lib.sda_job_container_set_row(buf, len(blob), r, bytes(p), len(p)))
         del buf
         return cls(blob, lay)
 

@@ -46,22 +46,33 @@ inline int modular_allreduce_plan(Transport& tr, Reducer& red, int rank, int wor
                                   int64_t* recv_scratch, int64_t* mine_scratch, int64_t* out) {
     const SlicePlan pl(world, len);
     const size_t mine = pl.count(rank);
-    int st;
+    // A send / recv that fails between group_start and group_end must not leave the group open (an open ncclGroupStart on
+    // the thread makes the next RCCL call misbehave): the group is always closed, best effort, and the FIRST error wins.
+    auto grouped = [&](auto&& post) -> int {
+        int st = tr.group_start();
+        if (st) return st;
+        st = post();
+        const int end = tr.group_end();
+        return st ? st : end;
+    };
     // reduce-scatter: slice g of every rank meets on rank g
-    if ((st = tr.group_start())) return st;
-    for (int g = 0; g < world; ++g) {
-        if (pl.count(g) && (st = tr.send(partial + pl.offset(g), pl.count(g), g))) return st;
-        if (mine && (st = tr.recv(recv_scratch + (size_t)g * pl.seg, mine, g))) return st;
-    }
-    if ((st = tr.group_end())) return st;
+    int st = grouped([&]() -> int {
+        for (int g = 0; g < world; ++g) {
+            if (pl.count(g)) if (int e = tr.send(partial + pl.offset(g), pl.count(g), g)) return e;
+            if (mine) if (int e = tr.recv(recv_scratch + (size_t)g * pl.seg, mine, g)) return e;
+        }
+        return 0;
+    });
+    if (st) return st;
     if (mine && (st = red.modsum(recv_scratch, (size_t)world, pl.seg, mine, mine_scratch))) return st;
     // all-gather: reduced slice g goes from rank g to everybody, straight into place
-    if ((st = tr.group_start())) return st;
-    for (int g = 0; g < world; ++g) {
-        if (mine && (st = tr.send(mine_scratch, mine, g))) return st;
-        if (pl.count(g) && (st = tr.recv(out + pl.offset(g), pl.count(g), g))) return st;
-    }
-    return tr.group_end();
+    return grouped([&]() -> int {
+        for (int g = 0; g < world; ++g) {
+            if (mine) if (int e = tr.send(mine_scratch, mine, g)) return e;
+            if (pl.count(g)) if (int e = tr.recv(out + pl.offset(g), pl.count(g), g)) return e;
+        }
+        return 0;
+    });
 }
 
 }  // namespace sda

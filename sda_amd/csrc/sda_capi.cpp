@@ -117,6 +117,16 @@ extern "C" int sda_set_device(int ordinal) {
     return SDA_OK;
 }
 
+extern "C" int sda_device_pci_bus_id(int ordinal, char* out, size_t cap) {
+    if (!out || cap < 16) return fail(SDA_ERR_INVALID_ARGUMENT, "pci bus id needs a buffer of at least 16 bytes");
+    out[0] = 0;
+    int n = sda_device_count();
+    if (n == 0) return fail(SDA_ERR_NO_DEVICE, "%s", sda_strerror(SDA_ERR_NO_DEVICE));
+    if (ordinal < 0 || ordinal >= n) return fail(SDA_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (have %d)", ordinal, n);
+    HIP_TRY(hipDeviceGetPCIBusId(out, (int)(cap > 64 ? 64 : cap), ordinal));
+    return SDA_OK;
+}
+
 namespace {
 
 struct Ctx {

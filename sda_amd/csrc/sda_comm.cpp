@@ -144,6 +144,7 @@ extern "C" void sda_comm_free(sda_comm_t* c) {
 
 extern "C" int sda_comm_rank(const sda_comm_t* c) { return c ? c->rank : -1; }
 extern "C" int sda_comm_world(const sda_comm_t* c) { return c ? c->world : 0; }
+extern "C" int sda_comm_device(const sda_comm_t* c) { return c ? c->device : -1; }
 
 extern "C" int sda_modular_allreduce_dev(sda_comm_t* c, int64_t modulus, const int64_t* d_partial, size_t len,
                                          int64_t* d_out, void* stream) {

@@ -145,6 +145,15 @@ extern "C" int sda_sealedbox_seal(sda_sealedbox_t* b, const uint8_t pk[32], cons
     if ((len && hipMemcpy(d_msg, msg, len, hipMemcpyHostToDevice) != hipSuccess) || hipMemcpy(d_len, &l64, 8, hipMemcpyHostToDevice) != hipSuccess)
         return capi_fail(SDA_ERR_HIP, "upload failed");
     if (int st = sda_sealedbox_seal_rows_dev(b, pk, 1, 1, esk, d_msg, mslot, d_len, 1, len, d_box, bslot, d_len + 1, nullptr)) return st;
+    // the per-row verdict: a recipient key of small order gives the all-zero shared secret, which crypto_box_seal refuses
+    // (-1) - the row's length is 0, nothing was encrypted, and the caller gets an error and a wiped buffer, never a box
+    uint64_t sealed = 0;
+    if (hipMemcpy(&sealed, d_len + 1, 8, hipMemcpyDeviceToHost) != hipSuccess) return capi_fail(SDA_ERR_HIP, "download failed");
+    if (sealed != len + SDA_SEALBYTES) {
+        (void)hipMemset(d_msg, 0, mslot);
+        memset(out, 0, out_cap);
+        return capi_fail(SDA_ERR_INVALID_ARGUMENT, "sealing refused: the recipient public key is a small-order point (all-zero shared secret)");
+    }
     if (hipMemcpy(out, d_box, len + SDA_SEALBYTES, hipMemcpyDeviceToHost) != hipSuccess) return capi_fail(SDA_ERR_HIP, "download failed");
     (void)hipMemset(d_msg, 0, mslot);
     return SDA_OK;

@@ -60,7 +60,9 @@ extern "C" int sda_job_container_init(uint8_t* buf, size_t cap, uint32_t payload
     return SDA_OK;
 }
 
-extern "C" int sda_job_container_parse(const uint8_t* buf, size_t n_bytes, sda_job_layout_t* out) {
+namespace {
+// header + geometry + total size of an untrusted blob: everything but the length table (O(1))
+int parse_header(const uint8_t* buf, size_t n_bytes, sda_job_layout_t* out) {
     if (!buf || !out) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_bytes < kHeader || memcmp(buf, kMagic, 8) != 0) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "not an SDAJOBv1 container");
     if (get32(buf + 8) != kHeader) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "unsupported header size %u", get32(buf + 8));
@@ -71,33 +73,45 @@ extern "C" int sda_job_container_parse(const uint8_t* buf, size_t n_bytes, sda_j
         get64(buf + 48) != total || get64(buf + 56) != 0)
         return capi_fail(SDA_ERR_INVALID_ARGUMENT, "inconsistent SDAJOBv1 header");
     if (n_bytes < total) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "truncated container: header says %llu bytes, have %zu", (unsigned long long)total, n_bytes);
-    for (uint64_t r = 0; r < rows; ++r)
-        if (get64(buf + lo + 8 * r) > slot) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "row %llu is longer than its slot", (unsigned long long)r);
     out->payload_kind = kind; out->rows = rows; out->slot_bytes = slot; out->lengths_offset = lo; out->payload_offset = po; out->total_bytes = total;
     return SDA_OK;
 }
+}  // namespace
 
-extern "C" int sda_job_container_set_row(uint8_t* buf, size_t row, const uint8_t* payload, size_t len) {
-    if (!buf) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "buf is NULL");
-    if (memcmp(buf, kMagic, 8) != 0) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "not an SDAJOBv1 container");
-    const uint64_t rows = get64(buf + 16), slot = get64(buf + 24), lo = get64(buf + 32), po = get64(buf + 40);
-    if (row >= rows) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "row %zu out of range (%llu rows)", row, (unsigned long long)rows);
-    if (len > slot) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "payload of %zu bytes does not fit the %llu-byte slot", len, (unsigned long long)slot);
-    if (len && !payload) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "payload is NULL");
-    uint8_t* dst = buf + po + row * slot;
-    if (len) memcpy(dst, payload, len);
-    memset(dst + len, 0, (size_t)(slot - len));        // the tail of a slot is defined (zero), never stale bytes
-    put64(buf + lo + 8 * row, len);
+extern "C" int sda_job_container_parse(const uint8_t* buf, size_t n_bytes, sda_job_layout_t* out) {
+    sda_job_layout_t L;
+    if (int st = parse_header(buf, n_bytes, out ? &L : nullptr)) return st;
+    for (uint64_t r = 0; r < L.rows; ++r)
+        if (get64(buf + L.lengths_offset + 8 * r) > L.slot_bytes) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "row %llu is longer than its slot", (unsigned long long)r);
+    *out = L;
     return SDA_OK;
 }
 
+// the buffer may be a parsed, untrusted blob: its header is re-validated against `cap` before a byte is written
+extern "C" int sda_job_container_set_row(uint8_t* buf, size_t cap, size_t row, const uint8_t* payload, size_t len) {
+    sda_job_layout_t L;
+    if (int st = parse_header(buf, cap, &L)) return st;
+    if (row >= L.rows) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "row %zu out of range (%llu rows)", row, (unsigned long long)L.rows);
+    if (len > L.slot_bytes) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "payload of %zu bytes does not fit the %llu-byte slot", len, (unsigned long long)L.slot_bytes);
+    if (len && !payload) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "payload is NULL");
+    uint8_t* dst = buf + L.payload_offset + row * L.slot_bytes;
+    if (len) memcpy(dst, payload, len);
+    memset(dst + len, 0, (size_t)(L.slot_bytes - len));        // the tail of a slot is defined (zero), never stale bytes
+    put64(buf + L.lengths_offset + 8 * row, len);
+    return SDA_OK;
+}
+
+// O(1) per row: the header is validated (geometry, total size) and this row's length against its slot - iterating a
+// 100k-row job through this call does not rescan the length table every time
 extern "C" int sda_job_container_get_row(const uint8_t* buf, size_t n_bytes, size_t row, const uint8_t** payload, size_t* len) {
     sda_job_layout_t L;
-    if (int st = sda_job_container_parse(buf, n_bytes, &L)) return st;
+    if (int st = parse_header(buf, n_bytes, &L)) return st;
     if (!payload || !len) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
     if (row >= L.rows) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "row %zu out of range", row);
+    const uint64_t n = get64(buf + L.lengths_offset + 8 * row);
+    if (n > L.slot_bytes) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "row %zu is longer than its slot", row);
     *payload = buf + L.payload_offset + row * L.slot_bytes;
-    *len = (size_t)get64(buf + L.lengths_offset + 8 * row);
+    *len = (size_t)n;
     return SDA_OK;
 }
 

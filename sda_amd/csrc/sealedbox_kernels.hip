@@ -187,7 +187,10 @@ __global__ __launch_bounds__(kSbThreads) void sbox_stream_kernel(const uint8_t* 
     __shared__ uint32_t tile[kSbThreads / 64][16][65];                      // [wave][word][block], padded rows
     const size_t r = row0 + blockIdx.y;
     const uint64_t have = lens[r];
-    const bool live = have >= len_sub && have - len_sub <= max_msg;         // a row longer than the caller's bound is refused, never read
+    // a row longer than the caller's bound is refused, never read; a row marked bad - small-order recipient key / all-zero
+    // shared secret (seal and open), or a box that failed authentication (open: the verdict is in before this pass runs) -
+    // is neither encrypted under the degenerate key nor decrypted into the caller's buffer
+    const bool live = have >= len_sub && have - len_sub <= max_msg && !states[r].bad;
     const uint64_t mlen = live ? have - len_sub : 0;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t J0 = (uint64_t)blockIdx.x * kSbThreads + (uint64_t)wave * 64;   // first Salsa20 block of this wave
@@ -302,13 +305,13 @@ __global__ __launch_bounds__(kSbThreads) void sbox_poly_kernel(const uint8_t* __
 // OPEN (seal == 0): compare with the tag in the box; out_bytes[r] = message length, or 0 for a box that fails.
 // SEAL: store the tag, row_bytes_out[r] = message length + 48.
 __global__ __launch_bounds__(64) void sbox_final_kernel(const uint32_t* __restrict__ partial, size_t regions,
-                                                        const SboxState* __restrict__ states, uint8_t* __restrict__ boxes, size_t slot,
+                                                        SboxState* __restrict__ states, uint8_t* __restrict__ boxes, size_t slot,
                                                         const uint64_t* __restrict__ lens, uint64_t len_sub, uint64_t max_msg, size_t rows, int seal,
                                                         uint64_t* __restrict__ out_bytes, uint32_t* __restrict__ ok,
                                                         uint32_t* __restrict__ status) {
     const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (r >= rows) return;
-    const SboxState& st = states[r];
+    SboxState& st = states[r];
     const uint64_t have = lens[r];
     bool good = have >= len_sub && have - len_sub <= max_msg && !st.bad;    // longer than the launch was sized for: refused
     const uint64_t mlen = good ? have - len_sub : 0;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64) void sbox_final_kernel(const uint32_t* __restri
     }
     out_bytes[r] = good ? mlen : 0;
     if (ok) ok[r] = good ? 1u : 0u;
-    if (!good) atomicOr(status, 16u);
+    if (!good) { atomicOr(status, 16u); states[r].bad = 1; }   // the keystream pass that follows leaves this row's output alone
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------
@@ -358,23 +361,26 @@ static SboxKeyArg key_arg(const uint8_t k[32]) {
     return a;
 }
 
+enum SboxPass { kPassStream = 1, kPassPoly = 2 };
+
+// the bulk passes over the rows' payloads: `first` then `second` (each kPassStream, kPassPoly or 0)
 static hipError_t bulk(const uint8_t* d_in, size_t in_slot, size_t in_off, uint8_t* d_out, size_t out_slot, size_t out_off,
                        const uint8_t* d_ct, size_t ct_slot, size_t ct_off, const uint64_t* d_lens, uint64_t len_sub, size_t rows,
-                       size_t max_msg, const SboxState* d_states, uint32_t* d_partial, bool stream_first, hipStream_t s) {
+                       size_t max_msg, const SboxState* d_states, uint32_t* d_partial, int first, int second, hipStream_t s) {
     const size_t regions = sbox_regions(max_msg);
     const uint64_t sblocks = cdiv64(cdiv64(max_msg + 32, 64), kSbThreads);
     const uint64_t pblocks = cdiv64(regions, kSbThreads / 64);
     if (sblocks > 0x7FFFFFFFull || pblocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
     for (size_t r0 = 0; r0 < rows; r0 += 65535) {
         const unsigned nr = (unsigned)(rows - r0 < 65535 ? rows - r0 : 65535);
-        if (stream_first && max_msg)
-            sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), 0, s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
-                                                                                        d_lens, len_sub, max_msg, d_states, r0);
-        sbox_poly_kernel<<<dim3((unsigned)pblocks, nr), dim3(kSbThreads), 0, s>>>(d_ct, ct_slot, ct_off, d_lens, len_sub, max_msg, d_states,
-                                                                                  d_partial, regions, r0);
-        if (!stream_first && max_msg)
-            sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), 0, s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
-                                                                                        d_lens, len_sub, max_msg, d_states, r0);
+        for (int pass : {first, second}) {
+            if (pass == kPassStream && max_msg)
+                sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), 0, s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
+                                                                                            d_lens, len_sub, max_msg, d_states, r0);
+            if (pass == kPassPoly)
+                sbox_poly_kernel<<<dim3((unsigned)pblocks, nr), dim3(kSbThreads), 0, s>>>(d_ct, ct_slot, ct_off, d_lens, len_sub, max_msg, d_states,
+                                                                                          d_partial, regions, r0);
+        }
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
@@ -391,14 +397,17 @@ hipError_t launch_sealedbox_open(const uint8_t pk[32], const uint8_t sk[32], con
     volatile uint32_t* wipe = ask.w;
     for (int i = 0; i < 8; ++i) wipe[i] = 0;
     if (hipError_t e = hipGetLastError()) return e;
-    // tag first, then the keystream xor (both read the ciphertext; the plaintext of a failing box is reported with length 0)
+    // verify, THEN decrypt: the tag of every box is checked before the keystream pass runs, and that pass skips the rows that
+    // failed - no unauthenticated plaintext ever reaches d_out (crypto_box_seal_open writes nothing on failure either)
     if (hipError_t e = bulk(d_boxes, slot, 48, d_out, out_slot, 0, d_boxes, slot, 48, d_row_bytes, 48, rows, max_msg, d_states,
-                            d_partial, false, s))
+                            d_partial, kPassPoly, 0, s))
         return e;
     sbox_final_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_partial, sbox_regions(max_msg), d_states,
                                                                            const_cast<uint8_t*>(d_boxes), slot, d_row_bytes, 48, max_msg, rows, 0,
                                                                            d_out_bytes, d_ok, d_status);
-    return hipGetLastError();
+    if (hipError_t e = hipGetLastError()) return e;
+    return bulk(d_boxes, slot, 48, d_out, out_slot, 0, d_boxes, slot, 48, d_row_bytes, 48, rows, max_msg, d_states, d_partial,
+                kPassStream, 0, s);
 }
 
 hipError_t launch_sealedbox_seal(const uint8_t* d_esk, const uint8_t* d_pks, size_t n_pks, size_t rows_per_key,
@@ -411,7 +420,7 @@ hipError_t launch_sealedbox_seal(const uint8_t* d_esk, const uint8_t* d_pks, siz
     if (hipError_t e = hipGetLastError()) return e;
     // encrypt into the box, then authenticate the ciphertext
     if (hipError_t e = bulk(d_msgs, msg_slot, 0, d_boxes, slot, 48, d_boxes, slot, 48, d_msg_bytes, 0, rows, max_msg_bytes, d_states,
-                            d_partial, true, s))
+                            d_partial, kPassStream, kPassPoly, s))
         return e;
     sbox_final_kernel<<<dim3((unsigned)cdiv64(rows, 64)), dim3(64), 0, s>>>(d_partial, sbox_regions(max_msg_bytes), d_states, d_boxes, slot,
                                                                            d_msg_bytes, 0, max_msg_bytes, rows, 1, d_row_bytes, nullptr, nullptr);

@@ -37,10 +37,17 @@ __global__ __launch_bounds__(kB64Threads) void base64_decode_rows_kernel(const u
                                                                          uint8_t* __restrict__ out, size_t out_slot,
                                                                          uint64_t* __restrict__ out_bytes,
                                                                          uint32_t* __restrict__ status,
-                                                                         uint32_t* __restrict__ row_status, size_t row0) {
+                                                                         uint32_t* __restrict__ row_status, size_t row0,
+                                                                         uint64_t max_chars) {
     const size_t r = row0 + blockIdx.y;
     const uint64_t len = lengths[r];
     const uint64_t c0 = ((uint64_t)blockIdx.x * kB64Threads + threadIdx.x) * 16;      // first character of this lane
+    if (len > max_chars) {
+        // the length is network input (a job blob or a JSON scan): a row longer than the bound the buffers were sized for is
+        // malformed - refused before a single byte of it is read or written (the grid only covers max_chars anyway)
+        if (c0 == 0) { out_bytes[r] = 0; atomicOr(status, 8u); if (row_status) row_status[r] = 1; }
+        return;
+    }
     if (c0 == 0) {                                                                      // the row's byte count
         uint64_t nb = (len / 4) * 3;
         bool bad = (len & 3) != 0;
@@ -106,10 +113,15 @@ __global__ __launch_bounds__(kB64Threads) void base64_decode_rows_kernel(const u
 __global__ __launch_bounds__(kB64Threads) void base64_encode_rows_kernel(const uint8_t* __restrict__ in, size_t in_slot,
                                                                          const uint64_t* __restrict__ in_bytes,
                                                                          uint8_t* __restrict__ text, size_t text_slot,
-                                                                         uint64_t* __restrict__ text_bytes, size_t row0) {
+                                                                         uint64_t* __restrict__ text_bytes, size_t row0,
+                                                                         uint64_t max_bytes) {
     const size_t r = row0 + blockIdx.y;
     const uint64_t n = in_bytes[r];
     const uint64_t b0 = ((uint64_t)blockIdx.x * kB64Threads + threadIdx.x) * 12;        // first byte of this lane
+    if (n > max_bytes) {                      // longer than the slots were sized for: refused, nothing read or written
+        if (b0 == 0) text_bytes[r] = 0;
+        return;
+    }
     if (b0 == 0) text_bytes[r] = (n + 2) / 3 * 4;
     if (b0 >= n) return;
     const uint8_t* src = in + r * in_slot + b0;
@@ -156,7 +168,7 @@ hipError_t launch_base64_decode_rows(const uint8_t* d_text, const uint64_t* d_of
     for (size_t r0 = 0; r0 < rows; r0 += 65535) {
         const unsigned nr = (unsigned)(rows - r0 < 65535 ? rows - r0 : 65535);
         base64_decode_rows_kernel<<<dim3((unsigned)chunks, nr), dim3(kB64Threads), 0, s>>>(d_text, d_offsets, text_slot, d_lengths, d_out,
-                                                                                           out_slot, d_out_bytes, d_status, d_row_status, r0);
+                                                                                           out_slot, d_out_bytes, d_status, d_row_status, r0, max_chars);
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
@@ -170,7 +182,7 @@ hipError_t launch_base64_encode_rows(const uint8_t* d_in, size_t in_slot, const 
     for (size_t r0 = 0; r0 < rows; r0 += 65535) {
         const unsigned nr = (unsigned)(rows - r0 < 65535 ? rows - r0 : 65535);
         base64_encode_rows_kernel<<<dim3((unsigned)chunks, nr), dim3(kB64Threads), 0, s>>>(d_in, in_slot, d_in_bytes, d_text, text_slot,
-                                                                                           d_text_bytes, r0);
+                                                                                           d_text_bytes, r0, max_bytes);
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;

@@ -217,7 +217,7 @@ struct JobContainer {
         j.blob.resize(size < 64 ? 64 : size);
         detail::check(sda_job_container_init(j.blob.data(), j.blob.size(), kind, payloads.size(), slot, &j.layout));
         for (size_t r = 0; r < payloads.size(); ++r)
-            detail::check(sda_job_container_set_row(j.blob.data(), r, payloads[r].data(), payloads[r].size()));
+            detail::check(sda_job_container_set_row(j.blob.data(), j.blob.size(), r, payloads[r].data(), payloads[r].size()));
         return j;
     }
     static JobContainer parse(std::vector<uint8_t> bytes) {

@@ -73,6 +73,42 @@ struct CheckerReducer : Reducer {
     }
 };
 
+// error path: an operation that fails inside a group must not leave the group open (an ncclGroupStart without its
+// ncclGroupEnd poisons the thread's next RCCL call) and the FIRST error is the one reported
+struct FailingTransport : Transport {
+    int fail_at, calls = 0, starts = 0, ends = 0, open = 0;
+    bool end_fails = false;
+    int group_start() override { ++starts; ++open; return 0; }
+    int send(const int64_t*, size_t, int) override { return ++calls == fail_at ? 77 : 0; }
+    int recv(int64_t*, size_t, int) override { return ++calls == fail_at ? 78 : 0; }
+    int group_end() override { ++ends; --open; return end_fails && fail_at && calls >= fail_at ? 79 : 0; }   // fails after a failed operation
+};
+struct NullReducer : Reducer {
+    int modsum(const int64_t*, size_t, size_t, size_t, int64_t*) override { return 0; }
+};
+static int error_path_checks() {
+    const int world = 4;
+    const size_t len = 10;
+    std::vector<int64_t> partial(len, 1), recv(world * 3 + 1), mine(4), out(len);
+    NullReducer red;
+    for (int fail_at = 1; fail_at <= 16; ++fail_at) {         // 8 operations per group, two groups
+        FailingTransport tr;
+        tr.fail_at = fail_at;
+        tr.end_fails = true;                                  // a failing group_end must not mask the earlier error
+        const int st = modular_allreduce_plan(tr, red, 1, world, partial.data(), len, recv.data(), mine.data(), out.data());
+        const int want = tr.calls % 2 ? 77 : 78;              // odd calls are sends, even calls are receives
+        if (st != want || tr.open != 0 || tr.starts != tr.ends) {
+            fprintf(stderr, "error path: failure at operation %d -> status %d (want %d), %d groups opened, %d closed\n", fail_at, st, want,
+                    tr.starts, tr.ends);
+            return 1;
+        }
+    }
+    FailingTransport ok;
+    ok.fail_at = 0;
+    if (modular_allreduce_plan(ok, red, 1, world, partial.data(), len, recv.data(), mine.data(), out.data()) || ok.starts != 2 || ok.ends != 2) return 1;
+    return 0;
+}
+
 static int run_rank(int rank, int world, size_t len, uint64_t q, bool worst, std::vector<int> fd) {
     std::vector<int64_t> partial(len ? len : 1), out(len ? len : 1, -1);
     for (size_t i = 0; i < len; ++i) partial[i] = value(rank, i, q, worst);
@@ -104,6 +140,7 @@ int main(int argc, char** argv) {
     size_t total = 0;
     for (int g = 0; g < world; ++g) { if (pl.offset(g) != total || pl.count(g) > pl.seg) return 3; total += pl.count(g); }
     if (total != len) return 3;
+    if (error_path_checks()) return 5;
     for (int worst = 0; worst < 2; ++worst) {
         std::vector<std::vector<int>> fds(world, std::vector<int>(world, -1));
         for (int a = 0; a < world; ++a)

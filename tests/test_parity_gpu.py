@@ -7,6 +7,14 @@ import pytest
 
 from conftest import load_golden
 
+
+def _free_port():
+    """a rendezvous port nobody holds right now (fixed ports collide when GPU tests run side by side)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
 pytestmark = pytest.mark.gpu
 
 P62 = 4611686006577364993
@@ -915,7 +923,7 @@ def test_bench_under_torchrun_single_rank_rccl(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SDA_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
+           "127.0.0.1", "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
            "--warmup", "1", "--participants", "128", "--dim", "65536", "--no-cpu-baseline", "--no-additional"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -923,7 +931,10 @@ def test_bench_under_torchrun_single_rank_rccl(gpu):
     assert len(lines) == 1, "stdout must be the ONE JSON line (banners of gloo / RCCL belong on stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["verified_reconstruct_equals_sum"] is True
-    assert d["roofline"]["bound"] == "hbm" and d["value"] > 0
+    assert d["roofline"]["bound"] in ("hbm", "valu") and d["value"] > 0
+    # the machine-readable record of what carried the exchange: the library's communicator spans the one rank
+    assert d["rccl"]["ranks"] == 1 and d["rccl"]["unique_devices"] == 1 and d["rccl"]["path"].startswith("send/recv")
+    assert d["rccl"]["comm_device"] == 0
 
 
 def test_launch_slicing_over_the_grid_limit(gpu):
@@ -1192,7 +1203,7 @@ def test_bench_two_ranks_rccl_refusal_falls_back_loudly(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SDA_SHARE_GPU="try")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--participants", "120", "--dim", "65536", "--no-additional", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -1203,6 +1214,26 @@ def test_bench_two_ranks_rccl_refusal_falls_back_loudly(gpu):
     assert "RCCL" in line["config"]["exchange"]
     if "unavailable" in line["config"]["exchange"]:
         assert "sda_comm_init failed" in out.stderr
+        assert line["rccl"]["ranks"] == 0 and line["rccl"]["path"].startswith("host-staged gloo (RCCL refused")
+    assert line["rccl"]["unique_devices"] == 1
+
+
+def test_bench_refused_communicator_is_fatal_without_the_rehearsal_switch(gpu):
+    """What a real N-GPU node must do when the library's RCCL communicator cannot be set up: exit non-zero and print NO
+    line.  Provoked here by pinning both ranks to device 0 (SDA_BENCH_DEVICE=0; RCCL refuses the duplicate device) WITHOUT
+    SDA_SHARE_GPU, the only switch that allows the host-staged exchange."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "SDA_SHARE_GPU"}
+    env["SDA_BENCH_DEVICE"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--participants", "120", "--dim", "65536", "--no-additional", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode != 0
+    assert "sda_comm_init failed" in out.stderr and "FATAL" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], "a refused communicator must not print a result"
 
 
 @pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--schedule", "serial", "--workload", "additive"]),
@@ -1218,7 +1249,7 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SDA_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29540 + ranks + 7 * len(extra)), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "3",
+           "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "3",
            "--warmup", "1", "--participants", "120", "--dim", "65536", "--no-additional", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -1226,6 +1257,57 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
     assert line["n_gpus"] == ranks and line["verified_reconstruct_equals_sum"] is True
     assert line["config"]["participants_total"] == ranks * 3 * 40 and line["scaling"] == "weak"
     assert f"{ranks * 120} participants" in line["config"]["workload"]                 # the label is what was processed
+    assert line["rccl"] == dict(line["rccl"], ranks=0, unique_devices=1) and "host-staged" in line["rccl"]["path"]
+    assert line["exchange_bytes_per_gpu"] == 8 * line["config"]["share_count"] * -(-65536 // line["config"]["secret_count"])
+
+
+def test_bench_multi_gpu_legs_configs_4_and_5(gpu):
+    """`bench.py --gpus N` (N > 1) as the driver launches it: after the config-3 line, BASELINE config 4 (packed Shamir
+    t=2 k=8 n=26) and config 5 (k=3 t=1 n=8 + Lagrange reveal) run with the job's participants sharded over the ranks,
+    each leg's clerk sums meeting in one modular reduce, each leg verified against the secrets of ALL ranks.  Rehearsed on
+    the one GPU of this box (ranks share it, gloo carries the exchange) at a small job size and dimension."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDA_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--participants", "120", "--dim", "65536", "--no-cpu-baseline", "--leg-participants", "400", "--leg-dim", "98304"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["verified_reconstruct_equals_sum"] is True and line["scaling"] == "weak"
+    legs = line["additional_workloads"]
+    assert set(legs) == {"config4_packed26", "config5_packed_dim16m"}
+    c4, c5 = legs["config4_packed26"], legs["config5_packed_dim16m"]
+    for leg, (k, t, n) in ((c4, (8, 2, 26)), (c5, (3, 1, 8))):
+        cfg = leg["config"]
+        assert (cfg["secret_count"], cfg["privacy_threshold"], cfg["share_count"]) == (k, t, n)
+        assert leg["verified_reconstruct_equals_sum"] is True and leg["n_gpus"] == 2 and leg["value"] > 0
+        assert cfg["participants_total"] == 400 and "200 per GPU" in cfg["job"]
+        assert leg["exchange_bytes_per_gpu"] == 8 * n * -(-98304 // k)
+        assert leg["roofline"]["bound"] in ("hbm", "valu") and leg["scaling"].startswith("strong")
+    assert c5["reveal"]["dim"] == 98304 and c5["reveal"]["ms"] > 0
+
+
+def test_bench_distinct_inputs_mode(gpu):
+    """--inputs distinct: every sub-tile shares different participants (tile i+1's secrets generated on a side stream
+    while tile i runs); the result is verified against the column sums of ALL of them."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--participants", "320", "--tile", "32",
+           "--dim", "65536", "--no-cpu-baseline", "--no-additional", "--inputs", "distinct"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["verified_reconstruct_equals_sum"] is True
+    assert line["config"]["distinct_participants"] == 320 == line["config"]["participants_total"]
+    assert "320 distinct participants" in line["verified_against"]
 
 
 @pytest.mark.parametrize("k,t,n,dim", [(8, 7, 26, 8 * 64 * 5 + 3), (8, 7, 26, 1), (8, 7, 26, 8 * 2048 + 8 * 77), (8, 2, 26, 8 * 300 + 1),

@@ -72,8 +72,26 @@ def test_job_container_refuses_malformed_headers(built):
     assert lib.sda_job_container_init(buf, 4096, 0, 3, 40, None) == capi.ERR_INVALID_ARGUMENT
     assert lib.sda_job_container_init(buf, 100, 0, 3, 48, None) == capi.ERR_INVALID_ARGUMENT      # buffer too small
     assert lib.sda_job_container_init(buf, 4096, 0, 3, 48, None) == capi.OK
-    assert lib.sda_job_container_set_row(buf, 3, b"a", 1) == capi.ERR_INVALID_ARGUMENT
-    assert lib.sda_job_container_set_row(buf, 0, b"a" * 49, 49) == capi.ERR_INVALID_ARGUMENT
-    assert lib.sda_job_container_set_row(buf, 2, b"a" * 48, 48) == capi.OK
+    assert lib.sda_job_container_set_row(buf, 4096, 3, b"a", 1) == capi.ERR_INVALID_ARGUMENT
+    assert lib.sda_job_container_set_row(buf, 4096, 0, b"a" * 49, 49) == capi.ERR_INVALID_ARGUMENT
+    assert lib.sda_job_container_set_row(buf, 4096, 2, b"a" * 48, 48) == capi.OK
+    # set_row re-validates the header against the caller's capacity: a blob whose header claims more rows / a larger slot
+    # than the buffer holds (a parsed, untrusted job) is refused before a byte is written
+    total = lib.sda_job_container_size(3, 48)
+    assert lib.sda_job_container_set_row(buf, total - 1, 2, b"a", 1) == capi.ERR_INVALID_ARGUMENT
+    assert lib.sda_job_container_set_row(buf, total, 2, b"a", 1) == capi.OK
+    lying = (C.c_uint8 * 4096).from_buffer_copy(bytes(buf))
+    lying[16:24] = (1 << 30).to_bytes(8, "little")                        # rows: header no longer consistent with itself
+    assert lib.sda_job_container_set_row(lying, 4096, 2, b"a", 1) == capi.ERR_INVALID_ARGUMENT
+    # get_row is O(1): it checks the header and ITS row's length only - a corrupt length elsewhere does not stop it, the
+    # corrupt row itself is refused, and the full parse still refuses the blob
+    lo = 64
+    bad = (C.c_uint8 * 4096).from_buffer_copy(bytes(buf))
+    bad[lo + 8:lo + 16] = (49).to_bytes(8, "little")                      # row 1 claims 49 bytes in a 48-byte slot
+    pay, ln = C.c_void_p(), C.c_size_t()
+    assert lib.sda_job_container_get_row(bad, 4096, 2, C.byref(pay), C.byref(ln)) == capi.OK and ln.value == 1
+    assert lib.sda_job_container_get_row(bad, 4096, 1, C.byref(pay), C.byref(ln)) == capi.ERR_INVALID_ARGUMENT
+    lay = capi.JobLayout()
+    assert lib.sda_job_container_parse(bad, 4096, C.byref(lay)) == capi.ERR_INVALID_ARGUMENT
     assert lib.sda_base64_encoded_size(0) == 0 and lib.sda_base64_encoded_size(1) == 4 and lib.sda_base64_encoded_size(3) == 4
     assert lib.sda_base64_decoded_max(8) == 6 and lib.sda_job_slot_size(17) == 32

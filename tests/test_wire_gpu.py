@@ -125,6 +125,57 @@ def test_base64_decode_inside_a_json_document_and_malformed_rows(gpu):
     assert np.frombuffer(d_status.to_bytes(), dtype="<u4")[0] == 8
 
 
+def test_rows_longer_than_the_declared_bound_are_refused_not_read(gpu):
+    """Row lengths are network input (a job blob's length table, a JSON scan).  A row whose length exceeds max_chars /
+    max_bytes - including an absurd 2^40 - must be refused without one byte of it read or written: byte count 0, status
+    bit 8 and the row's flag (decode); text length 0 (encode); every neighbour untouched and still decoded."""
+    import base64
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBytes
+    rng = np.random.default_rng(77)
+    rows, n = 6, 48
+    raw = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for _ in range(rows)]
+    texts = [base64.b64encode(b) for b in raw]
+    tl = len(texts[0])
+    text_slot, out_slot = 64, 48
+    blob = bytearray(rows * text_slot)
+    for r, t in enumerate(texts):
+        blob[r * text_slot:r * text_slot + tl] = t
+    lens = [tl, tl + 4, tl, 1 << 40, tl, (1 << 64) - 4]                     # rows 1, 3 and 5 lie about their length
+    d_text = DeviceBytes.from_bytes(blob)
+    d_lens = DeviceBytes.from_bytes(np.array(lens, dtype="<u8").tobytes())
+    d_out = DeviceBytes.from_bytes(b"\xA5" * (rows * out_slot))
+    d_nb = DeviceBytes.from_bytes(np.full(rows, 7, dtype="<u8").tobytes())
+    d_status, d_rs = DeviceBytes(4).zero(), DeviceBytes(rows * 4).zero()
+    crypto.base64_decode_rows_dev(d_text.ptr, text_slot, d_lens.ptr, rows, tl, d_out.ptr, out_slot, d_nb.ptr, d_status.ptr, d_rs.ptr)
+    rs = np.frombuffer(d_rs.to_bytes(), dtype="<u4")
+    nb = _u64(d_nb, rows)
+    ob = d_out.to_bytes()
+    assert list(rs != 0) == [False, True, False, True, False, True]
+    assert np.frombuffer(d_status.to_bytes(), dtype="<u4")[0] == 8
+    for r in range(rows):
+        if r in (1, 3, 5):
+            assert nb[r] == 0 and ob[r * out_slot:(r + 1) * out_slot] == b"\xA5" * out_slot      # not a byte written
+        else:
+            assert nb[r] == n and ob[r * out_slot:(r + 1) * out_slot] == raw[r]
+    # encode: a raw row longer than max_bytes
+    in_slot, tslot = 48, 64
+    d_in = DeviceBytes.from_bytes(b"".join(raw))
+    blens = [n, n + 1, 1 << 40, n]
+    d_blens = DeviceBytes.from_bytes(np.array(blens, dtype="<u8").tobytes())
+    d_t = DeviceBytes.from_bytes(b"\x5A" * (4 * tslot))
+    d_tl = DeviceBytes.from_bytes(np.full(4, 9, dtype="<u8").tobytes())
+    crypto.base64_encode_rows_dev(d_in.ptr, in_slot, d_blens.ptr, 4, n, d_t.ptr, tslot, d_tl.ptr)
+    tlen = _u64(d_tl, 4)
+    tb = d_t.to_bytes()
+    assert list(tlen) == [tl, 0, 0, tl]
+    for r in range(4):
+        if r in (1, 2):
+            assert tb[r * tslot:(r + 1) * tslot] == b"\x5A" * tslot
+        else:
+            assert tb[r * tslot:r * tslot + tl] == texts[r]
+
+
 def test_json_job_to_clerk_sums_on_the_device(gpu):
     """The clerk's side of the reference with the job kept in HBM: the JSON form of a ClerkingJob (base64 strings,
     resources.rs:128-139) -> SDAJOBv1 text container -> base64 decode into a VARINT container's slots -> streaming
