@@ -120,12 +120,10 @@ int main(void) {
         CHECK(sda_share_combiner_new(&additive, &comb));
         CHECK(sda_varint_codec_new(&codec));
         CHECK(sda_sealedbox_new(&sbox));
-        uint8_t sk[32], pk[32], probe[SDA_SEALBYTES], zero_pk[32] = {0};
+        uint8_t sk[32], pk[32];
         for (int i = 0; i < 32; ++i) sk[i] = (uint8_t)(3 * i + 7);
-        /* the public key X25519(sk, 9) is the first 32 bytes of a box sealed with the ephemeral secret sk (key generation
-         * itself stays with the reference's keystore) */
-        CHECK(sda_sealedbox_seal(sbox, zero_pk, sk, NULL, 0, probe, sizeof probe));
-        memcpy(pk, probe, 32);
+        /* the public key X25519(sk, 9) (key generation itself stays with the reference's keystore) */
+        CHECK(sda_sealedbox_public_key(sbox, sk, pk));
         const int64_t inputs[3][10] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9}, {0}, {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}};
         int64_t shares[3][10], clear_sum[10];
         uint8_t wire[128], boxes[3][128 + SDA_SEALBYTES];

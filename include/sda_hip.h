@@ -537,6 +537,9 @@ int  sda_sealedbox_open_rows_dev(sda_sealedbox_t* b, const uint8_t pk[32], const
 int  sda_sealedbox_seal_rows_dev(sda_sealedbox_t* b, const uint8_t* pks, size_t n_pks, size_t rows_per_key, const uint8_t* esk,
                                  const uint8_t* d_msgs, size_t msg_slot, const uint64_t* d_msg_bytes, size_t rows,
                                  size_t max_msg_bytes, uint8_t* d_boxes, size_t slot_bytes, uint64_t* d_row_bytes, void* stream);
+/* pk = X25519(sk, 9) (crypto_scalarmult_base), computed by the seal path's own ladder: lets tests and tools make key
+ * pairs without libsodium; key generation proper stays with the reference's keystore */
+int  sda_sealedbox_public_key(sda_sealedbox_t* b, const uint8_t sk[32], uint8_t pk[32]);
 int  sda_sealedbox_seal(sda_sealedbox_t* b, const uint8_t pk[32], const uint8_t* esk /* NULL = OS entropy */,
                         const uint8_t* msg, size_t len, uint8_t* out, size_t out_cap);
 int  sda_sealedbox_open(sda_sealedbox_t* b, const uint8_t pk[32], const uint8_t sk[32], const uint8_t* box, size_t len,

@@ -170,6 +170,7 @@ SIGNATURES = {
                                               C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sda_sealedbox_seal_rows_dev": (C.c_int, [_H, C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t,
                                               C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "sda_sealedbox_public_key": (C.c_int, [_H, C.c_char_p, C.c_char_p]),
     "sda_sealedbox_seal": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "sda_sealedbox_open": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, c_sizep]),
     "sda_comm_unique_id": (C.c_int, [c_u8p]),

@@ -590,6 +590,13 @@ class SealedBox(_Handle):
         super().__init__()
         check(self._lib.sda_sealedbox_new(C.byref(self._h)))
 
+    def public_key(self, sk: bytes) -> bytes:
+        """X25519(sk, 9): the public half of a key pair (crypto_scalarmult_base) - for tests and tools"""
+        assert len(sk) == 32
+        out = C.create_string_buffer(32)
+        check(self._lib.sda_sealedbox_public_key(self._h, sk, out))
+        return out.raw
+
     def seal(self, message: bytes, pk: bytes, esk: Optional[bytes] = None) -> bytes:
         """sealedbox::seal (sodium.rs:43); esk injects the ephemeral secret key (tests only)"""
         assert len(pk) == 32 and (esk is None or len(esk) == 32)

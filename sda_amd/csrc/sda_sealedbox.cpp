@@ -159,6 +159,22 @@ extern "C" int sda_sealedbox_seal(sda_sealedbox_t* b, const uint8_t pk[32], cons
     return SDA_OK;
 }
 
+// X25519(sk, base point): the setup pass of a seal writes exactly this as the box's first 32 bytes (its "ephemeral" public key),
+// whatever the recipient key is - so an empty message is sealed to the all-zero key and only the epk is read back
+extern "C" int sda_sealedbox_public_key(sda_sealedbox_t* b, const uint8_t sk[32], uint8_t pk[32]) {
+    if (!b || !sk || !pk) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (hipSetDevice(b->device) != hipSuccess) return capi_fail(SDA_ERR_HIP, "hipSetDevice failed");
+    if (int st = reserve(b->d_io, b->io_cap, 64 + 32, true)) return st;
+    uint8_t* d_box = static_cast<uint8_t*>(b->d_io);
+    uint64_t* d_len = reinterpret_cast<uint64_t*>(d_box + 64);
+    const uint8_t zero_pk[32] = {0};
+    if (hipMemset(d_len, 0, 16) != hipSuccess) return capi_fail(SDA_ERR_HIP, "memset failed");
+    if (int st = sda_sealedbox_seal_rows_dev(b, zero_pk, 1, 1, sk, d_box, 16, d_len, 1, 0, d_box, 64, d_len + 1, nullptr)) return st;
+    if (hipMemcpy(pk, d_box, 32, hipMemcpyDeviceToHost) != hipSuccess) return capi_fail(SDA_ERR_HIP, "download failed");
+    (void)hipMemset(d_box, 0, 64);
+    return SDA_OK;
+}
+
 extern "C" int sda_sealedbox_open(sda_sealedbox_t* b, const uint8_t pk[32], const uint8_t sk[32], const uint8_t* box, size_t len,
                                   uint8_t* out, size_t out_cap, size_t* out_len) {
     if (!b || !pk || !sk || !out_len || (len && !box)) return capi_fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");

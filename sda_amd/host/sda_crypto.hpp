@@ -179,6 +179,11 @@ struct SealedBox {
     ~SealedBox() { sda_sealedbox_free(h); }
     SealedBox(const SealedBox&) = delete;
     SealedBox& operator=(const SealedBox&) = delete;
+    EncryptionKey public_key(const DecryptionKey& sk) {            // X25519(sk, 9), for tests and tools
+        EncryptionKey pk(32);
+        detail::check(sda_sealedbox_public_key(h, sk.data(), pk.data()));
+        return pk;
+    }
     Encryption seal(const std::vector<uint8_t>& m, const EncryptionKey& pk, const uint8_t* esk = nullptr) {
         Encryption out(m.size() + SDA_SEALBYTES);
         detail::check(sda_sealedbox_seal(h, pk.data(), esk, m.data(), m.size(), out.data(), out.size()));

@@ -97,12 +97,15 @@ int main() {
     // (participate.rs:82-101, sodium.rs:33-46), the server hands the clerk ONE job (here an SDAJOBv1 blob instead of a
     // JSON array, stores.rs:86-101), the clerk decrypts and combines (clerk.rs:78-86, sodium.rs:72-92)
     {
-        // a key pair: the public key is X25519(sk, 9) = the first 32 bytes of a box sealed with esk = sk
+        // a key pair: the public key is X25519(sk, 9)
         DecryptionKey sk(32);
         for (int i = 0; i < 32; ++i) sk[i] = (uint8_t)(7 * i + 1);
         SealedBox kb;
-        const Encryption probe = kb.seal({}, EncryptionKey(32, 0), sk.data());
-        const EncryptionKey pk(probe.begin(), probe.begin() + 32);
+        const EncryptionKey pk = kb.public_key(sk);
+        // sealing to a small-order key (all-zero shared secret) is refused like crypto_box_seal's -1, never a box anyone can open
+        bool refused = false;
+        try { kb.seal({1, 2, 3}, EncryptionKey(32, 0)); } catch (const SdaClientError&) { refused = true; }
+        EXPECT(refused, "seal to the all-zero public key is refused");
         ShareGenerator gen(add);
         ShareEncryptor enc(pk);
         ShareDecryptor dec(pk, sk);

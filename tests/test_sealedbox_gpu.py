@@ -122,7 +122,7 @@ def test_rows_tamper_and_short_rows(gpu):
     L = job.layout
     d_job = DeviceBytes.from_bytes(bytes(job))
     rows, out_slot = len(boxes), 3072
-    d_out, d_nb = DeviceBytes(rows * out_slot).zero(), DeviceBytes(rows * 8).zero()
+    d_out, d_nb = DeviceBytes.from_bytes(b"\xC3" * (rows * out_slot)), DeviceBytes(rows * 8).zero()
     d_ok, d_status = DeviceBytes(rows * 4).zero(), DeviceBytes(4).zero()
     crypto.SealedBox().open_rows_dev(pk, sk, d_job.ptr + L.payload_offset, L.slot_bytes, d_job.ptr + L.lengths_offset, rows,
                                      max(len(b) for b in boxes), d_out.ptr, out_slot, d_nb.ptr, d_status.ptr, d_ok.ptr)
@@ -135,6 +135,10 @@ def test_rows_tamper_and_short_rows(gpu):
         assert nb[r] == (len(msgs[r]) if verdict[r] else 0)
         if verdict[r]:
             assert ob[r * out_slot:r * out_slot + len(msgs[r])] == msgs[r]
+        else:
+            # verify-then-decrypt: the slot of a box that fails is exactly what the caller passed - no unauthenticated
+            # plaintext of a forged box ever lands in d_out
+            assert ob[r * out_slot:(r + 1) * out_slot] == b"\xC3" * out_slot, r
 
 
 def test_more_rows_than_one_launch_slice(gpu):
@@ -183,6 +187,42 @@ def test_small_order_ephemeral_keys_are_refused(gpu):
         with pytest.raises(capi.SdaError) as e:
             crypto.SealedBox().open(forged, pk, sk)
         assert e.value.code == capi.ERR_SODIUM_DECRYPTION
+
+
+def test_sealing_to_a_small_order_key_is_refused_and_public_key(gpu):
+    """crypto_box_seal returns -1 for a recipient key of small order (all-zero shared secret: anybody could open the box).
+    Host form: an error and a wiped buffer; rows form: length 0 for that row, no tag, the payload NOT encrypted under the
+    degenerate key, the other rows sealed as usual.  Also sda_sealedbox_public_key == X25519(sk, 9) of the oracle."""
+    from sda_amd import capi, crypto
+    from sda_amd.device import DeviceBytes
+    from oracle import sealedbox_oracle as so
+    box = crypto.SealedBox()
+    for sk in (bytes(range(32)), bytes(range(7, 39)), b"\xff" * 32):
+        assert box.public_key(sk) == so.x25519_base(sk)
+    small = [bytes(32), (1).to_bytes(32, "little"),
+             bytes.fromhex("e0eb7a7c3b41b8ae1656e3faf19fc46ada098deb9c32b1fd866205165f49b800")]
+    for pk in small:
+        with pytest.raises(capi.SdaError) as e:
+            box.seal(b"secret shares", pk, bytes(range(1, 33)))
+        assert e.value.code == capi.ERR_INVALID_ARGUMENT and "small-order" in str(e.value)
+    good_sk = bytes(range(9, 41)); good_pk = so.x25519_base(good_sk)
+    msg = bytes(range(200))
+    rows, mslot, bslot = 4, 208, 256
+    pks = [good_pk, small[0], good_pk, small[2]]
+    esk = b"".join(bytes([i + 1]) * 32 for i in range(rows))
+    d_msgs = DeviceBytes.from_bytes(b"".join(msg + bytes(mslot - len(msg)) for _ in range(rows)))
+    d_mb = DeviceBytes.from_bytes(np.full(rows, len(msg), dtype="<u8").tobytes())
+    d_boxes, d_rb = DeviceBytes.from_bytes(b"\x3C" * (rows * bslot)), DeviceBytes(rows * 8).zero()
+    box.seal_rows_dev(pks, 1, d_msgs.ptr, mslot, d_mb.ptr, rows, len(msg), d_boxes.ptr, bslot, d_rb.ptr, esk=esk)
+    rb = np.frombuffer(d_rb.to_bytes(), dtype="<u8")
+    bb = d_boxes.to_bytes()
+    assert list(rb) == [len(msg) + 48, 0, len(msg) + 48, 0]
+    for r in range(rows):
+        got = bb[r * bslot:(r + 1) * bslot]
+        if r in (0, 2):
+            assert got[:len(msg) + 48] == so.seal(msg, good_pk, esk[32 * r:32 * r + 32])
+        else:
+            assert got[32:] == b"\x3C" * (bslot - 32)              # no tag, no ciphertext: only the epk was written
 
 
 def test_rows_longer_than_the_declared_bound_are_refused_not_read(gpu):

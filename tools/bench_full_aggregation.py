@@ -39,7 +39,7 @@ status = DeviceBytes(4).zero()
 gen = crypto.ShareGenerator(sch)
 comb = crypto.ShareCombiner(sch)
 sks = [bytes([c + 1]) * 32 for c in range(n)]
-pks = [box.seal(b"", bytes(32), sk)[:32] for sk in sks]        # a box's first 32 bytes are X25519(esk, 9): the clerks' public keys
+pks = [box.public_key(sk) for sk in sks]                        # X25519(sk, 9): the clerks' public keys
 
 
 def ev():

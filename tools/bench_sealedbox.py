@@ -29,7 +29,7 @@ pk = (C.c_uint8 * 32)()
 # the clerk's public key = X25519(sk, 9): computed by sealing an empty message to the base point?  No - simplest: the
 # library has no key-generation entry point (the keystore is out of scope); derive it with the oracle-free trick that
 # a sealed box's first 32 bytes are X25519(esk, 9)
-pk = box.seal(b"", bytes(32), sk)[:32]
+pk = box.public_key(sk)
 
 
 def ev():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r02/<workload>/{pmc_hbm.json, bench_under_rocprof.json} -> profiles/traffic.json (HBM bytes per launch of the
+"""profiles/rNN/final/<workload>/{pmc_hbm.json, bench_under_rocprof.json} -> profiles/traffic.json (HBM bytes per launch of the
 dominant kernel, FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide coalesced reads on
-gfx950, WRITE_SIZE as reported) and a summary table on stdout.   python tools/make_traffic.py profiles/r02"""
+gfx950, WRITE_SIZE as reported) and a summary table on stdout.   python tools/make_traffic.py profiles/r03/final"""
 import json, os, sys
 
 root = sys.argv[1]
@@ -45,6 +45,8 @@ for w in sorted(os.listdir(root)):
     meas = entry.get("fused_bytes_per_launch") or (entry.get("gen_bytes_per_launch", 0) + entry.get("comb_bytes_per_launch", 0))
     rows.append((cfg["name"], P, line["value"] / 1e9, line["path_roofline"]["frac_of_hbm_peak"], r["kernel"], r["avg_launch_ms"], alg / 1e9, meas / 1e9))
 json.dump(traffic, open(os.path.join(os.path.dirname(root.rstrip("/")), "traffic.json"), "w"), indent=1)
+# ... and the copy bench.py reads for `roofline.traffic` (always the current round's)
+json.dump(traffic, open(os.path.join(os.path.dirname(os.path.dirname(root.rstrip("/"))), "traffic.json"), "w"), indent=1)
 print("| workload | tile | Gelem/s | path frac of 8 TB/s | dominant kernel | avg launch ms | algorithmic GB/launch | PMC GB/launch |")
 print("|---|---|---|---|---|---|---|---|")
 for r in rows:
