@@ -5,9 +5,21 @@
 // This is the path for LARGE tss-valid shapes (k + t > 32, e.g. tss's PSS_155_728_100: k=100, t=155, n=728), where the
 // dense n x (k+t) matrix form costs n (k+t) multiply-accumulates per batch (185,640) against ~2,200 butterflies here.
 // One workgroup owns a group of G batches (8 = the batches one CSPRNG block serves, or 1 when a batch alone fills the
-// LDS); values live in LDS as lazily reduced signed 64-bit numbers in [-p, p); every multiplication is ONE balanced
-// 31-bit-limb Montgomery product by a table constant (exactness and register bounds: tests/test_fft_model.py).
-// VALU-bound by the butterfly arithmetic; HBM traffic is the algorithmic 8 B in + 8 n / k B out per element.
+// LDS); values live in LDS as lazily reduced UNSIGNED 64-bit numbers.
+//
+// Arithmetic (round 3; exactness and every bound: tests/test_fft_model.py).  p < 2^62, so 4p < 2^64: values are kept in
+// [0, 4p) ("relaxed") or [0, 2p) ("reduced") and a butterfly needs a conditional subtraction of 2p only where a third
+// term would pass 4p.  Every multiplication is by a table constant w with its precomputed companion w' = floor(w 2^64 / p)
+// (Shoup / Harvey): q = hi64(x w'), x w - q p (low 64 bits) lies in [0, 2p) for ANY 64-bit x - one exact 64x64 high
+// product and two low products, ~16 VALU instructions against ~30 for the balanced-limb Montgomery product round 2 used
+// here, and its operand needs no reduction first.
+//
+// Structure.  The zero-extended vector has m2 = k+t+1 non-zero coefficients out of m3 = n+1, and the first two radix-3
+// levels (decimation in time, digit-reversed input) only ever see one coefficient per 3-block, so they are folded into
+// the scatter: one work item scales <= 9 coefficients and writes a finished 9-block (12 multiplications instead of the
+// 18 + 9 of two dense levels + a scaling pass, no zero fill).  The remaining levels run two at a time in registers
+// (radix 9: 9 loads, 18 multiplications, 9 stores per item), with a single radix-3 level first when their number is
+// odd.  Twiddles and their companions sit in LDS (16-byte reads) when the group's values leave room (G = 8).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -18,38 +30,40 @@
 
 namespace sda {
 
-__device__ __forceinline__ int32_t f_sext31(uint32_t x) { return ((int32_t)(x << 1)) >> 1; }
-
-// x in [-p, p] times the packed constant c (lo32 = m0, hi32 = m1; Montgomery form, R = 2^62): result in (-p, p)
-__device__ __forceinline__ int64_t f_mulc(int64_t x, uint64_t c, const L31Params& P) {
-    const int32_t m0 = (int32_t)(uint32_t)c, m1 = (int32_t)(uint32_t)(c >> 32);
-    const int32_t x0 = f_sext31((uint32_t)x);
-    const int32_t x1 = (int32_t)((x - x0) >> 31);
-    int64_t C0 = (int64_t)m0 * x0;
-    const int64_t C1 = (int64_t)m0 * x1 + (int64_t)m1 * x0;
-    const int64_t C2 = (int64_t)m1 * x1;
-    const int32_t q0 = f_sext31((uint32_t)C0 * P.pinvB);
-    C0 += (int64_t)P.p0 * q0;
-    int64_t E = (int64_t)P.p1 * q0 + (C0 >> 31);
-    const int32_t q1 = f_sext31(((uint32_t)C1 + (uint32_t)E) * P.pinvB);
-    E += (int64_t)P.p0 * q1;
-    return (int64_t)P.p1 * q1 + C2 + (C1 >> 31) + ((E + 0x7FFFFFFF) >> 31);
+// x (any 64-bit value) times the constant w < p, given ws = floor(w 2^64 / p): congruent to x w, in [0, 2p)
+__device__ __forceinline__ uint64_t f_mulS(uint64_t x, uint64_t w, uint64_t ws, uint64_t p) {
+    const uint64_t q = __umul64hi(x, ws);
+    return x * w - q * p;
 }
-// [-2p, 2p) -> [-p, p)
-__device__ __forceinline__ int64_t f_narrow(int64_t x, int64_t p) { return x >= 0 ? x - p : x + p; }
-// canonical residue -> centred (-p/2, p/2]
-__device__ __forceinline__ int64_t f_centre(uint64_t v, const L31Params& P) { return (int64_t)(v >= P.h ? v - P.p : v); }
+// [0, 4p) -> [0, 2p)
+__device__ __forceinline__ uint64_t f_red2(uint64_t x, uint64_t p2) { return x >= p2 ? x - p2 : x; }
+
+struct FftConst {
+    uint64_t p, p2;          // modulus, 2p
+    uint64_t om, oms;        // omega_shares^(m3/3) (a primitive cube root of unity) and its companion
+};
+
+// radix-3 butterfly on A, B, C in [0, 2p) (B, C already multiplied by their twiddles): y_d = A + w^d B + w^2d C, in [0, 4p)
+__device__ __forceinline__ void f_r3(uint64_t A, uint64_t Bv, uint64_t Cv, const FftConst& c, uint64_t& y0, uint64_t& y1,
+                                     uint64_t& y2) {
+    const uint64_t w = f_mulS(Bv + c.p2 - Cv, c.om, c.oms, c.p);     // w (B - C); w^2 = -1 - w
+    y0 = f_red2(A + Bv, c.p2) + Cv;
+    y1 = f_red2(A + c.p2 - Cv, c.p2) + w;                            // A - C + w (B - C)
+    y2 = f_red2(A + c.p2 - Bv, c.p2) + (c.p2 - w);                   // A - B - w (B - C)
+}
 
 __device__ __forceinline__ uint32_t f_bitrev(uint32_t i, uint32_t bits) { return bits ? __brev(i) >> (32 - bits) : 0u; }
 __device__ __forceinline__ uint32_t f_trirev(uint32_t i, uint32_t digits) {
     uint32_t r = 0;
     for (uint32_t d = 0; d < digits; ++d) {
-        const uint32_t q = i / 3u;
+        const uint32_t q = __umulhi(i, 0x55555556u);                 // i / 3, exact for i < 2^31
         r = r * 3u + (i - 3u * q);
         i = q;
     }
     return r;
 }
+// exact floor(x / d) for x < 2^16, magic = floor(2^32 / d) + 1 (d > 1), identity for d = 1
+__device__ __forceinline__ uint32_t f_div(uint32_t x, uint32_t d, uint32_t magic) { return d > 1 ? __umulhi(x, magic) : x; }
 
 // one uniform value per (stream, batch, draw) - sda-drbg-v1, identical to drbg_pair() of sda_kernels.hip
 template <int ROUNDS>
@@ -68,29 +82,41 @@ __device__ __noinline__ uint64_t f_drbg_retry(const DrbgKey& key, uint64_t strea
     return val;
 }
 
-template <int ROUNDS>
-__global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, L31Params lp, DrbgKey key, FftPlan F, uint64_t groups,
-                                      uint64_t batches) {
-    extern __shared__ int64_t lds[];
+// TWL: the twiddle tables (with their companions) are copied to LDS; otherwise they are read from global memory
+template <int ROUNDS, bool TWL>
+__global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, FftPlan F, uint64_t groups, uint64_t batches) {
+    extern __shared__ __align__(16) uint64_t lds[];
     const uint32_t T = blockDim.x, tid = threadIdx.x;
     const uint64_t p = blockIdx.x / groups, g = blockIdx.x - p * groups;
     const uint32_t G = F.G, m2 = F.m2, m3 = F.m3, k = F.k, t = F.t;
-    int64_t* X = lds;                         // [G][m2]  secret-node values / coefficients
-    int64_t* Y = lds + (size_t)G * m2;        // [G][m3]  share-point values
-    const int64_t P = (int64_t)lp.p;
+    // LDS: [twiddles of the radix-3 part | twiddles of the radix-2 part |] X [G][m2] | Y [G][m3]
+    const ulonglong2* tw3 = TWL ? reinterpret_cast<const ulonglong2*>(lds) : reinterpret_cast<const ulonglong2*>(F.tw3);
+    const ulonglong2* tw2 = TWL ? reinterpret_cast<const ulonglong2*>(lds) + m3 : reinterpret_cast<const ulonglong2*>(F.tw2);
+    uint64_t* X = lds + (TWL ? 2 * ((size_t)m3 + (m2 >> 1)) : 0);   // secret-node values / coefficients
+    uint64_t* Y = X + (size_t)G * m2;                               // share-point values
+    FftConst c;
+    c.p = mod.m; c.p2 = 2 * mod.m; c.om = F.omega; c.oms = F.omega_s;
     const int64_t* sp = L.secrets + p * L.secrets_stride;
     const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
     const uint64_t stream = L.first_participant + p;
     const uint64_t b_first = g * G;
 
-    // ---- values: [0, secrets (zero-padded, batched.rs:37-43), draws] ------------------------------------------
+    if (TWL) {
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(lds);
+        const ulonglong2* s3 = reinterpret_cast<const ulonglong2*>(F.tw3);
+        const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(F.tw2);
+        for (uint32_t u = tid; u < m3; u += T) dst[u] = s3[u];
+        for (uint32_t u = tid; u < (m2 >> 1); u += T) dst[m3 + u] = s2[u];
+    }
+
+    // ---- values: [0, secrets (zero-padded, batched.rs:37-43), draws], canonical -----------------------------------
     for (uint32_t u = tid; u < G * (k + 1); u += T) {
         const uint32_t j = u / (k + 1), i = u - j * (k + 1);
         const uint64_t b = b_first + j;
-        int64_t v = 0;
+        uint64_t v = 0;
         if (i > 0) {
             const uint64_t e = b * k + (i - 1);
-            if (b < batches && e < L.len) v = f_centre(canon_i64(sp[e], mod.m, mod.mu), lp);
+            if (b < batches && e < L.len) v = canon_i64(sp[e], mod.m, mod.mu);
         }
         X[(size_t)j * m2 + i] = v;
     }
@@ -98,7 +124,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, L31Params lp, 
         for (uint32_t u = tid; u < G * t; u += T) {
             const uint32_t j = u / t, i = u - j * t;
             const uint64_t b = b_first + j;
-            X[(size_t)j * m2 + 1 + k + i] = b < batches ? f_centre(canon_i64(rp[b * t + i], mod.m, mod.mu), lp) : 0;
+            X[(size_t)j * m2 + 1 + k + i] = b < batches ? canon_i64(rp[b * t + i], mod.m, mod.mu) : 0;
         }
     } else if (G == 8) {                      // one CSPRNG block serves draw i of the 8 batches of this group
         const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
@@ -108,18 +134,18 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, L31Params lp, 
             chacha_block_lane<ROUNDS>(kk, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream, (uint32_t)(stream >> 32) & 0xFFFFFFu, o);
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const int c = jj >> 1, e = jj & 1;
-                const uint64_t xw = ((uint64_t)o[8 * e + c] << 32) | o[8 * e + 4 + c];
+                const int cc = jj >> 1, e = jj & 1;
+                const uint64_t xw = ((uint64_t)o[8 * e + cc] << 32) | o[8 * e + 4 + cc];
                 uint64_t val;
                 if (!lemire_sample(xw, mod.m, mod.lemire_thr, val))
                     val = f_drbg_retry<ROUNDS>(key, stream, (b_first + jj) * (uint64_t)t + i, mod);
-                X[(size_t)jj * m2 + 1 + k + i] = f_centre(val, lp);
+                X[(size_t)jj * m2 + 1 + k + i] = val;
             }
         }
     } else {                                  // G == 1: this batch uses its two words of each block
         const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
         const uint64_t b = b_first;
-        const int c = (int)((b & 7) >> 1), e = (int)(b & 1);
+        const int cc = (int)((b & 7) >> 1), e = (int)(b & 1);
         for (uint32_t i = tid; i < t; i += T) {
             const uint64_t I = (b >> 3) * (uint64_t)t + i;
             uint32_t o[16];
@@ -127,63 +153,126 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, L31Params lp, 
             uint32_t hi = 0, lo = 0;
 #pragma unroll
             for (int w = 0; w < 16; ++w) {
-                if (w == 8 * e + c) hi = o[w];
-                if (w == 8 * e + 4 + c) lo = o[w];
+                if (w == 8 * e + cc) hi = o[w];
+                if (w == 8 * e + 4 + cc) lo = o[w];
             }
             uint64_t val;
             if (!lemire_sample(((uint64_t)hi << 32) | lo, mod.m, mod.lemire_thr, val))
                 val = f_drbg_retry<ROUNDS>(key, stream, b * (uint64_t)t + i, mod);
-            X[1 + k + i] = f_centre(val, lp);
+            X[1 + k + i] = val;
         }
     }
     __syncthreads();
 
-    // ---- radix-2 inverse transform, decimation in frequency: natural order in, bit-reversed order out ------------
+    // ---- radix-2 inverse transform, decimation in frequency: natural order in, bit-reversed order out; values in [0, 2p) ----
     const uint32_t half2 = m2 >> 1;
     for (uint32_t m = m2, lg = F.a; m >= 2; m >>= 1, --lg) {
         const uint32_t h = m >> 1, step = m2 / m;
         for (uint32_t u = tid; u < G * half2; u += T) {
             const uint32_t j = u >> (F.a - 1), q = u & (half2 - 1);
             const uint32_t blk = q >> (lg - 1), jj = q & (h - 1);
-            int64_t* x = X + (size_t)j * m2 + (size_t)blk * m + jj;
-            const int64_t a = x[0], b = x[h];
-            x[0] = f_narrow(a + b, P);
-            const int64_t d = f_narrow(a - b, P);
-            x[h] = jj ? f_mulc(d, F.tw2[jj * step], lp) : d;
+            uint64_t* x = X + (size_t)j * m2 + (size_t)blk * m + jj;
+            const uint64_t av = x[0], bv = x[h];
+            x[0] = f_red2(av + bv, c.p2);
+            const uint64_t d = av + c.p2 - bv;                             // (0, 4p)
+            if (jj) {
+                const ulonglong2 w = tw2[jj * step];
+                x[h] = f_mulS(d, w.x, w.y, c.p);
+            } else {
+                x[h] = f_red2(d, c.p2);
+            }
         }
         __syncthreads();
     }
 
-    // ---- zero-extension: coefficient j, scaled by 1 / m2, to its digit-reversed position ---------------------------
-    for (uint32_t u = tid; u < G * m3; u += T) Y[u] = 0;
-    __syncthreads();
-    for (uint32_t u = tid; u < G * m2; u += T) {
-        const uint32_t j = u >> F.a, i = u & (m2 - 1);
-        Y[(size_t)j * m3 + f_trirev(i, F.b)] = f_mulc(X[(size_t)j * m2 + f_bitrev(i, F.a)], F.scale, lp);
+    // ---- scale by 1 / m2, zero-extend, and the first TWO radix-3 levels (decimation in time, digit-reversed input) -----
+    // 9-block q of Y takes the coefficients r + e1 S2 + e0 S1 (r = the digit reversal of q over b - 2 digits, S1 = m3 / 3,
+    // S2 = m3 / 9), at position e0 + 3 e1 of the block; those at or beyond m2 are the zero extension.
+    const uint32_t ninth = m3 / 9, S1 = m3 / 3, S2 = ninth;
+    const uint32_t magic_ninth = ninth > 1 ? (uint32_t)(0x100000000ull / ninth) + 1u : 0u;
+    const uint32_t nz = F.nz_mask;
+    for (uint32_t u = tid; u < G * ninth; u += T) {
+        const uint32_t j = f_div(u, ninth, magic_ninth), q = u - j * ninth;
+        const uint32_t r = f_trirev(q, F.b - 2);
+        const uint64_t* xj = X + (size_t)j * m2;
+        uint64_t v[3][3];                                                  // [e1][d]: level-1 outputs
+#pragma unroll
+        for (int e1 = 0; e1 < 3; ++e1) {
+            uint64_t in[3];
+#pragma unroll
+            for (int e0 = 0; e0 < 3; ++e0) {
+                in[e0] = 0;
+                if (nz >> (3 * e0 + e1) & 1u) {                            // uniform: some block has this coefficient
+                    const uint32_t ci = r + (uint32_t)e1 * S2 + (uint32_t)e0 * S1;
+                    if (ci < m2) in[e0] = f_mulS(xj[f_bitrev(ci, F.a)], F.scale, F.scale_s, c.p);
+                }
+            }
+            if ((nz >> (3 + e1) & 1u) || (nz >> (6 + e1) & 1u)) {          // uniform
+                f_r3(in[0], in[1], in[2], c, v[e1][0], v[e1][1], v[e1][2]);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) v[e1][d] = f_red2(v[e1][d], c.p2);
+            } else {
+                v[e1][0] = v[e1][1] = v[e1][2] = in[0];                    // two of three inputs are zero-extension zeros
+            }
+        }
+        uint64_t* y = Y + (size_t)j * m3 + 9u * q;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            uint64_t Bv = v[1][jj], Cv = v[2][jj];
+            if (jj) {
+                const ulonglong2 w1 = tw3[jj * ninth], w2 = tw3[2 * jj * ninth];
+                Bv = f_mulS(Bv, w1.x, w1.y, c.p);
+                Cv = f_mulS(Cv, w2.x, w2.y, c.p);
+            }
+            f_r3(v[0][jj], Bv, Cv, c, y[jj], y[jj + 3], y[jj + 6]);
+        }
     }
     __syncthreads();
 
-    // ---- radix-3 forward transform, decimation in time: digit-reversed order in, natural order out ----------------
-    const uint32_t third = m3 / 3;
-    const uint32_t magic_third = third > 1 ? (uint32_t)(0x100000000ull / third) + 1u : 0u;   // exact for u * third < 2^32
-    uint32_t t3 = 1;
-    for (uint32_t s = 0; s < F.b; ++s, t3 *= 3) {
-        const uint32_t m = 3 * t3, step = m3 / m;
-        const uint32_t magic = t3 > 1 ? (uint32_t)(0x100000000ull / t3) + 1u : 0u;       // exact division of q < 2^16 by t3
-        for (uint32_t u = tid; u < G * third; u += T) {
-            const uint32_t j = third > 1 ? __umulhi(u, magic_third) : u, q = u - j * third;
-            const uint32_t blk = t3 > 1 ? __umulhi(q, magic) : q, jj = q - blk * t3;
-            int64_t* y = Y + (size_t)j * m3 + (size_t)blk * m + jj;
-            const int64_t A = y[0];
-            int64_t Bv = y[t3], C = y[2 * t3];
-            if (jj) {
-                Bv = f_mulc(Bv, F.tw3[jj * step], lp);
-                C = f_mulc(C, F.tw3[2 * jj * step], lp);
+    // ---- remaining radix-3 levels: a single one when their number is odd, then two at a time ---------------------------
+    uint32_t t3 = 9, left = F.b - 2;
+    if (left & 1u) {
+        const uint32_t step = m3 / (3 * t3);
+        const uint32_t magic_third = (uint32_t)(0x100000000ull / S1) + 1u, magic = (uint32_t)(0x100000000ull / t3) + 1u;
+        for (uint32_t u = tid; u < G * S1; u += T) {
+            const uint32_t j = f_div(u, S1, magic_third), q = u - j * S1;
+            const uint32_t blk = f_div(q, t3, magic), jj = q - blk * t3;
+            uint64_t* y = Y + (size_t)j * m3 + (size_t)blk * (3 * t3) + jj;
+            const ulonglong2 w1 = tw3[jj * step], w2 = tw3[2 * jj * step];
+            const uint64_t A = f_red2(y[0], c.p2);
+            const uint64_t Bv = f_mulS(y[t3], w1.x, w1.y, c.p), Cv = f_mulS(y[2 * t3], w2.x, w2.y, c.p);
+            f_r3(A, Bv, Cv, c, y[0], y[t3], y[2 * t3]);
+        }
+        __syncthreads();
+        t3 *= 3; --left;
+    }
+    for (; left; left -= 2, t3 *= 9) {
+        const uint32_t step_a = m3 / (3 * t3), step_b = m3 / (9 * t3);
+        const uint32_t magic = (uint32_t)(0x100000000ull / t3) + 1u;
+        for (uint32_t u = tid; u < G * ninth; u += T) {
+            const uint32_t j = f_div(u, ninth, magic_ninth), q = u - j * ninth;
+            const uint32_t blk = f_div(q, t3, magic), jj = q - blk * t3;
+            uint64_t* y = Y + (size_t)j * m3 + (size_t)blk * (9 * t3) + jj;
+            uint64_t a[9], v[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) a[e] = y[(uint32_t)e * t3];
+            {   // level with blocks of 3 t3: the three butterflies share their twiddles
+                const ulonglong2 w1 = tw3[jj * step_a], w2 = tw3[2 * jj * step_a];
+#pragma unroll
+                for (int e1 = 0; e1 < 3; ++e1) {
+                    const uint64_t A = f_red2(a[3 * e1], c.p2);
+                    const uint64_t Bv = f_mulS(a[3 * e1 + 1], w1.x, w1.y, c.p), Cv = f_mulS(a[3 * e1 + 2], w2.x, w2.y, c.p);
+                    f_r3(A, Bv, Cv, c, v[3 * e1], v[3 * e1 + 1], v[3 * e1 + 2]);
+                }
             }
-            const int64_t w = f_mulc(f_narrow(Bv - C, P), F.omega, lp);
-            y[0] = f_narrow(f_narrow(A + Bv, P) + C, P);              // three-term sums in two steps: 3p does not fit 64 bits
-            y[t3] = f_narrow(f_narrow(A - C, P) + w, P);
-            y[2 * t3] = f_narrow(f_narrow(A - Bv, P) - w, P);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {   // level with blocks of 9 t3: element jj + d t3 of each third
+                const uint32_t jb = jj + (uint32_t)d * t3;
+                const ulonglong2 w1 = tw3[jb * step_b], w2 = tw3[2 * jb * step_b];
+                const uint64_t A = f_red2(v[d], c.p2);
+                const uint64_t Bv = f_mulS(v[3 + d], w1.x, w1.y, c.p), Cv = f_mulS(v[6 + d], w2.x, w2.y, c.p);
+                f_r3(A, Bv, Cv, c, y[(uint32_t)d * t3], y[(uint32_t)(d + 3) * t3], y[(uint32_t)(d + 6) * t3]);
+            }
         }
         __syncthreads();
     }
@@ -194,23 +283,30 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, L31Params lp, 
         const uint32_t sj = G == 8 ? u >> 3 : u, jj = G == 8 ? u & 7u : 0u;   // batch fastest: G consecutive values per clerk row
         const uint64_t b = b_first + jj;
         if (b >= batches) continue;
-        const int64_t v = Y[(size_t)jj * m3 + sj + 1];
-        op[(size_t)sj * L.out_stride_clerk + b] = v < 0 ? v + P : v;
+        uint64_t v = f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2);
+        v = v >= c.p ? v - c.p : v;
+        op[(size_t)sj * L.out_stride_clerk + b] = (int64_t)v;
     }
 }
 
-hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const L31Params& lp, const DrbgKey& key,
-                                      const FftPlan& F, int rounds, hipStream_t s) {
+size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds) {
+    return ((size_t)G * ((size_t)m2 + m3) + (tw_lds ? 2 * ((size_t)m3 + m2 / 2) : 0)) * 8;
+}
+
+hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
+                                      hipStream_t s) {
     const uint64_t batches = (L.len + F.k - 1) / F.k;
     const uint64_t groups = (batches + F.G - 1) / F.G;
     if (groups * L.participants == 0) return hipSuccess;
-    const size_t lds = (size_t)F.G * ((size_t)F.m2 + F.m3) * 8;
-    // 512 threads = 4 waves per SIMD with the two workgroups a CU's LDS holds (PSS_155_728_100: 58 ms per 500 x 1 Mi tile
-    // against 66 with 256 threads, 79 with 1024, 120 with 128); a zero-input shortcut in the first radix-3 level, where
-    // two of three inputs are zero-extension zeros, was measured 7 % SLOWER (divergence) and dropped
-    const unsigned threads = F.G == 1 && F.m3 > 2187 ? 1024u : 512u;
-    auto kern = rounds == 20 ? packed_gen_fft_kernel<20> : rounds == 12 ? packed_gen_fft_kernel<12> : packed_gen_fft_kernel<8>;
+    const size_t lds = fft_lds_bytes(F.m2, F.m3, F.G, F.tw_lds != 0);
+    // 512 threads = 4 waves per SIMD with the two workgroups a CU's LDS holds (PSS_155_728_100, round 2: 58 ms per 500 x 1 Mi
+    // tile against 66 with 256 threads, 79 with 1024, 120 with 128)
+    static const char* env_threads = getenv("SDA_FFT_THREADS");                 // A/B only
+    unsigned threads = F.G == 1 && F.m3 > 2187 ? 1024u : 512u;
+    if (env_threads && atoi(env_threads) >= 64 && atoi(env_threads) <= 1024 && atoi(env_threads) % 64 == 0) threads = (unsigned)atoi(env_threads);
     if (rounds != 20 && rounds != 12 && rounds != 8) return hipErrorInvalidValue;
+    auto kern = F.tw_lds ? (rounds == 20 ? packed_gen_fft_kernel<20, true> : rounds == 12 ? packed_gen_fft_kernel<12, true> : packed_gen_fft_kernel<8, true>)
+                         : (rounds == 20 ? packed_gen_fft_kernel<20, false> : rounds == 12 ? packed_gen_fft_kernel<12, false> : packed_gen_fft_kernel<8, false>);
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     const uint64_t max_blocks = 0x7FFFFFFFull;
@@ -225,12 +321,10 @@ hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, 
         S.out = L.out + p0 * L.out_stride_participant;
         S.participants = cnt;
         S.first_participant = L.first_participant + p0;
-        kern<<<dim3((unsigned)(groups * cnt)), dim3(threads), lds, s>>>(S, mod, lp, key, F, groups, batches);
+        kern<<<dim3((unsigned)(groups * cnt)), dim3(threads), lds, s>>>(S, mod, key, F, groups, batches);
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
 }
-
-size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G) { return (size_t)G * ((size_t)m2 + m3) * 8; }
 
 }  // namespace sda

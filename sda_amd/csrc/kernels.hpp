@@ -86,20 +86,24 @@ hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uin
                                              const DrbgKey& key, int rounds, hipStream_t s);
 
 // packed Shamir, transform form (tss's own radix-2 inverse / radix-3 forward structure) for large tss-valid shapes:
-// k + t + 1 = 2^a = ord(omega_secrets), n + 1 = 3^b = ord(omega_shares), p < 2^62 - 2^31.  Constants are packed
-// balanced limbs in Montgomery form (R = 2^62), like the limb-31 matrix entries.
+// k + t + 1 = 2^a = ord(omega_secrets), n + 1 = 3^b = ord(omega_shares), b >= 2, p < 2^62.  Every constant w travels with
+// its companion floor(w 2^64 / p) (Shoup): table entries are (w, companion) pairs of 16 bytes.
 struct FftPlan {
     uint32_t k, t, n;
     uint32_t m2, a;            // k + t + 1 = 2^a
     uint32_t m3, b;            // n + 1 = 3^b
     uint32_t G;                // batches per workgroup: 8 (one CSPRNG block per draw serves them) or 1
-    const uint64_t* tw2;       // m2 / 2 entries: omega_secrets^-j            (device)
-    const uint64_t* tw3;       // m3 entries:     omega_shares^j              (device)
-    uint64_t omega, scale;     // omega_shares^(m3 / 3), 1 / m2
+    uint32_t tw_lds;           // 1: the workgroup copies both twiddle tables to LDS
+    uint32_t nz_mask;          // bit 3 e0 + e1: e1 (m3 / 9) + e0 (m3 / 3) < m2, i.e. some 9-block of the zero-extended
+                               // vector holds a coefficient at that position (fft_kernels.hip, the folded first two levels)
+    const uint64_t* tw2;       // m2 / 2 pairs: omega_secrets^-j              (device)
+    const uint64_t* tw3;       // m3 pairs:     omega_shares^j                (device)
+    uint64_t omega, omega_s;   // omega_shares^(m3 / 3) and its companion
+    uint64_t scale, scale_s;   // 1 / m2 and its companion
 };
-size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G);
-hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const L31Params& lp, const DrbgKey& key,
-                                      const FftPlan& F, int rounds, hipStream_t s);
+size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds);
+hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
+                                      hipStream_t s);
 
 // packed Shamir, any shape: matrix in global memory, randomness must be materialised (L.rand != 0)
 hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,

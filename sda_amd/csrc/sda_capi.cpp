@@ -539,33 +539,32 @@ static int l31_params(uint64_t p, L31Params& lp) {
     return SDA_OK;
 }
 
-// x -> x * 2^62 mod p, centred, as balanced limbs (lo32 = m0 in [-2^30, 2^30), hi32 = m1)
-static uint64_t pack_l31(uint64_t x, uint64_t p) {
-    const uint64_t B = 1ull << 31;
-    const uint64_t mr = (uint64_t)((((u128)x) << 62) % p);
-    const int64_t c = mr > (p - 1) / 2 ? (int64_t)mr - (int64_t)p : (int64_t)mr;
-    int64_t m0 = (int64_t)((uint64_t)c & (B - 1));
-    if (m0 >= (int64_t)(B >> 1)) m0 -= (int64_t)B;
-    const int64_t m1 = (c - m0) / (int64_t)B;
-    return (uint64_t)(uint32_t)(int32_t)m0 | ((uint64_t)(uint32_t)(int32_t)m1 << 32);
-}
-
 // tss's transform structure applies when k + t + 1 = 2^a = ord(omega_secrets) and n + 1 = 3^b = ord(omega_shares)
-// (SURVEY.md App. B); the kernel also needs p < 2^62 - 2^31 and the group's values in LDS.
-static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, uint32_t& G) {
+// (SURVEY.md App. B); the kernel also needs the group's values in LDS (p < 2^62 holds for every modulus the library takes).
+// Two workgroups per CU (80 KB each) when a group of 8 batches fits, with the twiddle tables in LDS too if there is room.
+static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, uint32_t& G, uint32_t& tw_lds) {
     const uint64_t p = g->mod.m, m2 = (uint64_t)g->k + g->t + 1, m3 = (uint64_t)g->n + 1;
-    if (p >= (1ull << 62) - (1ull << 31)) return false;
+    if (p >= (1ull << 62)) return false;
     a = 0; while ((1ull << a) < m2) ++a;
     if ((1ull << a) != m2) return false;
     uint64_t q = 1; b = 0; while (q < m3) { q *= 3; ++b; }
-    if (q != m3 || m3 > 19683 || m2 > 4096 || m2 > m3) return false;
+    if (q != m3 || b < 2 || m3 > 19683 || m2 > 4096 || m2 > m3) return false;
     const uint64_t w2 = h_canon(g->scheme.omega_secrets, p), w3 = h_canon(g->scheme.omega_shares, p);
     if (h_powmod(w2, m2, p) != 1 || h_powmod(w2, m2 / 2, p) == 1) return false;      // order exactly 2^a
     if (h_powmod(w3, m3, p) != 1 || h_powmod(w3, m3 / 3, p) == 1) return false;      // order exactly 3^b
-    if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 8) <= 64 * 1024) G = 8;
-    else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1) <= 160 * 1024) G = 1;
+    const size_t half_cu = 80 * 1024, whole_cu = 160 * 1024;
+    if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 8, true) <= half_cu) { G = 8; tw_lds = 1; }
+    else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 8, false) <= half_cu) { G = 8; tw_lds = 0; }
+    else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, true) <= half_cu) { G = 1; tw_lds = 1; }
+    else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, false) <= whole_cu) { G = 1; tw_lds = 0; }
     else return false;
     return true;
+}
+
+// a constant and its Shoup companion floor(w 2^64 / p)
+static void shoup_pair(uint64_t w, uint64_t p, uint64_t& out_w, uint64_t& out_s) {
+    out_w = w;
+    out_s = (uint64_t)((((u128)w) << 64) / p);
 }
 
 // the limb-GEMM kernel's constants: centred Montgomery-form (R = 2^64) entries in balanced base-256 digits (the kernel cuts its
@@ -585,24 +584,28 @@ static int build_mfma(sda_share_generator* g) {
     return SDA_OK;
 }
 
-static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G) {
+static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G, uint32_t tw_lds) {
     const uint64_t p = g->mod.m, m2 = (uint64_t)g->k + g->t + 1, m3 = (uint64_t)g->n + 1;
-    SDA_TRY(l31_params(p, g->lp));
     const uint64_t w2 = h_canon(g->scheme.omega_secrets, p), w3 = h_canon(g->scheme.omega_shares, p);
     uint64_t w2i, m2i;
     if (!h_invmod(w2, p, w2i) || !h_invmod(m2 % p, p, m2i)) return fail(SDA_ERR_INVALID_ARGUMENT, "omega_secrets is not invertible");
-    std::vector<uint64_t> tab(m2 / 2 + m3);
+    std::vector<uint64_t> tab(2 * (m3 + m2 / 2));               // [radix-3 twiddles | radix-2 twiddles], (w, companion) pairs
     uint64_t x = 1;
-    for (uint64_t j = 0; j < m2 / 2; ++j) { tab[j] = pack_l31(x, p); x = h_mulmod(x, w2i, p); }
+    for (uint64_t j = 0; j < m3; ++j) { shoup_pair(x, p, tab[2 * j], tab[2 * j + 1]); x = h_mulmod(x, w3, p); }
     x = 1;
-    for (uint64_t j = 0; j < m3; ++j) { tab[m2 / 2 + j] = pack_l31(x, p); x = h_mulmod(x, w3, p); }
+    for (uint64_t j = 0; j < m2 / 2; ++j) { shoup_pair(x, p, tab[2 * (m3 + j)], tab[2 * (m3 + j) + 1]); x = h_mulmod(x, w2i, p); }
     SDA_TRY(g->d_fft.reserve(tab.size() * 8));
     HIP_TRY(hipMemcpy(g->d_fft.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     FftPlan& F = g->fplan;
     F.k = g->k; F.t = g->t; F.n = g->n; F.m2 = (uint32_t)m2; F.a = a; F.m3 = (uint32_t)m3; F.b = b; F.G = G;
-    F.tw2 = g->d_fft.as<uint64_t>(); F.tw3 = g->d_fft.as<uint64_t>() + m2 / 2;
-    F.omega = pack_l31(h_powmod(w3, m3 / 3, p), p);
-    F.scale = pack_l31(m2i, p);
+    F.tw_lds = tw_lds;
+    F.nz_mask = 0;
+    for (uint32_t e0 = 0; e0 < 3; ++e0)
+        for (uint32_t e1 = 0; e1 < 3; ++e1)
+            if (e1 * (m3 / 9) + e0 * (m3 / 3) < m2) F.nz_mask |= 1u << (3 * e0 + e1);
+    F.tw3 = g->d_fft.as<uint64_t>(); F.tw2 = g->d_fft.as<uint64_t>() + 2 * m3;
+    shoup_pair(h_powmod(w3, m3 / 3, p), p, F.omega, F.omega_s);
+    shoup_pair(m2i, p, F.scale, F.scale_s);
     return SDA_OK;
 }
 
@@ -640,11 +643,11 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
                   !getenv("SDA_FORCE_MONT64");
         // the transform form: every tss-valid shape with k + t > 32 (beyond that the matrix kernels run at one wave per SIMD
         // or not at all); SDA_FORCE_FFT=1 selects it for any tss-valid shape (A/B runs, parity tests of small shapes)
-        uint32_t fa = 0, fb = 0, fG = 0;
+        uint32_t fa = 0, fb = 0, fG = 0, ftw = 0;
         if (!getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64") && ((uint64_t)g->k + g->t > 32 || getenv("SDA_FORCE_FFT")) &&
-            fft_shape(g, fa, fb, fG)) {
+            fft_shape(g, fa, fb, fG, ftw)) {
             g->fft = true; g->l31 = g->l31g = g->fast = false;
-            st = build_fft(g, fa, fb, fG);
+            st = build_fft(g, fa, fb, fG, ftw);
         } else if (packed_mfma_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64") &&
                    !getenv("SDA_NO_MFMA") && (g->k + g->t >= 12 || getenv("SDA_FORCE_MFMA"))) {
             // the limb GEMM on the matrix cores: measured ahead of the limb-31 kernel from k + t = 15 with n = 26 (+12 %),
@@ -738,7 +741,7 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
         return SDA_OK;
     }
     if (g->fft) {
-        HIP_TRY(launch_packed_generate_fft(L, g->mod, g->lp, key, g->fplan, g->drbg.rounds, s));
+        HIP_TRY(launch_packed_generate_fft(L, g->mod, key, g->fplan, g->drbg.rounds, s));
         return SDA_OK;
     }
     if (g->mfma) {
