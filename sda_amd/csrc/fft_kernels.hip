@@ -30,23 +30,37 @@
 
 namespace sda {
 
-// x (any 64-bit value) times the constant w < p, given ws = floor(w 2^64 / p): congruent to x w, in [0, 2p)
-__device__ __forceinline__ uint64_t f_mulS(uint64_t x, uint64_t w, uint64_t ws, uint64_t p) {
+// x (any 64-bit value) times the constant w < p, given ws = floor(w 2^64 / p) and np = 2^64 - p: congruent to x w, in
+// [0, 2p).  q = hi64(x ws); the low 64 bits of x w - q p = x w + q np are ONE pair of accumulating 32 x 32 -> 64 products
+// plus four low products into the high word (16 VALU instructions as compiled, 20 in the plain x * w - q * p form)
+__device__ __forceinline__ uint64_t f_mulS(uint64_t x, uint64_t w, uint64_t ws, uint64_t np) {
     const uint64_t q = __umul64hi(x, ws);
-    return x * w - q * p;
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+    const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32), n0 = (uint32_t)np, n1 = (uint32_t)(np >> 32);
+    const uint64_t t = (uint64_t)x0 * w0 + (uint64_t)q0 * n0;
+    const uint32_t h = x0 * w1 + x1 * w0 + q0 * n1 + q1 * n0;
+    return t + ((uint64_t)h << 32);
 }
-// [0, 4p) -> [0, 2p)
-__device__ __forceinline__ uint64_t f_red2(uint64_t x, uint64_t p2) { return x >= p2 ? x - p2 : x; }
+// x < 2m -> x < m (m = 2p: [0, 4p) -> [0, 2p); m = p: [0, 2p) -> canonical).  The borrow of the 64-bit subtraction selects:
+// four instructions, where the compare-and-select form hipcc emits takes five
+__device__ __forceinline__ uint64_t f_csub(uint64_t x, uint64_t m) {
+    uint32_t lo, hi;
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), ml = (uint32_t)m, mh = (uint32_t)(m >> 32);
+    asm("v_sub_co_u32 %0, vcc, %2, %4\n\tv_subb_co_u32 %1, vcc, %3, %5, vcc\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %3, vcc"
+        : "=&v"(lo), "=&v"(hi) : "v"(xl), "v"(xh), "v"(ml), "v"(mh) : "vcc");
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t f_red2(uint64_t x, uint64_t p2) { return f_csub(x, p2); }
 
 struct FftConst {
-    uint64_t p, p2;          // modulus, 2p
+    uint64_t p, p2, np;      // modulus, 2p, 2^64 - p
     uint64_t om, oms;        // omega_shares^(m3/3) (a primitive cube root of unity) and its companion
 };
 
 // radix-3 butterfly on A, B, C in [0, 2p) (B, C already multiplied by their twiddles): y_d = A + w^d B + w^2d C, in [0, 4p)
 __device__ __forceinline__ void f_r3(uint64_t A, uint64_t Bv, uint64_t Cv, const FftConst& c, uint64_t& y0, uint64_t& y1,
                                      uint64_t& y2) {
-    const uint64_t w = f_mulS(Bv + c.p2 - Cv, c.om, c.oms, c.p);     // w (B - C); w^2 = -1 - w
+    const uint64_t w = f_mulS(Bv + c.p2 - Cv, c.om, c.oms, c.np);    // w (B - C); w^2 = -1 - w
     y0 = f_red2(A + Bv, c.p2) + Cv;
     y1 = f_red2(A + c.p2 - Cv, c.p2) + w;                            // A - C + w (B - C)
     y2 = f_red2(A + c.p2 - Bv, c.p2) + (c.p2 - w);                   // A - B - w (B - C)
@@ -95,7 +109,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
     uint64_t* X = lds + (TWL ? 2 * ((size_t)m3 + (m2 >> 1)) : 0);   // secret-node values / coefficients
     uint64_t* Y = X + (size_t)G * m2;                               // share-point values
     FftConst c;
-    c.p = mod.m; c.p2 = 2 * mod.m; c.om = F.omega; c.oms = F.omega_s;
+    c.p = mod.m; c.p2 = 2 * mod.m; c.np = 0 - mod.m; c.om = F.omega; c.oms = F.omega_s;
     const int64_t* sp = L.secrets + p * L.secrets_stride;
     const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
     const uint64_t stream = L.first_participant + p;
@@ -111,7 +125,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
 
     // ---- values: [0, secrets (zero-padded, batched.rs:37-43), draws], canonical -----------------------------------
     for (uint32_t u = tid; u < G * (k + 1); u += T) {
-        const uint32_t j = u / (k + 1), i = u - j * (k + 1);
+        const uint32_t j = f_div(u, k + 1, F.magic_k1), i = u - j * (k + 1);
         const uint64_t b = b_first + j;
         uint64_t v = 0;
         if (i > 0) {
@@ -122,7 +136,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
     }
     if (rp) {
         for (uint32_t u = tid; u < G * t; u += T) {
-            const uint32_t j = u / t, i = u - j * t;
+            const uint32_t j = f_div(u, t, F.magic_t), i = u - j * t;
             const uint64_t b = b_first + j;
             X[(size_t)j * m2 + 1 + k + i] = b < batches ? canon_i64(rp[b * t + i], mod.m, mod.mu) : 0;
         }
@@ -164,23 +178,50 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
     }
     __syncthreads();
 
-    // ---- radix-2 inverse transform, decimation in frequency: natural order in, bit-reversed order out; values in [0, 2p) ----
-    const uint32_t half2 = m2 >> 1;
-    for (uint32_t m = m2, lg = F.a; m >= 2; m >>= 1, --lg) {
-        const uint32_t h = m >> 1, step = m2 / m;
-        for (uint32_t u = tid; u < G * half2; u += T) {
-            const uint32_t j = u >> (F.a - 1), q = u & (half2 - 1);
-            const uint32_t blk = q >> (lg - 1), jj = q & (h - 1);
-            uint64_t* x = X + (size_t)j * m2 + (size_t)blk * m + jj;
+    // ---- radix-2 inverse transform, decimation in frequency: natural order in, bit-reversed order out; values in [0, 2p).
+    // A single radix-2 level first when the number of levels is odd, then two levels at a time in registers (radix 4).
+    uint32_t mblk = m2, lg = F.a;
+    if (lg & 1u) {
+        const uint32_t h = mblk >> 1;
+        for (uint32_t u = tid; u < G * h; u += T) {
+            const uint32_t j = u >> (lg - 1), jj = u & (h - 1);
+            uint64_t* x = X + (size_t)j * m2 + jj;
             const uint64_t av = x[0], bv = x[h];
+            const ulonglong2 w = tw2[jj];
             x[0] = f_red2(av + bv, c.p2);
-            const uint64_t d = av + c.p2 - bv;                             // (0, 4p)
-            if (jj) {
-                const ulonglong2 w = tw2[jj * step];
-                x[h] = f_mulS(d, w.x, w.y, c.p);
-            } else {
-                x[h] = f_red2(d, c.p2);
+            x[h] = f_mulS(av + c.p2 - bv, w.x, w.y, c.np);                  // the table's entry 0 is 1 with its companion
+        }
+        __syncthreads();
+        mblk >>= 1; --lg;
+    }
+    for (; lg >= 2; lg -= 2, mblk >>= 2) {
+        const uint32_t qd = mblk >> 2, step = m2 / mblk;                   // quarter of a block; twiddle stride of the outer level
+        const uint32_t items = m2 >> 2;                                     // per batch
+        for (uint32_t u = tid; u < G * items; u += T) {
+            const uint32_t j = u >> (F.a - 2), i = u & (items - 1);
+            const uint32_t blk = i >> (lg - 2), jj = i & (qd - 1);
+            uint64_t* x = X + (size_t)j * m2 + (size_t)blk * mblk + jj;
+            const uint64_t x0 = x[0], x1 = x[qd], x2 = x[2 * qd], x3 = x[3 * qd];
+            // level with blocks of mblk: (x0, x2) and (x1, x3), twiddles w^jj and w^(jj + qd)
+            const uint64_t a0 = f_red2(x0 + x2, c.p2), a1 = f_red2(x1 + x3, c.p2);
+            const ulonglong2 wb = tw2[(jj + qd) * step];
+            const uint64_t a3 = f_mulS(x1 + c.p2 - x3, wb.x, wb.y, c.np);
+            uint64_t a2, b1, b3;
+            if (qd > 1) {
+                const ulonglong2 wa = tw2[jj * step], wc = tw2[2 * jj * step];
+                a2 = f_mulS(x0 + c.p2 - x2, wa.x, wa.y, c.np);
+                // level with blocks of mblk / 2: (a0, a1) and (a2, a3), twiddle (w^2)^jj
+                b1 = f_mulS(a0 + c.p2 - a1, wc.x, wc.y, c.np);
+                b3 = f_mulS(a2 + c.p2 - a3, wc.x, wc.y, c.np);
+            } else {                                                        // the last pass: jj = 0, those twiddles are 1
+                a2 = f_red2(x0 + c.p2 - x2, c.p2);
+                b1 = f_red2(a0 + c.p2 - a1, c.p2);
+                b3 = f_red2(a2 + c.p2 - a3, c.p2);
             }
+            x[0] = f_red2(a0 + a1, c.p2);
+            x[qd] = b1;
+            x[2 * qd] = f_red2(a2 + a3, c.p2);
+            x[3 * qd] = b3;
         }
         __syncthreads();
     }
@@ -204,7 +245,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 in[e0] = 0;
                 if (nz >> (3 * e0 + e1) & 1u) {                            // uniform: some block has this coefficient
                     const uint32_t ci = r + (uint32_t)e1 * S2 + (uint32_t)e0 * S1;
-                    if (ci < m2) in[e0] = f_mulS(xj[f_bitrev(ci, F.a)], F.scale, F.scale_s, c.p);
+                    if (ci < m2) in[e0] = f_mulS(xj[f_bitrev(ci, F.a)], F.scale, F.scale_s, c.np);
                 }
             }
             if ((nz >> (3 + e1) & 1u) || (nz >> (6 + e1) & 1u)) {          // uniform
@@ -221,8 +262,8 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
             uint64_t Bv = v[1][jj], Cv = v[2][jj];
             if (jj) {
                 const ulonglong2 w1 = tw3[jj * ninth], w2 = tw3[2 * jj * ninth];
-                Bv = f_mulS(Bv, w1.x, w1.y, c.p);
-                Cv = f_mulS(Cv, w2.x, w2.y, c.p);
+                Bv = f_mulS(Bv, w1.x, w1.y, c.np);
+                Cv = f_mulS(Cv, w2.x, w2.y, c.np);
             }
             f_r3(v[0][jj], Bv, Cv, c, y[jj], y[jj + 3], y[jj + 6]);
         }
@@ -240,17 +281,24 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
             uint64_t* y = Y + (size_t)j * m3 + (size_t)blk * (3 * t3) + jj;
             const ulonglong2 w1 = tw3[jj * step], w2 = tw3[2 * jj * step];
             const uint64_t A = f_red2(y[0], c.p2);
-            const uint64_t Bv = f_mulS(y[t3], w1.x, w1.y, c.p), Cv = f_mulS(y[2 * t3], w2.x, w2.y, c.p);
+            const uint64_t Bv = f_mulS(y[t3], w1.x, w1.y, c.np), Cv = f_mulS(y[2 * t3], w2.x, w2.y, c.np);
             f_r3(A, Bv, Cv, c, y[0], y[t3], y[2 * t3]);
         }
         __syncthreads();
         t3 *= 3; --left;
     }
+    int64_t* op = L.out + p * L.out_stride_participant;
+    bool stored = false;
     for (; left; left -= 2, t3 *= 9) {
         const uint32_t step_a = m3 / (3 * t3), step_b = m3 / (9 * t3);
         const uint32_t magic = (uint32_t)(0x100000000ull / t3) + 1u;
+        // the LAST pass (one block of 9 t3 = m3 per batch) hands its evaluations straight to global memory: items are then
+        // dealt batch-fastest, so that 8 neighbouring lanes store the 8 batches of one clerk row (64 contiguous bytes)
+        const bool last = left == 2;
         for (uint32_t u = tid; u < G * ninth; u += T) {
-            const uint32_t j = f_div(u, ninth, magic_ninth), q = u - j * ninth;
+            uint32_t j, q;
+            if (last && G == 8) { j = u & 7u; q = u >> 3; }
+            else { j = f_div(u, ninth, magic_ninth); q = u - j * ninth; }
             const uint32_t blk = f_div(q, t3, magic), jj = q - blk * t3;
             uint64_t* y = Y + (size_t)j * m3 + (size_t)blk * (9 * t3) + jj;
             uint64_t a[9], v[9];
@@ -261,31 +309,45 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
 #pragma unroll
                 for (int e1 = 0; e1 < 3; ++e1) {
                     const uint64_t A = f_red2(a[3 * e1], c.p2);
-                    const uint64_t Bv = f_mulS(a[3 * e1 + 1], w1.x, w1.y, c.p), Cv = f_mulS(a[3 * e1 + 2], w2.x, w2.y, c.p);
+                    const uint64_t Bv = f_mulS(a[3 * e1 + 1], w1.x, w1.y, c.np), Cv = f_mulS(a[3 * e1 + 2], w2.x, w2.y, c.np);
                     f_r3(A, Bv, Cv, c, v[3 * e1], v[3 * e1 + 1], v[3 * e1 + 2]);
                 }
             }
+            uint64_t o[9];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {   // level with blocks of 9 t3: element jj + d t3 of each third
                 const uint32_t jb = jj + (uint32_t)d * t3;
                 const ulonglong2 w1 = tw3[jb * step_b], w2 = tw3[2 * jb * step_b];
                 const uint64_t A = f_red2(v[d], c.p2);
-                const uint64_t Bv = f_mulS(v[3 + d], w1.x, w1.y, c.p), Cv = f_mulS(v[6 + d], w2.x, w2.y, c.p);
-                f_r3(A, Bv, Cv, c, y[(uint32_t)d * t3], y[(uint32_t)(d + 3) * t3], y[(uint32_t)(d + 6) * t3]);
+                const uint64_t Bv = f_mulS(v[3 + d], w1.x, w1.y, c.np), Cv = f_mulS(v[6 + d], w2.x, w2.y, c.np);
+                f_r3(A, Bv, Cv, c, o[d], o[d + 3], o[d + 6]);
+            }
+            if (!last) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) y[(uint32_t)e * t3] = o[e];
+            } else {
+                // shares = evaluations 1..n, canonical, clerk-major (batched.rs:46-48); evaluation 0 is f(1) = 0
+                const uint64_t b = b_first + j;
+                if (b < batches) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) {
+                        const uint32_t pos = jj + (uint32_t)e * t3;
+                        if (pos) op[(size_t)(pos - 1) * L.out_stride_clerk + b] = (int64_t)f_csub(f_red2(o[e], c.p2), c.p);
+                    }
+                }
             }
         }
-        __syncthreads();
+        if (!last) __syncthreads();
+        stored = last;
     }
+    if (stored) return;
 
-    // ---- shares = evaluations 1..n, canonical, clerk-major (batched.rs:46-48) -------------------------------------
-    int64_t* op = L.out + p * L.out_stride_participant;
+    // ---- shares = evaluations 1..n from LDS (shapes without a radix-9 pass), canonical, clerk-major ------------------------
     for (uint32_t u = tid; u < G * F.n; u += T) {
         const uint32_t sj = G == 8 ? u >> 3 : u, jj = G == 8 ? u & 7u : 0u;   // batch fastest: G consecutive values per clerk row
         const uint64_t b = b_first + jj;
         if (b >= batches) continue;
-        uint64_t v = f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2);
-        v = v >= c.p ? v - c.p : v;
-        op[(size_t)sj * L.out_stride_clerk + b] = (int64_t)v;
+        op[(size_t)sj * L.out_stride_clerk + b] = (int64_t)f_csub(f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2), c.p);
     }
 }
 

@@ -100,6 +100,7 @@ struct FftPlan {
     const uint64_t* tw3;       // m3 pairs:     omega_shares^j                (device)
     uint64_t omega, omega_s;   // omega_shares^(m3 / 3) and its companion
     uint64_t scale, scale_s;   // 1 / m2 and its companion
+    uint32_t magic_k1, magic_t; // floor(2^32 / d) + 1 for d = k + 1 and d = t (exact quotients of the loader's small indices)
 };
 size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds);
 hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
@@ -120,7 +121,7 @@ hipError_t launch_drbg_fill(int64_t* d_out, size_t stride, size_t participants, 
 // acc (lo, hi) += sum over rows; element (job, row, i) at shares + job*job_stride + row*row_stride + i
 hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const int64_t* d_shares,
                                  size_t jobs, size_t job_stride, size_t n_rows, size_t row_stride,
-                                 size_t dimension, hipStream_t s, unsigned max_wg_per_cu = 0);
+                                 size_t dimension, hipStream_t s, unsigned max_wg_per_cu = 0, unsigned walk_workgroups = 0);
 hipError_t launch_combine_finish(const uint64_t* d_acc_lo, const int64_t* d_acc_hi, size_t count,
                                  const ModParams& mod, int64_t* d_out, hipStream_t s);
 

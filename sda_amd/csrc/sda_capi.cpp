@@ -460,6 +460,24 @@ struct sda_share_generator {
     Drbg drbg;
     Ctx ctx;
     DevBuf d_M, d_secrets, d_rand, d_out;
+    // generate_combine_dev for shapes without a dual-role kernel: the clerk sum of the previous tile runs on this side stream
+    // beside the share generation (fork / join with events), created on first use
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int side_stream() {
+        if (aux) return SDA_OK;
+        // a stream of another priority class gets a hardware queue of its own (plain streams are dealt round-robin over a
+        // few queues and this one landed on the default stream's: both kernels then ran back to back, rocprofv3 queue ids)
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        // LOW priority: the transform kernel's workgroups (8 waves + 77 KB of LDS each) must keep being dispatched first; the
+        // clerk sum takes the wave slots and registers they leave (at high priority it starved them: no gain, measured)
+        const char* pr = getenv("SDA_SIDE_STREAM_PRIORITY");                        // A/B only: "high"
+        HIP_TRY(hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, pr && pr[0] == 'h' ? greatest : least));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        return SDA_OK;
+    }
 };
 
 // Builds the n x (k+t) share matrix of tss::packed::PackedSecretSharing::share:
@@ -606,6 +624,8 @@ static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G,
     F.tw3 = g->d_fft.as<uint64_t>(); F.tw2 = g->d_fft.as<uint64_t>() + 2 * m3;
     shoup_pair(h_powmod(w3, m3 / 3, p), p, F.omega, F.omega_s);
     shoup_pair(m2i, p, F.scale, F.scale_s);
+    F.magic_k1 = (uint32_t)(0x100000000ull / ((uint64_t)g->k + 1)) + 1u;                 // k + 1 >= 2
+    F.magic_t = g->t > 1 ? (uint32_t)(0x100000000ull / g->t) + 1u : 0u;
     return SDA_OK;
 }
 
@@ -678,6 +698,9 @@ extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
     if (!g) return;
     if (g->ctx.device >= 0) (void)hipSetDevice(g->ctx.device);
     g->d_M.release(); g->d_fft.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
+    if (g->aux) { (void)hipStreamSynchronize(g->aux); (void)hipStreamDestroy(g->aux); }
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     g->ctx.destroy();
     g->drbg.wipe();
     delete g->matarg;
@@ -922,12 +945,41 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     }
     int st = SDA_OK;
     if (he != hipSuccess) st = fail(SDA_ERR_HIP, "dual-role launch failed: %s", hipGetErrorString(he));
-    // layouts / shapes the dual-role kernel does not cover: the two ordinary launches, same result
-    if (st == SDA_OK && !fused && prev_participants > 0)
-        st = sda_share_combiner_update_dev(c, d_prev, out_stride_clerk, prev_participants, out_stride_participant, stream);
-    if (st == SDA_OK && !fused && participants > 0 && len > 0)
-        st = generate_batch_impl(g, key, d_secrets, participants, len, secrets_stride, nullptr, 0, first_participant,
-                                 d_out, out_stride_participant, out_stride_clerk, stream);
+    // layouts / shapes the dual-role kernel does not cover: the two ordinary launches, same result.  The transform kernel is
+    // bound by its vector ALUs (two workgroups per CU, LDS-limited, 0.9 TB/s of HBM traffic) and the clerk sum by HBM, so for
+    // that shape the clerk sum of the previous tile is issued on a side stream and runs in the wave slots the transform
+    // kernel leaves free: fork after whatever precedes this call on `stream`, join before anything that follows it
+    const bool both = prev_participants > 0 && participants > 0 && len > 0;
+    if (st == SDA_OK && !fused && both && g->fft && !getenv("SDA_NO_SIDE_STREAM")) {
+        st = g->side_stream();
+        if (st == SDA_OK) {
+            hipError_t e = hipEventRecord(g->ev_fork, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(g->aux, g->ev_fork, 0);
+            if (e != hipSuccess) st = fail(SDA_ERR_HIP, "fork to the side stream failed: %s", hipGetErrorString(e));
+        }
+        if (st == SDA_OK)
+            st = generate_batch_impl(g, key, d_secrets, participants, len, secrets_stride, nullptr, 0, first_participant,
+                                     d_out, out_stride_participant, out_stride_clerk, stream);
+        if (st == SDA_OK) {
+            // one clerk-sum workgroup per CU (4 waves, 72 registers: what two transform workgroups leave free on every SIMD),
+            // walking the job in grid strides
+            static const char* ww = getenv("SDA_SIDE_STREAM_WGS");                 // A/B only
+            const unsigned walk = ww ? (unsigned)atoi(ww) : 256u;
+            hipError_t e = launch_combine_update(c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, c->jobs, out_stride_clerk,
+                                                 prev_participants, out_stride_participant, c->dimension, g->aux, 0, walk);
+            if (e != hipSuccess) st = fail(SDA_ERR_HIP, "clerk-sum launch on the side stream failed: %s", hipGetErrorString(e));
+        }
+        // join even after a failure, so that `stream` never runs ahead of work already queued on the side stream
+        hipError_t e = hipEventRecord(g->ev_join, g->aux);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, g->ev_join, 0);
+        if (e != hipSuccess && st == SDA_OK) st = fail(SDA_ERR_HIP, "join from the side stream failed: %s", hipGetErrorString(e));
+    } else {
+        if (st == SDA_OK && !fused && prev_participants > 0)
+            st = sda_share_combiner_update_dev(c, d_prev, out_stride_clerk, prev_participants, out_stride_participant, stream);
+        if (st == SDA_OK && !fused && participants > 0 && len > 0)
+            st = generate_batch_impl(g, key, d_secrets, participants, len, secrets_stride, nullptr, 0, first_participant,
+                                     d_out, out_stride_participant, out_stride_clerk, stream);
+    }
     explicit_bzero(&key, sizeof key);
     return st;
 }

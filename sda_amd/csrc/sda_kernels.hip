@@ -891,6 +891,22 @@ __global__ __launch_bounds__(kThreads) void combine_update_kernel(uint64_t* __re
                               blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// The same sum with a FIXED number of workgroups, each walking the (column block, job, row split) items in grid strides:
+// launched beside a VALU-bound kernel on another stream it occupies exactly the wave slots and registers it was sized
+// for (one workgroup of 4 waves per CU) instead of taking every slot the other kernel's workgroups free.
+template <bool VEC, int UNROLL>
+__global__ __launch_bounds__(kThreads) void combine_update_walk_kernel(uint64_t* __restrict__ acc_lo, int64_t* __restrict__ acc_hi,
+                                                                       const int64_t* __restrict__ shares, size_t job_stride,
+                                                                       size_t n_rows, size_t row_stride, size_t dimension,
+                                                                       size_t rows_per_split, bool atomic, uint32_t col_blocks,
+                                                                       uint32_t jobs, uint64_t items) {
+    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint64_t bx = it % col_blocks, rest = it / col_blocks;      // column block fastest: neighbours stream neighbouring lines
+        combine_body<VEC, UNROLL>(acc_lo, acc_hi, shares, job_stride, n_rows, row_stride, dimension, rows_per_split, atomic,
+                                  bx, rest % jobs, rest / jobs);
+    }
+}
+
 // =================================================================================================
 // Dual-role launch: software pipelining across tiles inside ONE grid.
 // Share generation is VALU-bound, the clerk sum HBM-bound; run back to back each leaves the other
@@ -1688,7 +1704,7 @@ hipError_t launch_drbg_fill(int64_t* d_out, size_t stride, size_t participants, 
 
 hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const int64_t* d_shares, size_t jobs,
                                  size_t job_stride, size_t n_rows, size_t row_stride, size_t dimension,
-                                 hipStream_t s, unsigned max_wg_per_cu) {
+                                 hipStream_t s, unsigned max_wg_per_cu, unsigned walk_workgroups) {
     if (jobs == 0 || n_rows == 0 || dimension == 0) return hipSuccess;
     if (jobs > 65535) return hipErrorInvalidConfiguration;
     const uint64_t col_blocks = ceil_div(ceil_div(dimension, 2), kThreads);
@@ -1710,6 +1726,19 @@ hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const in
     // HBM-bound kernel (8 waves per CU already saturate HBM) leaves wave slots to a VALU-bound kernel
     // running on another stream
     const unsigned lds_pad = max_wg_per_cu > 0 ? (160u * 1024u) / max_wg_per_cu - 256u : 0u;
+    if (walk_workgroups > 0) {
+        const uint64_t items = col_blocks * jobs * split;
+        const unsigned wgs = (unsigned)(items < walk_workgroups ? items : walk_workgroups);
+        if (vec)
+            combine_update_walk_kernel<true, 8><<<dim3(wgs), dim3(kThreads), 0, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows, row_stride,
+                                                                                    dimension, rows_per_split, atomic, (uint32_t)col_blocks,
+                                                                                    (uint32_t)jobs, items);
+        else
+            combine_update_walk_kernel<false, 1><<<dim3(wgs), dim3(kThreads), 0, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows, row_stride,
+                                                                                     dimension, rows_per_split, atomic, (uint32_t)col_blocks,
+                                                                                     (uint32_t)jobs, items);
+        return hipGetLastError();
+    }
     if (vec)
         combine_update_kernel<true, 8><<<grid, dim3(kThreads), lds_pad, s>>>(d_acc_lo, d_acc_hi, d_shares, job_stride, n_rows,
                                                                        row_stride, dimension, rows_per_split, atomic);

@@ -1,59 +1,73 @@
-"""Big-int model of the transform form of packed-Shamir share generation (sda_amd/csrc/fft_kernels.hip): tss's own
-algorithm - radix-2 inverse transform over the k+t+1 secret nodes, zero-extension, radix-3 forward transform over the
-n+1 share points (packed_shamir.rs:42 -> tss `share`) - on lazily reduced signed 64-bit values with
-single balanced-31-bit-limb Montgomery multiplications.  Checks exactness against the oracle's FFT and matrix forms
-and that every intermediate fits the registers the kernel keeps it in.  CPU only."""
+"""Big-int model of the transform form of packed-Shamir share generation (sda_amd/csrc/fft_kernels.hip, round 3): tss's
+own algorithm - radix-2 inverse transform over the k+t+1 secret nodes, zero-extension, radix-3 forward transform over the
+n+1 share points (packed_shamir.rs:42 -> tss `share`) - on lazily reduced UNSIGNED 64-bit values with
+Shoup multiplications by table constants, in exactly the kernel's order: a single radix-2 level when their number is odd,
+then radix-4 passes; the first two radix-3 levels folded into the zero-extending scatter; a single radix-3 level when the
+rest is odd, then radix-9 passes.  Checks exactness against the oracle's FFT / matrix / Lagrange forms and that every
+intermediate fits the 64-bit register (and the [0, 2p) / [0, 4p) range) the kernel keeps it in.  CPU only."""
 import random
 
 import pytest
 
 from oracle import pyoracle as po
-from test_limb31_model import B, MB, bal, i32, i64, sext31
+
+M64 = (1 << 64) - 1
+M32 = (1 << 32) - 1
 
 
-def packc(c, p):
-    """host side: a twiddle in Montgomery form (R = 2^62), centred, as balanced limbs"""
-    mr = (c << 62) % p
-    if mr > (p - 1) // 2:
-        mr -= p
-    return bal(mr)
+def u64(x):
+    assert 0 <= x <= M64, x                                      # the kernel's registers: no wrap-around anywhere
+    return x
 
 
 class Dev:
-    """device-side arithmetic with register-width assertions"""
+    """device-side arithmetic with register-width and range assertions"""
 
     def __init__(self, p):
-        assert p % 2 == 1 and p < (1 << 62) - (1 << 31)          # the transform path's precondition (host-checked)
-        self.p, self.pinvB, self.p0, self.p1 = p, (-pow(p, -1, B)) % B, p % B, p >> 31
+        assert 2 <= p < (1 << 62)                                # every modulus the library takes (make_mod): 4p < 2^64
+        self.p, self.p2, self.np = p, 2 * p, (1 << 64) - p
 
-    def split(self, x):
-        assert abs(x) <= self.p                                  # every multiplication input is a narrowed value
-        x0, x1 = bal(x)
-        i32(x0); i32(x1)
-        return x0, x1
+    def pair(self, w):
+        """host side: a constant and its companion floor(w 2^64 / p)"""
+        w %= self.p
+        return w, (w << 64) // self.p
 
-    def mulc(self, x, c):
-        """x in [-p, p] times the constant c = (m0, m1): result in (-p, p), congruent to x * const"""
-        p = self.p
-        m0, m1 = c
-        x0, x1 = self.split(i64(x))
-        C0 = i64(m0 * x0); C1 = i64(i64(m0 * x1) + m1 * x0); C2 = i64(m1 * x1)
-        q0 = sext31(((C0 & 0xFFFFFFFF) * self.pinvB) & 0xFFFFFFFF)
-        C0 = i64(C0 + q0 * self.p0)
-        assert C0 % B == 0
-        E = i64((C0 >> 31) + q0 * self.p1)
-        q1 = sext31((((C1 & 0xFFFFFFFF) + (E & 0xFFFFFFFF)) * self.pinvB) & 0xFFFFFFFF)
-        E = i64(E + q1 * self.p0)
-        assert (C1 + E) % B == 0
-        r = i64(i64(C2 + q1 * self.p1) + (C1 >> 31) + (i64(E + MB) >> 31))
-        assert -p < r < p, (r, p)
+    def mulS(self, x, c):
+        """x (ANY 64-bit value) times the constant c = (w, ws): congruent to x w, in [0, 2p)"""
+        w, ws = c
+        u64(x)
+        q = (x * ws) >> 64
+        r = x * w - q * self.p
+        assert 0 <= r < self.p2, (x, w, r)
+        # the kernel computes the low 64 bits as x w + q (2^64 - p): one pair of accumulating 32 x 32 products plus four
+        # low products into the high word
+        x0, x1, q0, q1 = x & M32, x >> 32, q & M32, q >> 32
+        w0, w1, n0, n1 = w & M32, w >> 32, self.np & M32, self.np >> 32
+        t = (x0 * w0 + q0 * n0) & M64
+        h = (x0 * w1 + x1 * w0 + q0 * n1 + q1 * n0) & M32
+        assert (t + (h << 32)) & M64 == r
         return r
 
-    def narrow2(self, x):
-        """[-2p, 2p) -> [-p, p)"""
-        i64(x)
-        assert -2 * self.p <= x < 2 * self.p
-        return x - self.p if x >= 0 else x + self.p
+    def csub(self, x, m):
+        """x < 2m -> x < m (the borrow of the 64-bit subtraction selects)"""
+        u64(x)
+        assert x < 2 * m, (x, m)
+        return x - m if x >= m else x
+
+    def red2(self, x):
+        return self.csub(x, self.p2)
+
+    def r3(self, A, Bv, Cv, om):
+        """radix-3 butterfly on A, B, C in [0, 2p): y_d = A + w^d B + w^2d C, in [0, 4p)"""
+        p2 = self.p2
+        assert A < p2 and Bv < p2 and Cv < p2
+        w = self.mulS(u64(Bv + p2 - Cv), om)
+        y0 = u64(self.red2(u64(A + Bv)) + Cv)
+        y1 = u64(self.red2(u64(A + p2 - Cv)) + w)
+        y2 = u64(self.red2(u64(A + p2 - Bv)) + (p2 - w))
+        for y in (y0, y1, y2):
+            assert y < 2 * p2
+        return y0, y1, y2
 
 
 def bitrev(i, bits):
@@ -70,53 +84,110 @@ def trirev(i, digits):
 
 def share_transform(dev, k, t, n, w2, w3, secrets, draws):
     """one batch, exactly as the kernel does it"""
-    p = dev.p
+    p, p2 = dev.p, dev.p2
     m2, m3 = k + t + 1, n + 1
     a, b = m2.bit_length() - 1, 0
     while 3 ** b < m3:
         b += 1
-    assert 1 << a == m2 and 3 ** b == m3
+    assert 1 << a == m2 and 3 ** b == m3 and b >= 2
     w2i = pow(w2, -1, p)
-    tw2 = [packc(pow(w2i, j, p), p) for j in range(max(m2 // 2, 1))]
-    tw3 = [packc(pow(w3, j, p), p) for j in range(m3)]
-    omega = packc(pow(w3, m3 // 3, p), p)
-    scale = packc(pow(m2, -1, p), p)
-    centre = lambda v: v - p if v > (p - 1) // 2 else v
-    x = [0] + [centre(s % p) for s in secrets] + [centre(r % p) for r in draws]
-    # radix-2 inverse transform, decimation in frequency: natural order in, bit-reversed order out
-    m = m2
-    while m >= 2:
-        h = m // 2
-        for k0 in range(0, m2, m):
-            for j in range(h):
-                u, v = x[k0 + j], x[k0 + j + h]
-                x[k0 + j] = dev.narrow2(u + v)
-                d = dev.narrow2(u - v)
-                x[k0 + j + h] = dev.mulc(d, tw2[j * (m2 // m)]) if j else d           # w^0 = 1: no multiply
-        m = h
-    # zero-extension: coefficient j (at bit-reversed position), scaled by 1 / m2, to its digit-reversed position
-    y = [0] * m3
-    for j in range(m2):
-        y[trirev(j, b)] = dev.mulc(x[bitrev(j, a)], scale)
-    # radix-3 forward transform, decimation in time: digit-reversed order in, natural order out
-    m = 3
-    while m <= m3:
-        t3 = m // 3
-        step = m3 // m
-        for k0 in range(0, m3, m):
-            for j in range(t3):
-                A, Bv, C = y[k0 + j], y[k0 + j + t3], y[k0 + j + 2 * t3]
-                if j:
-                    Bv = dev.mulc(Bv, tw3[j * step])
-                    C = dev.mulc(C, tw3[2 * j * step])
-                u = dev.mulc(dev.narrow2(Bv - C), omega)
-                # three-term sums in two steps: 3p does not fit a signed 64-bit register when p is close to 2^62
-                y[k0 + j] = dev.narrow2(dev.narrow2(A + Bv) + C)
-                y[k0 + j + t3] = dev.narrow2(dev.narrow2(A - C) + u)
-                y[k0 + j + 2 * t3] = dev.narrow2(dev.narrow2(A - Bv) - u)
-        m *= 3
-    assert y[0] % p == 0                                                           # f(1) = 0 (tss asserts the same)
-    return [v % p for v in y[1:]]
+    tw2 = [dev.pair(pow(w2i, j, p)) for j in range(max(m2 // 2, 1))]
+    tw3 = [dev.pair(pow(w3, j, p)) for j in range(m3)]
+    om = dev.pair(pow(w3, m3 // 3, p))
+    scale = dev.pair(pow(m2, -1, p))
+    x = [0] + [s % p for s in secrets] + [r % p for r in draws]            # canonical
+    # ---- radix-2 inverse transform, decimation in frequency: natural order in, bit-reversed order out, values in [0, 2p)
+    mblk, lg = m2, a
+    if lg & 1:
+        h = mblk // 2
+        for jj in range(h):
+            av, bv = x[jj], x[jj + h]
+            x[jj] = dev.red2(u64(av + bv))
+            x[jj + h] = dev.mulS(u64(av + p2 - bv), tw2[jj])
+        mblk //= 2
+        lg -= 1
+    while lg >= 2:
+        qd, step = mblk // 4, m2 // mblk
+        for i in range(m2 // 4):
+            blk, jj = i // qd, i % qd
+            base = blk * mblk + jj
+            x0, x1, x2, x3 = (x[base + e * qd] for e in range(4))
+            assert max(x0, x1, x2, x3) < p2
+            a0, a1 = dev.red2(u64(x0 + x2)), dev.red2(u64(x1 + x3))
+            a3 = dev.mulS(u64(x1 + p2 - x3), tw2[(jj + qd) * step])
+            if qd > 1:
+                a2 = dev.mulS(u64(x0 + p2 - x2), tw2[jj * step])
+                b1 = dev.mulS(u64(a0 + p2 - a1), tw2[2 * jj * step])
+                b3 = dev.mulS(u64(a2 + p2 - a3), tw2[2 * jj * step])
+            else:
+                a2 = dev.red2(u64(x0 + p2 - x2))
+                b1 = dev.red2(u64(a0 + p2 - a1))
+                b3 = dev.red2(u64(a2 + p2 - a3))
+            x[base], x[base + qd], x[base + 2 * qd], x[base + 3 * qd] = dev.red2(u64(a0 + a1)), b1, dev.red2(u64(a2 + a3)), b3
+        lg -= 2
+        mblk //= 4
+    assert lg == 0
+    # ---- scale by 1 / m2, zero-extend, first two radix-3 levels (decimation in time, digit-reversed input) ----------------
+    y = [None] * m3
+    ninth, S1 = m3 // 9, m3 // 3
+    S2 = ninth
+    nz = [[e1 * S2 + e0 * S1 < m2 for e1 in range(3)] for e0 in range(3)]   # the plan's nz_mask, [e0][e1]
+    for q in range(ninth):
+        r = trirev(q, b - 2)
+        v = [[None] * 3 for _ in range(3)]
+        for e1 in range(3):
+            inp = [0, 0, 0]
+            for e0 in range(3):
+                ci = r + e1 * S2 + e0 * S1
+                if nz[e0][e1] and ci < m2:
+                    inp[e0] = dev.mulS(x[bitrev(ci, a)], scale)
+                else:
+                    assert ci >= m2                                        # the mask never hides a coefficient
+            if nz[1][e1] or nz[2][e1]:
+                v[e1] = [dev.red2(z) for z in dev.r3(inp[0], inp[1], inp[2], om)]
+            else:
+                v[e1] = [inp[0]] * 3
+        for jj in range(3):
+            Bv, Cv = v[1][jj], v[2][jj]
+            if jj:
+                Bv = dev.mulS(Bv, tw3[jj * ninth])
+                Cv = dev.mulS(Cv, tw3[2 * jj * ninth])
+            y[9 * q + jj], y[9 * q + jj + 3], y[9 * q + jj + 6] = dev.r3(v[0][jj], Bv, Cv, om)
+    assert all(z is not None and z < 2 * p2 for z in y)
+    # ---- remaining levels: a single one when their number is odd, then two at a time -----------------------------------
+    t3, left = 9, b - 2
+    if left & 1:
+        step = m3 // (3 * t3)
+        for q in range(S1):
+            blk, jj = q // t3, q % t3
+            base = blk * 3 * t3 + jj
+            A = dev.red2(y[base])
+            Bv, Cv = dev.mulS(y[base + t3], tw3[jj * step]), dev.mulS(y[base + 2 * t3], tw3[2 * jj * step])
+            y[base], y[base + t3], y[base + 2 * t3] = dev.r3(A, Bv, Cv, om)
+        t3 *= 3
+        left -= 1
+    while left:
+        step_a, step_b = m3 // (3 * t3), m3 // (9 * t3)
+        for q in range(ninth):
+            blk, jj = q // t3, q % t3
+            base = blk * 9 * t3 + jj
+            av = [y[base + e * t3] for e in range(9)]
+            v = [None] * 9
+            for e1 in range(3):
+                A = dev.red2(av[3 * e1])
+                Bv, Cv = dev.mulS(av[3 * e1 + 1], tw3[jj * step_a]), dev.mulS(av[3 * e1 + 2], tw3[2 * jj * step_a])
+                v[3 * e1:3 * e1 + 3] = dev.r3(A, Bv, Cv, om)
+            for d in range(3):
+                jb = jj + d * t3
+                A = dev.red2(v[d])
+                Bv, Cv = dev.mulS(v[3 + d], tw3[jb * step_b]), dev.mulS(v[6 + d], tw3[2 * jb * step_b])
+                y[base + d * t3], y[base + (d + 3) * t3], y[base + (d + 6) * t3] = dev.r3(A, Bv, Cv, om)
+        t3 *= 9
+        left -= 2
+    assert t3 == m3
+    out = [dev.csub(dev.red2(z), p) for z in y]                                    # canonical
+    assert out[0] == 0                                                             # f(1) = 0 (tss asserts the same)
+    return out[1:]
 
 
 def _roots(p, o2, o3):
@@ -125,8 +196,12 @@ def _roots(p, o2, o3):
 
 
 @pytest.mark.parametrize("p,k,t,n", [(433, 3, 4, 8), (po.P62, 3, 4, 8), (po.P62, 8, 7, 26), (po.P62, 1, 2, 8),
-                                     (po.P62, 20, 11, 80), (746497, 100, 155, 728), (po.P62, 40, 23, 242)])
+                                     (po.P62, 20, 11, 80), (746497, 100, 155, 728), (po.P62, 40, 23, 242),
+                                     (po.P62, 70, 57, 242), (po.P62, 2, 1, 26), (po.P62, 1, 0, 8)])
 def test_transform_share_equals_the_oracle(p, k, t, n):
+    """shapes cover: an odd and an even number of radix-2 levels (single level + radix-4 passes), 0 / 1 / 2 / 3 / 4 radix-3
+    levels after the folded two (single level, radix-9 passes), and every zero-extension pattern of the first levels
+    (m2 <= m3/9, m3/9 < m2 <= m3/3, m3/3 < m2 <= 2 m3/3 incl. tss's 256 of 729)"""
     rnd = random.Random(k * 1000 + n)
     if p == 433:
         w2, w3 = 354, 150
@@ -158,23 +233,39 @@ def test_transform_share_equals_the_oracle(p, k, t, n):
         elif want is not None:
             assert got == want
         else:
-            # large prime, large shape: check through the polynomial itself - interpolate nothing, evaluate the
-            # transform's own coefficients would be circular; use Lagrange evaluation at three share points instead
+            # large prime, large shape: Lagrange evaluation at three share points (independent of any transform)
+            lag = pss.share_lagrange(s, r)
             for j in (1, n // 2, n):
-                assert got[j - 1] == pss.share_lagrange(s, r)[j - 1]
+                assert got[j - 1] == lag[j - 1]
 
 
-def test_mulc_range_edges():
-    """the single multiplication accepts any |x| <= p and lands in (-p, p), for the largest admissible modulus
-    (p < 2^62 - 2^31 keeps the high limb of x inside a signed 32-bit register)"""
-    p = (1 << 62) - (1 << 31) - 69
-    while not all(pow(a, p - 1, p) == 1 for a in (2, 3, 5, 7, 11, 13)):
-        p -= 2
+def _prime_below(x):
+    x -= 1 - (x & 1)
+    while not all(pow(a, x - 1, x) == 1 for a in (2, 3, 5, 7, 11, 13, 17)):
+        x -= 2
+    return x
+
+
+@pytest.mark.parametrize("p", [_prime_below(1 << 62), po.P62, 433, 2])
+def test_multiplication_and_butterfly_ranges_at_the_edges(p):
+    """the Shoup product accepts ANY 64-bit operand and lands in [0, 2p); the butterfly keeps every sum inside 64 bits -
+    for the largest modulus the library admits (p just below 2^62: 4p just below 2^64) and for tiny ones"""
     dev = Dev(p)
-    rnd = random.Random(7)
-    rinv = pow(1 << 62, -1, p)
-    for mr in [(p - 1) // 2, -((p - 1) // 2), 1, -1, 0] + [rnd.randrange(-(p // 2), p // 2) for _ in range(50)]:
-        c = bal(mr)
-        for x in [p, -p, p - 1, 1 - p, (1 << 61), -(1 << 61), 0, 1, -1] + [rnd.randrange(-p, p + 1) for _ in range(50)]:
-            r = dev.mulc(x, c)
-            assert (r - x * mr * rinv) % p == 0
+    rnd = random.Random(p & 0xFFFF)
+    consts = [0, 1, p - 1, p // 2] + [rnd.randrange(p) for _ in range(40)]
+    xs = [0, 1, p - 1, p, 2 * p - 1, 2 * p, 4 * p - 1, M64, M64 - 1, 1 << 63, (1 << 63) - 1] + [rnd.getrandbits(64) for _ in range(60)]
+    for w in consts:
+        c = dev.pair(w)
+        for x in xs:
+            r = dev.mulS(x & M64, c)
+            assert r % p == (x & M64) * w % p
+    om = dev.pair(consts[5])                                   # range checks do not need a true cube root
+    edge = [0, 1, 2 * p - 1, p, p - 1] + [rnd.randrange(2 * p) for _ in range(8)]
+    for A in edge:
+        for Bv in edge:
+            for Cv in edge:
+                y = dev.r3(A, Bv, Cv, om)
+                w = om[0]
+                assert y[0] % p == (A + Bv + Cv) % p
+                assert y[1] % p == (A - Cv + w * (Bv - Cv)) % p
+                assert y[2] % p == (A - Bv - w * (Bv - Cv)) % p

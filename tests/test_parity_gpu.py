@@ -169,6 +169,8 @@ def _root(p, order):
     (TSS_P1, 100, 155, 728, 95660, 610121, 100 * 29 + 37, False),        # PSS_155_728_100: groups of 8 batches + a ragged group
     (P62, 100, 155, 728, None, None, 100 * 17 + 1, False),               # the same shape over the 62-bit prime
     (P62, 40, 23, 242, None, None, 40 * 40, False),                      # k + t + 1 = 64, n + 1 = 243
+    (P62, 70, 57, 242, None, None, 70 * 19 + 3, False),                  # 128 of 243: first-level butterflies in two of three groups, odd radix-2 count
+    (P62, 100, 155, 2186, None, None, 100 * 3 + 7, False),               # n + 1 = 3^7: one batch per workgroup with the twiddles in LDS, single level + two radix-9 passes
     (TSS_P2, 100, 155, 19682, 4318906, 1814687, 250, False),             # PSS_155_19682_100: one batch fills the LDS (G = 1)
     (P62, 3, 4, 8, W[8], W[9], 1000, True), (P62, 8, 7, 26, W[16], W[27], 6151, True),   # small tss-valid shapes, forced
     (433, 3, 4, 8, 354, 150, 7, True)])
@@ -241,8 +243,8 @@ def test_transform_group_boundaries(gpu, dim):
 
 @pytest.mark.parametrize("above", [False, True])
 def test_transform_path_modulus_bound(gpu, above):
-    """the transform kernel needs p < 2^62 - 2^31 (the high limb of a value in [-p, p] must fit a signed 32-bit register);
-    a prime just below the bound runs it, one just above takes the generic kernel - both bit-exact"""
+    """round 2's transform kernel needed p < 2^62 - 2^31 (signed limbs); round 3's unsigned form takes every modulus the
+    library admits (p < 2^62: 4p < 2^64).  Primes on either side of the old bound, special and random operands - bit-exact"""
     from sda_amd import crypto
     from oracle import coracle
     k, t, n = 40, 23, 242
