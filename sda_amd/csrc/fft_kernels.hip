@@ -140,10 +140,11 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
             const uint64_t b = b_first + j;
             X[(size_t)j * m2 + 1 + k + i] = b < batches ? canon_i64(rp[b * t + i], mod.m, mod.mu) : 0;
         }
-    } else if (G == 8) {                      // one CSPRNG block serves draw i of the 8 batches of this group
+    } else if (G >= 8) {                      // one CSPRNG block serves draw i of 8 consecutive batches; G / 8 such blocks of 8
         const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
-        for (uint32_t i = tid; i < t; i += T) {
-            const uint64_t I = g * (uint64_t)t + i;
+        for (uint32_t u = tid; u < (G >> 3) * t; u += T) {
+            const uint32_t nb = f_div(u, t, F.magic_t), i = u - nb * t;
+            const uint64_t I = (g * (G >> 3) + nb) * (uint64_t)t + i;
             uint32_t o[16];
             chacha_block_lane<ROUNDS>(kk, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream, (uint32_t)(stream >> 32) & 0xFFFFFFu, o);
 #pragma unroll
@@ -152,8 +153,8 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 const uint64_t xw = ((uint64_t)o[8 * e + cc] << 32) | o[8 * e + 4 + cc];
                 uint64_t val;
                 if (!lemire_sample(xw, mod.m, mod.lemire_thr, val))
-                    val = f_drbg_retry<ROUNDS>(key, stream, (b_first + jj) * (uint64_t)t + i, mod);
-                X[(size_t)jj * m2 + 1 + k + i] = val;
+                    val = f_drbg_retry<ROUNDS>(key, stream, (b_first + 8u * nb + jj) * (uint64_t)t + i, mod);
+                X[(size_t)(8u * nb + jj) * m2 + 1 + k + i] = val;
             }
         }
     } else {                                  // G == 1: this batch uses its two words of each block
@@ -293,11 +294,13 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
         const uint32_t step_a = m3 / (3 * t3), step_b = m3 / (9 * t3);
         const uint32_t magic = (uint32_t)(0x100000000ull / t3) + 1u;
         // the LAST pass (one block of 9 t3 = m3 per batch) hands its evaluations straight to global memory: items are then
-        // dealt batch-fastest, so that 8 neighbouring lanes store the 8 batches of one clerk row (64 contiguous bytes)
+        // dealt batch-fastest, so that G neighbouring lanes store the G batches of one clerk row (64 contiguous bytes), with
+        // non-temporal stores: write-back stores cost 1.35x the share bytes in WRITE_SIZE (lines written back more than
+        // once), these 1.02x - measured, also with whole 128-byte lines per row (16 batches per workgroup), same figures
         const bool last = left == 2;
         for (uint32_t u = tid; u < G * ninth; u += T) {
             uint32_t j, q;
-            if (last && G == 8) { j = u & 7u; q = u >> 3; }
+            if (last && G >= 8) { j = u & (G - 1); q = u >> F.lgG; }
             else { j = f_div(u, ninth, magic_ninth); q = u - j * ninth; }
             const uint32_t blk = f_div(q, t3, magic), jj = q - blk * t3;
             uint64_t* y = Y + (size_t)j * m3 + (size_t)blk * (9 * t3) + jj;
@@ -332,7 +335,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
 #pragma unroll
                     for (int e = 0; e < 9; ++e) {
                         const uint32_t pos = jj + (uint32_t)e * t3;
-                        if (pos) op[(size_t)(pos - 1) * L.out_stride_clerk + b] = (int64_t)f_csub(f_red2(o[e], c.p2), c.p);
+                        if (pos) __builtin_nontemporal_store((int64_t)f_csub(f_red2(o[e], c.p2), c.p), op + (size_t)(pos - 1) * L.out_stride_clerk + b);
                     }
                 }
             }
@@ -344,10 +347,10 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
 
     // ---- shares = evaluations 1..n from LDS (shapes without a radix-9 pass), canonical, clerk-major ------------------------
     for (uint32_t u = tid; u < G * F.n; u += T) {
-        const uint32_t sj = G == 8 ? u >> 3 : u, jj = G == 8 ? u & 7u : 0u;   // batch fastest: G consecutive values per clerk row
+        const uint32_t sj = u >> F.lgG, jj = u & (G - 1);   // batch fastest: G consecutive values per clerk row
         const uint64_t b = b_first + jj;
         if (b >= batches) continue;
-        op[(size_t)sj * L.out_stride_clerk + b] = (int64_t)f_csub(f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2), c.p);
+        __builtin_nontemporal_store((int64_t)f_csub(f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2), c.p), op + (size_t)sj * L.out_stride_clerk + b);
     }
 }
 
@@ -364,7 +367,7 @@ hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, 
     // 512 threads = 4 waves per SIMD with the two workgroups a CU's LDS holds (PSS_155_728_100, round 2: 58 ms per 500 x 1 Mi
     // tile against 66 with 256 threads, 79 with 1024, 120 with 128)
     static const char* env_threads = getenv("SDA_FFT_THREADS");                 // A/B only
-    unsigned threads = F.G == 1 && F.m3 > 2187 ? 1024u : 512u;
+    unsigned threads = (F.G == 1 && F.m3 > 2187) || F.G > 8 ? 1024u : 512u;
     if (env_threads && atoi(env_threads) >= 64 && atoi(env_threads) <= 1024 && atoi(env_threads) % 64 == 0) threads = (unsigned)atoi(env_threads);
     if (rounds != 20 && rounds != 12 && rounds != 8) return hipErrorInvalidValue;
     auto kern = F.tw_lds ? (rounds == 20 ? packed_gen_fft_kernel<20, true> : rounds == 12 ? packed_gen_fft_kernel<12, true> : packed_gen_fft_kernel<8, true>)

@@ -92,7 +92,7 @@ struct FftPlan {
     uint32_t k, t, n;
     uint32_t m2, a;            // k + t + 1 = 2^a
     uint32_t m3, b;            // n + 1 = 3^b
-    uint32_t G;                // batches per workgroup: 8 (one CSPRNG block per draw serves them) or 1
+    uint32_t G, lgG;           // batches per workgroup (a power of two): 16 or 8 (one CSPRNG block per draw serves 8) or 1
     uint32_t tw_lds;           // 1: the workgroup copies both twiddle tables to LDS
     uint32_t nz_mask;          // bit 3 e0 + e1: e1 (m3 / 9) + e0 (m3 / 3) < m2, i.e. some 9-block of the zero-extended
                                // vector holds a coefficient at that position (fft_kernels.hip, the folded first two levels)

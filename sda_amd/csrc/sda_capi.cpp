@@ -571,6 +571,10 @@ static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, ui
     if (h_powmod(w2, m2, p) != 1 || h_powmod(w2, m2 / 2, p) == 1) return false;      // order exactly 2^a
     if (h_powmod(w3, m3, p) != 1 || h_powmod(w3, m3 / 3, p) == 1) return false;      // order exactly 3^b
     const size_t half_cu = 80 * 1024, whole_cu = 160 * 1024;
+    // (16 batches in one 1024-thread workgroup per CU - whole 128-byte lines per clerk row - was measured: 41.7 ms against 36.0
+    // per 500-participant tile of PSS_155_728_100, its barriers no longer hidden by a second workgroup, and the same
+    // WRITE_SIZE: the 1.35x write amplification of round 2 came from write-back stores, not from half lines - the
+    // non-temporal stores of the last pass bring it to 1.02x in either form.)
     if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 8, true) <= half_cu) { G = 8; tw_lds = 1; }
     else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 8, false) <= half_cu) { G = 8; tw_lds = 0; }
     else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, true) <= half_cu) { G = 1; tw_lds = 1; }
@@ -616,6 +620,7 @@ static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G,
     HIP_TRY(hipMemcpy(g->d_fft.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     FftPlan& F = g->fplan;
     F.k = g->k; F.t = g->t; F.n = g->n; F.m2 = (uint32_t)m2; F.a = a; F.m3 = (uint32_t)m3; F.b = b; F.G = G;
+    F.lgG = G == 16 ? 4 : G == 8 ? 3 : 0;
     F.tw_lds = tw_lds;
     F.nz_mask = 0;
     for (uint32_t e0 = 0; e0 < 3; ++e0)
