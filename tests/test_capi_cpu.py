@@ -180,3 +180,149 @@ def test_header_is_plain_c(built):
                 ["g++", "-x", "c++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", hdr]):
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+# ---- the Rust shim of INTEGRATION.md is the deliverable a maintainer pastes: keep it equal to the header --------------------
+_C2RUST = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "int64_t": "i64", "uint32_t": "u32",
+           "int32_t": "i32", "uint8_t": "u8", "char": "c_char", "void": "c_void", "float": "f32"}
+
+
+def _c_type_to_rust(ctype: str) -> str:
+    """'const int64_t* const*' -> '*const *const i64' (what a Rust extern "C" declaration must say for that C parameter)"""
+    import re
+    t = ctype.strip()
+    arr = re.search(r"\[[^\]]*\]\s*$", t)                       # `uint8_t id[128]` decays to a pointer
+    if arr:
+        t = t[:arr.start()].strip() + "*"
+    toks = re.findall(r"\*|const|[A-Za-z_][A-Za-z_0-9]*", t)
+    base, stars, const_base = None, [], False
+    pending_const = False
+    for tok in toks:
+        if tok == "const":
+            if base is None:
+                const_base = True
+            else:
+                pending_const = True                              # qualifies the pointer to its left
+        elif tok == "*":
+            stars.append(False)
+            pending_const = False
+        elif tok == "struct" or tok == "unsigned" and base is not None:
+            continue
+        elif base is None:
+            base = tok
+        # a trailing identifier is the parameter name: ignored
+        if tok == "const" and stars:
+            stars[-1] = True
+    name = base[:-2] if base.endswith("_t") and base.startswith("sda_") and base not in ("sda_sharing_scheme_t", "sda_masking_scheme_t", "sda_job_layout_t") else base
+    rust = _C2RUST.get(name, name)
+    # innermost pointee constness is the base's; each further level takes the const that FOLLOWS the previous star
+    quals = [const_base] + stars[:-1] if stars else []
+    for q in quals:
+        rust = ("*const " if q else "*mut ") + rust
+    return rust
+
+
+def _split_args(arglist: str):
+    args, depth, cur = [], 0, ""
+    for ch in arglist:
+        if ch in "([<":
+            depth += 1
+        elif ch in ")]>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        args.append(cur)
+    return [a.strip() for a in args]
+
+
+def _header_functions():
+    import re
+    text = open(os.path.join(ROOT, "include", "sda_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#[^\n]*", " ", text, flags=re.M)
+    funcs = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9\s\*]*?)\b(sda_[a-z0-9_]+)\s*\(([^;{}]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret:
+            continue
+        params = [] if args in ("", "void") else [_c_type_to_rust(a) for a in _split_args(args)]
+        funcs[name] = (None if ret == "void" else _c_type_to_rust(ret), params)
+    return funcs
+
+
+def _rust_shim():
+    import re
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```rust\n(.*?)```", md, flags=re.S)
+    fns, structs = {}, {}
+    for b in blocks:
+        b = re.sub(r"//[^\n]*", "", b)
+        b = re.sub(r"/\*.*?\*/", "", b, flags=re.S)
+        for ext in re.findall(r'extern "C" \{(.*?)\n\}', b, flags=re.S):
+            for m in re.finditer(r"pub fn (sda_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([^;]+))?;", ext, flags=re.S):
+                params = [re.sub(r"\s+", " ", a.split(":", 1)[1]).strip() for a in _split_args(m.group(2)) if ":" in a]
+                fns[m.group(1)] = (m.group(3).strip() if m.group(3) else None, params)
+        for m in re.finditer(r"#\[repr\(C\)\]\s*pub struct (\w+)\s*\{(.*?)\}", b, flags=re.S):
+            structs[m.group(1)] = [(f.split(":")[0].replace("pub", "").strip(), f.split(":")[1].strip())
+                                   for f in _split_args(m.group(2)) if ":" in f]
+    return fns, structs
+
+
+def test_c_type_translation_examples():
+    assert _c_type_to_rust("const int64_t* secrets") == "*const i64"
+    assert _c_type_to_rust("const int64_t* const* rows") == "*const *const i64"
+    assert _c_type_to_rust("sda_share_generator_t** out") == "*mut *mut sda_share_generator"
+    assert _c_type_to_rust("const uint8_t id[SDA_COMM_ID_BYTES]") == "*const u8"
+    assert _c_type_to_rust("uint8_t id[128]") == "*mut u8"
+    assert _c_type_to_rust("const sda_sharing_scheme_t* s") == "*const sda_sharing_scheme_t"
+    assert _c_type_to_rust("const uint8_t** payload") == "*mut *const u8"
+    assert _c_type_to_rust("void* stream") == "*mut c_void" and _c_type_to_rust("size_t") == "usize"
+
+
+def test_integration_md_rust_shim_matches_the_header(built, tmp_path):
+    """Every `pub fn` of INTEGRATION.md's extern "C" blocks (the binding for the traits of sharing/mod.rs:10-33 and
+    masking/mod.rs:9-31, plus the codec, sealed-box, job and communicator calls) exists in include/sda_hip.h with the same
+    arity, the same integer widths and the same pointer constness; the #[repr(C)] structs have the C structs' size and
+    field offsets (checked with a compiled C program)."""
+    import subprocess
+    header = _header_functions()
+    fns, structs = _rust_shim()
+    assert len(fns) >= 45 and {"sda_share_generator_generate", "sda_share_combiner_combine", "sda_secret_reconstructor_reconstruct",
+                               "sda_secret_masker_mask", "sda_mask_combiner_combine", "sda_secret_unmasker_unmask"} <= set(fns)
+    for name, (ret, params) in sorted(fns.items()):
+        assert name in header, f"{name} is declared in INTEGRATION.md but not in include/sda_hip.h"
+        cret, cparams = header[name]
+        assert ret == cret, f"{name}: return type {ret} vs C {cret}"
+        assert len(params) == len(cparams), f"{name}: {len(params)} parameters in the Rust shim, {len(cparams)} in the header"
+        for i, (r, c) in enumerate(zip(params, cparams)):
+            assert r == c, f"{name}, parameter {i}: Rust `{r}` vs header `{c}`"
+    # struct layouts: what #[repr(C)] gives for the Rust field lists == what the C compiler gives for the header's structs
+    size = {"i32": 4, "u32": 4, "i64": 8, "u64": 8, "usize": 8, "u8": 1}
+    assert {"sda_sharing_scheme_t", "sda_masking_scheme_t", "sda_job_layout_t"} <= set(structs)
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "sda_hip.h"', "int main(void) {"]
+    for sname, fields in structs.items():
+        prog.append(f'printf("{sname} size %zu\\n", sizeof({sname}));')
+        for f, _ in fields:
+            prog.append(f'printf("{sname} {f} %zu\\n", offsetof({sname}, {f}));')
+    prog.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        s, f, v = ln.split()
+        got[(s, f)] = int(v)
+    for sname, fields in structs.items():
+        off, align = 0, 1
+        for f, t in fields:
+            a = size[t]
+            off = (off + a - 1) // a * a
+            assert got[(sname, f)] == off, f"{sname}.{f}: repr(C) offset {off}, C offset {got[(sname, f)]}"
+            off += size[t]
+            align = max(align, a)
+        assert got[(sname, "size")] == (off + align - 1) // align * align, sname
