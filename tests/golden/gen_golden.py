@@ -30,6 +30,28 @@ from oracle import pyoracle as po  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
+# Provenance vocabulary of every golden file (what pins each part, so a reader need not trace the generator):
+#   reference-held   inputs / expected outputs that appear in /root/reference's own tests or README
+#   recalled         vectors of an un-vendored crate's unit tests, recalled in SURVEY.md App. B / C - NOT reference output
+#   published-RFC    vectors of a published specification
+#   oracle-generated produced by this repository's oracle (oracle/pyoracle.py); pins implementations against each other only
+#   (reference-generated: only tests/golden/reference_generated.json, made by tests/reference_harness where cargo exists)
+PROV_FULL_LOOP = {
+    "inputs, aggregation parameters, expected_positive": "reference-held (integration-tests/tests/full_loop.rs:29-67,113,148; README.md:86,105-107,157)",
+    "mask_rand, share_rand, clerk_subset": "oracle-generated (injected randomness: the reference draws from OsRng)",
+    "stages (every intermediate value, both value modes)": "oracle-generated",
+}
+PROV_KATS = {
+    "B1_recover_polynomial.recalled_*, B2_evaluate_polynomial.recalled_canonical": "recalled (threshold-secret-sharing 0.2 unit tests test_recover_polynomial / test_evaluate_polynomial, SURVEY.md App. B)",
+    "B1 / B2 signed and canonical": "oracle-generated (equal to the recalled vectors, signs included)",
+    "B3_share, B4_share_matrix_row0, B5_reconstruct": "oracle-generated (FFT form == Lagrange-matrix form; derived in SURVEY.md App. B)",
+    "C1_chacha20_zero_key_block0.expected_first4": "published-RFC (RFC 7539 / draft-nir zero-key keystream; also rand's test_rng_true_values [recalled])",
+    "C2_masks_seed0, C3_masks_seed1234": "oracle-generated from the RFC-pinned block function and the RECALLED rand 0.3 next_u64 / gen_range rules (SURVEY.md App. C) - parity unpinned by any reference test",
+}
+PROV_P62 = {"everything": "oracle-generated (62-bit prime scenarios; the reference's own packed-Shamir arithmetic overflows there, SURVEY.md App. A.3)"}
+PROV_DRBG = {"cases, call_keys": "oracle-generated (sda-drbg-v1 is the product's own stream layout; the reference uses OsRng)",
+             "the ChaCha20 block function underneath": "published-RFC (RFC 7539 2.3.2, pinned in tests/test_oracle.py::test_chacha_kats)"}
+
 
 def scenario(name, source, expected_positive, aggregation, inputs, seed, clerk_subset=None):
     rnd = random.Random(seed)
@@ -82,7 +104,7 @@ def main():
                  agg(dict(kind="Full", modulus=433), dict(po.PSS_433)), two, 1006),
     ]
     with open(os.path.join(OUT, "full_loop.json"), "w") as f:
-        json.dump({"generator": "tests/golden/gen_golden.py", "scenarios": scenarios}, f, indent=1)
+        json.dump({"generator": "tests/golden/gen_golden.py", "provenance": PROV_FULL_LOOP, "scenarios": scenarios}, f, indent=1)
 
     # ---- KATs of the third-party algorithms ---------------------------------------------------------
     pss = po.PackedSecretSharing(4, 8, 3, 433, 354, 150)
@@ -114,7 +136,7 @@ def main():
                               "first_u64": hex(po.ChaChaRng([1, 2, 3, 4]).next_u64()), "expected_first_u64": "0xea54ec620210af6f"},
     }
     with open(os.path.join(OUT, "kats.json"), "w") as f:
-        json.dump({"generator": "tests/golden/gen_golden.py", "kats": kats}, f, indent=1)
+        json.dump({"generator": "tests/golden/gen_golden.py", "provenance": PROV_KATS, "kats": kats}, f, indent=1)
 
     # ---- 62-bit configurations: exact Z_p vectors from the big-int oracle ------
     rnd = random.Random(62)
@@ -151,7 +173,7 @@ def main():
         big.append({"name": "cfg2_additive_" + mk["kind"].lower(), "aggregation": a, "inputs": inputs,
                     "mask_rand": mask_rand, "share_rand": share_rand, "clerk_subset": None, "stages": stages})
     with open(os.path.join(OUT, "p62.json"), "w") as f:
-        json.dump({"generator": "tests/golden/gen_golden.py", "prime": P, "scenarios": big}, f, indent=1)
+        json.dump({"generator": "tests/golden/gen_golden.py", "provenance": PROV_P62, "prime": P, "scenarios": big}, f, indent=1)
 
     # ---- sda-drbg-v1 vectors (product CSPRNG layout; pins the C oracle's copy and the device) --------
     key = bytes(range(32))
@@ -162,7 +184,7 @@ def main():
                               "values": po.drbg_fill(key, stream, batches, T, m, rounds)})
     drbg["call_keys"] = [{"call_index": i, "key_hex": po.drbg_call_key(key, i).hex()} for i in (0, 1, 2, (1 << 32) + 5)]
     with open(os.path.join(OUT, "drbg.json"), "w") as f:
-        json.dump({"generator": "tests/golden/gen_golden.py", "spec": "sda-drbg-v1 (DESIGN.md)", **drbg}, f, indent=1)
+        json.dump({"generator": "tests/golden/gen_golden.py", "provenance": PROV_DRBG, "spec": "sda-drbg-v1 (DESIGN.md)", **drbg}, f, indent=1)
     print("wrote", sorted(x for x in os.listdir(OUT) if x.endswith(".json")))
 
 

@@ -108,7 +108,13 @@ def main():
         c = so.seal(m, pk, esk)
         assert so.seal_open(c, pk, sk) == m and len(c) == mlen + 48
         sealed.append({"pk": pk.hex(), "sk": sk.hex(), "esk": esk.hex(), "m": m.hex(), "c": c.hex()})
-    out = {"generator": "tests/golden/gen_sealedbox.py", "kats": kats,
+    out = {"generator": "tests/golden/gen_sealedbox.py",
+           "provenance": {"kats": "published-RFC (RFC 7748 5.2 / 6.1, RFC 8439 2.5.2, RFC 7693 App. A) and the worked example of "
+                                  "\"Cryptography in NaCl\" (published)",
+                          "sealed.vectors": "oracle-generated (libsodium's documented crypto_box_seal construction; the reference links "
+                                            "libsodium through the un-vendored sodiumoxide 0.0.14 and sealing is randomised there)",
+                          "cross_checks": "X25519 of the oracle against OpenSSL 3 libcrypto at generation time"},
+           "kats": kats,
            "sealed": {"source": "oracle/sealedbox_oracle.py (libsodium crypto_box_seal construction; composition unpinned "
                                 "by any reference fixture - sealing is randomised)", "vectors": sealed},
            "cross_checks": {"openssl_x25519_random_pairs": checked,

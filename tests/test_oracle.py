@@ -2,6 +2,8 @@
  and cross-check its two implementations (Python big-int vs C) and its two
 formulations (tss FFT/Newton vs Lagrange matrix)."""
 import itertools
+import json
+import os
 import random
 
 import numpy as np
@@ -325,3 +327,117 @@ def test_c_oracle_under_sanitizers():
     if r.returncode != 0 and ("cannot find -lasan" in r.stderr or "libasan" in r.stderr or "cannot find -lubsan" in r.stderr):
         pytest.skip("sanitizer runtimes not installed")
     assert r.returncode == 0 and "oracle selftest: OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- reference-generated fixtures (tests/reference_harness: the real crates, run where cargo exists) -----------------------
+REFERENCE_GENERATED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_generated.json")
+
+
+def _load_harness_generator():
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_harness", "gen_inputs.py")
+    spec = importlib.util.spec_from_file_location("reference_harness_gen_inputs", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def check_reference_generated(doc, gen):
+    """What tests/reference_harness printed (threshold-secret-sharing 0.2, rand 0.3) against the oracle:
+      * ChaChaRng::from_seed + gen_range(0_i64, q) prefixes, first next_u64 / next_u32s == the oracle's restatement
+        (chacha.rs:36-39: word order of next_u64, zone rejection, seeds shorter / longer than four words);
+      * oracle-reconstruct(shares made by tss) == the secrets, tss-reconstruct(shares made by the oracle) == the secrets,
+        for arbitrary clerk subsets (packed_shamir.rs:42,76: the evaluation-point convention index i <-> omega_shares^(i+1))."""
+    assert doc["provenance"].startswith("reference-generated")
+    by_name = {c["name"]: c for c in doc["chacha"]}
+    for name, seed, q, count in gen.CHACHA_CASES:
+        c = by_name[name]
+        assert c["seed"] == seed and c["modulus"] == q
+        rng = po.ChaChaRng(seed)
+        assert c["masks"] == [rng.gen_range_i64(0, q) for _ in range(count)], name
+        assert c["first_next_u64"] == po.ChaChaRng(seed).next_u64(), name
+        r = po.ChaChaRng(seed)
+        assert c["first_next_u32s"] == [r.next_u32() for _ in range(4)], name
+    by_name = {c["name"]: c for c in doc["pss"]}
+    for args in gen.PSS_CASES:
+        want = gen.pss_case(*args)
+        c = by_name[want["name"]]
+        p, n = want["p"], want["n"]
+        pss = po.PackedSecretSharing(want["t"], n, want["k"], p, want["w2"], want["w3"])
+        assert c["secrets"] == want["secrets"] and c["subset"] == want["subset"] and c["reconstruct_limit"] == pss.reconstruct_limit()
+        # tss reconstructed the ORACLE's shares
+        assert [v % p for v in c["tss_reconstruct_of_oracle_shares"]] == want["secrets"], want["name"]
+        assert [v % p for v in c["tss_reconstruct_of_tss_shares"]] == want["secrets"], want["name"]
+        # the oracle reconstructs TSS's shares: from every clerk, and from the subset (Newton path and Lagrange-matrix path)
+        tss_shares = [v % p for v in c["tss_shares"]]
+        assert len(tss_shares) == n
+        every = list(range(n))
+        assert [v % p for v in pss.reconstruct(every, tss_shares, "canonical")] == want["secrets"], want["name"]
+        sub = want["subset"]
+        assert [v % p for v in pss.reconstruct(sub, [tss_shares[i] for i in sub], "canonical")] == want["secrets"]
+        assert [v % p for v in pss.reconstruct_lagrange(sub, [tss_shares[i] for i in sub])] == want["secrets"]
+
+
+def _simulated_reference_output(gen):
+    """the document the harness WOULD print if the crates behave as the oracle restates them (used to keep the consumer
+    above exercised while no machine with cargo has produced the real file)"""
+    import random as _r
+    doc = {"provenance": "reference-generated (SIMULATED by the oracle for the consumer's self-test)", "chacha": [], "pss": []}
+    for name, seed, q, count in gen.CHACHA_CASES:
+        rng = po.ChaChaRng(seed)
+        r = po.ChaChaRng(seed)
+        doc["chacha"].append({"name": name, "seed": seed, "modulus": q, "masks": [rng.gen_range_i64(0, q) for _ in range(count)],
+                              "first_next_u64": po.ChaChaRng(seed).next_u64(), "first_next_u32s": [r.next_u32() for _ in range(4)]})
+    rnd = _r.Random(99)
+    for args in gen.PSS_CASES:
+        w = gen.pss_case(*args)
+        pss = po.PackedSecretSharing(w["t"], w["n"], w["k"], w["p"], w["w2"], w["w3"])
+        fresh = [rnd.randrange(w["p"] - 1) for _ in range(w["t"])]                       # tss draws its own randomness
+        shares = pss.share(w["secrets"], fresh, "rust_signed")                          # signed, as tss returns them
+        doc["pss"].append({"name": w["name"], "secrets": w["secrets"], "subset": w["subset"], "reconstruct_limit": pss.reconstruct_limit(),
+                           "tss_shares": shares,
+                           "tss_reconstruct_of_oracle_shares": pss.reconstruct(w["subset"], [w["shares"][i] for i in w["subset"]], "rust_signed"),
+                           "tss_reconstruct_of_tss_shares": pss.reconstruct(list(range(w["n"])), shares, "rust_signed")})
+    return doc
+
+
+def test_reference_harness_inputs_are_current():
+    """tests/reference_harness/src/oracle_inputs.rs (what the Rust harness feeds the real crates) is what the oracle
+    generates today; and the consumer of the harness's output accepts a faithful document and refuses a wrong one"""
+    gen = _load_harness_generator()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_harness", "src", "oracle_inputs.rs")
+    assert open(path).read() == gen.render(), "run python tests/reference_harness/gen_inputs.py"
+    doc = _simulated_reference_output(gen)
+    check_reference_generated(doc, gen)
+    bad = json.loads(json.dumps(doc))
+    bad["chacha"][5]["masks"][7] ^= 1
+    with pytest.raises(AssertionError):
+        check_reference_generated(bad, gen)
+    bad = json.loads(json.dumps(doc))
+    bad["pss"][0]["tss_shares"] = bad["pss"][0]["tss_shares"][1:] + bad["pss"][0]["tss_shares"][:1]     # shares off by one clerk index
+    with pytest.raises(AssertionError):
+        check_reference_generated(bad, gen)
+
+
+def test_reference_generated_fixtures():
+    """Consumes tests/golden/reference_generated.json - the output of tests/reference_harness (the crates the reference
+    links, run on a machine with cargo).  ABSENT in this tree: the image has no rustc / cargo and no network, so share-level
+    parity still rests on recalled crate vectors - this test says so loudly instead of passing."""
+    if not os.path.exists(REFERENCE_GENERATED):
+        pytest.skip("PARITY PIN MISSING: tests/golden/reference_generated.json does not exist - nobody has run "
+                    "`cd tests/reference_harness && cargo run --release > ../golden/reference_generated.json` yet "
+                    "(needs cargo + crates.io); share-level parity rests on RECALLED tss 0.2 / rand 0.3 vectors until then")
+    check_reference_generated(json.load(open(REFERENCE_GENERATED)), _load_harness_generator())
+
+
+def test_every_golden_file_states_its_provenance():
+    """each fixture file says, part by part, which of reference-held / recalled / published-RFC / oracle-generated pins it"""
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    words = ("reference-held", "recalled", "published-RFC", "oracle-generated", "reference-generated", "published")
+    files = sorted(f for f in os.listdir(golden) if f.endswith(".json"))
+    assert {"kats.json", "full_loop.json", "p62.json", "drbg.json", "sealedbox.json"} <= set(files)
+    for f in files:
+        prov = json.load(open(os.path.join(golden, f))).get("provenance")
+        assert prov, f"{f} has no provenance key"
+        texts = [prov] if isinstance(prov, str) else list(prov.values())
+        assert all(any(w in t for w in words) for t in texts), (f, texts)
