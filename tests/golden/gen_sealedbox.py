@@ -113,7 +113,7 @@ def main():
                                   "\"Cryptography in NaCl\" (published)",
                           "sealed.vectors": "oracle-generated (libsodium's documented crypto_box_seal construction; the reference links "
                                             "libsodium through the un-vendored sodiumoxide 0.0.14 and sealing is randomised there)",
-                          "cross_checks": "X25519 of the oracle against OpenSSL 3 libcrypto at generation time"},
+                          "cross_checks": "oracle-generated, with the oracle's X25519 compared against OpenSSL 3 libcrypto at generation time"},
            "kats": kats,
            "sealed": {"source": "oracle/sealedbox_oracle.py (libsodium crypto_box_seal construction; composition unpinned "
                                 "by any reference fixture - sealing is randomised)", "vectors": sealed},
