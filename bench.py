@@ -429,8 +429,12 @@ def _traffic(name, P, dim, key):
     passes, measured at one tile size per workload; bytes scale with the tile)"""
     for kk, v in _profiles_json("traffic.json").items():
         parts = kk.split(":")
-        if len(parts) == 3 and parts[0] == name and parts[2] == f"dim{dim}" and key in v:
-            return v[key] * P / int(parts[1][4:])
+        if len(parts) == 3 and parts[0] == name and parts[2] == f"dim{dim}":
+            scale = P / int(parts[1][4:])
+            if key in v:
+                return v[key] * scale
+            if key == "fused_bytes_per_launch" and "gen_bytes_per_launch" in v and "comb_bytes_per_launch" in v:
+                return (v["gen_bytes_per_launch"] + v["comb_bytes_per_launch"]) * scale      # two launches per call
     return None
 
 
@@ -444,7 +448,10 @@ def _bound(name, role, roof):
     traffic / duration is within 10 % of the floor tools/microbench_hbm reaches with the same access pattern and no
     arithmetic; otherwise "valu", with the VALU wave-instructions per element, the SIMD cycles available per issued VALU
     instruction and the VALU-busy fraction the counters give.  `frac` stays the HBM fraction either way."""
-    e = _profiles_json("bounds.json").get(name, {}).get(role)
+    entry = _profiles_json("bounds.json").get(name, {})
+    # a shape without a dual-role kernel runs share-gen and clerk-sum as two launches (side by side on two streams): the
+    # share-gen kernel is the dominant one and its counters are the evidence
+    e = entry.get(role) or (entry.get("serial_gen") if role == "fused" else None)
     if not e:
         return {"bound": BOUND_WITHOUT_EVIDENCE.get(name, "valu"), "bound_evidence": None}
     out = {"bound": e["bound"], "bound_evidence": e.get("evidence")}
