@@ -8,15 +8,22 @@ An *element* is one (participant, vector component) pair, so a step processes P_
 Default workload = BASELINE config 3 (configs[2]): packed Shamir t=1, k=3, n=8, dim 1,048,576, 62-bit
 prime, 100k participants (the configuration the north-star target is quoted on).  The K timed steps
 cover ALL of them: a step = 100000 / K participants, issued as resident sub-tiles of <= 2500
-(50 steps x 2000; 20 steps x 2 x 2500); `config.workload` is derived from what was processed.  `--workload additive` = config 2 (configs[1]); at N=1 a short run of it is
-attached to the JSON line as `additional_workloads`.
+(50 steps x 2000; 20 steps x 2 x 2500); `config.workload` is derived from what was processed and
+`config.inputs` says what was shared (default: one resident tile replayed; --inputs distinct: 100k different
+participants).  `--workload additive` = config 2 (configs[1]); at N=1 a short run of it and of config 5's
+dimension are attached to the JSON line as `additional_workloads`.
 
-N > 1: one process per GPU (torchrun), participants sharded across ranks (weak scaling: the per-GPU
-work is fixed), no collective on the data path, ONE modular reduce of the partial clerk sums over
-RCCL at the end of the timed region - the library's own code behind the C ABI
-(sda_modular_allreduce_dev; torch.distributed only launches the ranks and carries the RCCL id).
+N > 1: one process per GPU (torchrun), participants sharded across ranks, no collective on the data path,
+ONE modular reduce of the partial clerk sums over RCCL at the end of the timed region - the library's own
+code behind the C ABI (sda_modular_allreduce_dev; torch.distributed only launches the ranks and carries the
+RCCL id).  The headline (config 3) is weak-scaled (100k participants per GPU); attached to it are BASELINE
+config 4 (1,000,000 participants of t=2 k=8 n=26) and config 5 (100,000 participants at dim 16,777,216 with
+the Lagrange reveal), each with its job sharded over the N ranks.  `rccl` records what carried the exchange;
+a communicator that cannot be set up is fatal (exit code 3) unless SDA_SHARE_GPU allows the rehearsal.
 
-Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte accounting.
+`roofline.bound` is the active ceiling ("hbm" / "valu") from profiles/bounds.json (counter passes of this
+round); `roofline.frac` is always the HBM fraction.  Prints ONE JSON line (rank 0).  See DESIGN.md
+"Measurement" for the byte accounting.
 """
 from __future__ import annotations
 
