@@ -587,6 +587,10 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
                        "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic(name, P, dim, "fused_bytes_per_launch"),
                        "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": all_ms,
                        "launches": tiles + 1, "both_roles_launch_ms": full_ms,
+                       # SURVEY.md 8d asks for a median over >= 5 repetitions: `value` is total elements / wall time (the
+                       # contract), these are the per-launch HIP-event durations behind it
+                       "both_roles_launch_ms_median": _median(full) if full else None,
+                       "both_roles_launch_ms_min_max": [min(full), max(full)] if full else None,
                        "first_launch_ms_share_gen_only": launch_ms[0], "last_launch_ms_clerk_sum_only": launch_ms[-1],
                        "note": "one launch = share-gen of a tile (8 + 8n/k B/element) + clerk-sum of the previous tile "
                                "(8n/k B/element); K tiles take K+1 launches (the first only generates, the last only "

@@ -214,6 +214,35 @@ def test_transform_share_generation_vs_oracle(gpu, monkeypatch, p, k, t, n, w2, 
     assert np.array_equal(rec, sec2[0])
 
 
+@pytest.mark.parametrize("a,b,split", [(2, 2, 0.5), (3, 2, 0.4), (3, 3, 0.9), (4, 3, 0.1), (4, 4, 0.5), (5, 4, 0.3), (6, 4, 0.7), (6, 5, 0.5),
+                                       (7, 5, 0.2), (7, 6, 0.6), (8, 6, 0.39), (9, 6, 0.5), (9, 7, 0.5), (10, 7, 0.25)])
+def test_transform_kernel_over_the_shape_space(gpu, monkeypatch, a, b, split):
+    """the transform kernel for EVERY structure it can take: k + t + 1 = 2^a with a = 2..10 (odd and even: single radix-2
+    level + radix-4 passes), n + 1 = 3^b with b = 2..7 (0..5 levels after the folded two: single level, radix-9 passes),
+    every zero-extension pattern of the folded levels (2^a below 3^b / 9, between, above 2 * 3^b / 3), 8 batches or one per
+    workgroup, twiddles in LDS or in global memory - forced for the small shapes - against the oracle's matrix form with
+    injected randomness and ragged batches"""
+    from sda_amd import crypto
+    from oracle import coracle
+    m2, m3 = 1 << a, 3 ** b
+    assert m3 > m2
+    kt = m2 - 1
+    k = max(1, min(kt, int(round(kt * split))))
+    t, n = kt - k, m3 - 1
+    monkeypatch.setenv("SDA_FORCE_FFT", "1")
+    w2, w3 = _root(P62, m2), _root(P62, m3)
+    rng = np.random.default_rng(a * 100 + b)
+    sch = crypto.PackedShamir(k, n, t, P62, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    batches = 19 if m3 <= 729 else 3
+    dim = k * batches - (k // 2)                                    # ragged last batch
+    B = gen.batch_count(dim)
+    secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
+    rand = rng.integers(-(1 << 62), 1 << 62, size=B * t, dtype=np.int64)
+    got = gen.generate(secrets, rand)
+    assert np.array_equal(got, coracle.packed_generate(P62, k, t, n, w2, w3, secrets, rand))
+
+
 @pytest.mark.parametrize("dim", [1, 39, 40, 40 * 7 + 3, 40 * 8, 40 * 9 - 1, 40 * 16 + 5])
 def test_transform_group_boundaries(gpu, dim):
     """the transform kernel's groups of 8 batches (one CSPRNG block per draw serves a group): 1 batch, 7, 8, 9, 17 - ragged
@@ -1083,7 +1112,8 @@ def test_odd_strides_and_unaligned_bases_dev(gpu):
 
 @pytest.mark.parametrize("kind", ["packed_k3_t1_n8", "packed_k8_t2_n26", "additive_n3", "packed_odd_strides",
                                   "packed_k4_t3_n8", "packed_k6_t2_n8", "packed_k9_t6_n26",     # these three: run-time (k, t) form
-                                  "packed_k8_t7_n26"])                                          # limb GEMM on the matrix cores
+                                  "packed_k8_t7_n26",                                           # limb GEMM on the matrix cores
+                                  "packed_k40_t23_n242"])   # transform kernel: no dual-role form, clerk sum on the low-priority side stream
 def test_dual_role_pipeline_equals_separate_launches(gpu, kind):
     """sda_share_generator_generate_combine_dev (tile i+1 generated while tile i is summed, one grid) must
     produce exactly the shares and clerk sums of generate_batch_dev + combiner update_dev."""
@@ -1109,6 +1139,9 @@ def test_dual_role_pipeline_equals_separate_launches(gpu, kind):
     elif kind == "packed_k9_t6_n26":
         k, t, n = 9, 6, 26
         sch = crypto.PackedShamir(k, n, t, P62, W[16], W[27])
+    elif kind == "packed_k40_t23_n242":
+        k, t, n = 40, 23, 242
+        sch = crypto.PackedShamir(k, n, t, P62, _root(P62, 64), _root(P62, 243))
     else:
         k, t, n = 3, 1, 8
         sch = crypto.PackedShamir(k, n, t, P62, W[8], W[9])
@@ -1148,6 +1181,50 @@ def test_dual_role_pipeline_equals_separate_launches(gpu, kind):
     # and against the oracle: clerk 0's sum over all tiles
     host = np.concatenate([r.to_numpy().reshape(n, P, Bs)[0, :, :B] for r in ref_shares])
     assert np.array_equal(sums.to_numpy()[:B], coracle.combine(P62, host))
+
+
+def test_side_stream_pipeline_without_host_synchronisation(gpu):
+    """the transform shape's generate_combine_dev forks the clerk sum of tile i-1 to a side stream and joins it before it
+    returns control of `stream`: five launches back to back over two share buffers with NO host synchronisation in between
+    (the buffer the next launch overwrites is the one the side stream is still reading unless the join works), against
+    separate launches; also with the side stream switched off, and a clerk-sum grid smaller than the job"""
+    from sda_amd import crypto
+    from sda_amd.capi import check
+    from sda_amd.device import DeviceBuffer
+    k, t, n, dim, P, tiles = 40, 23, 242, 40 * 700 + 11, 96, 4
+    sch = crypto.PackedShamir(k, n, t, P62, _root(P62, 64), _root(P62, 243))
+    B = (dim + k - 1) // k
+    Bs = (B + 15) // 16 * 16
+    secrets = DeviceBuffer(P * dim)
+    check(gpu.sda_fill_synthetic_dev(secrets.ptr, P, dim, dim, 0, 78, P62, None))
+    gen = crypto.ShareGenerator(sch); gen.set_drbg_key(KEY)
+    comb = crypto.ShareCombiner(sch)
+    buf = DeviceBuffer(n * P * Bs).zero()
+    comb.begin_dev(n, B)
+    for i in range(tiles):
+        gen.generate_batch_dev(secrets.ptr, P, dim, dim, buf.ptr, Bs, P * Bs, first_participant=i * P)
+        comb.update_dev(buf.ptr, P * Bs, P, Bs)
+    want = DeviceBuffer(n * B)
+    comb.finish_dev(want.ptr)
+    want = want.to_numpy()
+    for env in ({}, {"SDA_NO_SIDE_STREAM": "1"}):
+        for kk, vv in env.items():
+            os.environ[kk] = vv
+        try:
+            gen2 = crypto.ShareGenerator(sch); gen2.set_drbg_key(KEY)
+            comb2 = crypto.ShareCombiner(sch)
+            bufs = [DeviceBuffer(n * P * Bs).zero() for _ in range(2)]
+            comb2.begin_dev(n, B)
+            for i in range(tiles + 1):
+                gen2.generate_combine_dev(comb2, secrets.ptr, P if i < tiles else 0, dim, dim, bufs[i % 2].ptr, Bs, P * Bs,
+                                          d_prev=bufs[(i - 1) % 2].ptr if i > 0 else 0, prev_participants=P if i > 0 else 0,
+                                          first_participant=i * P)
+            got = DeviceBuffer(n * B)
+            comb2.finish_dev(got.ptr)
+            assert np.array_equal(got.to_numpy(), want), env
+        finally:
+            for kk in env:
+                del os.environ[kk]
 
 
 def test_device_entry_points_refuse_bad_arguments(gpu):

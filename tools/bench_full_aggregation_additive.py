@@ -22,7 +22,7 @@ from sda_amd.device import DeviceBuffer, DeviceBytes, synchronize  # noqa: E402
 P62 = 4611686006577364993
 lib = capi.load()
 n, dim = 3, 1 << 20
-P, tiles = int(os.environ.get("TILE", "500")), int(os.environ.get("TILES", "4"))
+P, tiles = int(os.environ.get("TILE", "512")), int(os.environ.get("TILES", "4"))   # 3 x 512 = 1536 share rows: the streaming clerk path
 sch, msch = crypto.Additive(n, P62), crypto.Full(P62)
 parties = n + 1                                                 # three clerks and the recipient
 rows = parties * P
