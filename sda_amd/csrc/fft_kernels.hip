@@ -79,10 +79,12 @@ __device__ __forceinline__ uint32_t f_trirev(uint32_t i, uint32_t digits) {
 // exact floor(x / d) for x < 2^16, magic = floor(2^32 / d) + 1 (d > 1), identity for d = 1
 __device__ __forceinline__ uint32_t f_div(uint32_t x, uint32_t d, uint32_t magic) { return d > 1 ? __umulhi(x, magic) : x; }
 
-// one uniform value per (stream, batch, draw) - sda-drbg-v1, identical to drbg_pair() of sda_kernels.hip
+// one uniform value per (stream, batch, draw) - sda-drbg-v1, identical to drbg_pair() of sda_kernels.hip.  The key travels
+// BY VALUE: a by-reference key in this rare path makes every lane park the key in scratch memory at kernel entry
 template <int ROUNDS>
-__device__ __noinline__ uint64_t f_drbg_retry(const DrbgKey& key, uint64_t stream, uint64_t I, const ModParams& mod) {
-    const uint32_t k[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
+__device__ __noinline__ uint64_t f_drbg_retry(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t k4, uint32_t k5, uint32_t k6,
+                                              uint32_t k7, uint64_t stream, uint64_t I, uint64_t m, uint64_t lemire_thr) {
+    const uint32_t k[8] = {k0, k1, k2, k3, k4, k5, k6, k7};
     uint64_t val = 0;
     for (uint32_t a = 1; a < 256; ++a) {
         uint32_t o[16];
@@ -90,7 +92,7 @@ __device__ __noinline__ uint64_t f_drbg_retry(const DrbgKey& key, uint64_t strea
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint64_t x = ((uint64_t)o[2 * j] << 32) | o[2 * j + 1];
-            if (lemire_sample(x, mod.m, mod.lemire_thr, val)) return val;
+            if (lemire_sample(x, m, lemire_thr, val)) return val;
         }
     }
     return val;
@@ -153,7 +155,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 const uint64_t xw = ((uint64_t)o[8 * e + cc] << 32) | o[8 * e + 4 + cc];
                 uint64_t val;
                 if (!lemire_sample(xw, mod.m, mod.lemire_thr, val))
-                    val = f_drbg_retry<ROUNDS>(key, stream, (b_first + 8u * nb + jj) * (uint64_t)t + i, mod);
+                    val = f_drbg_retry<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, (b_first + 8u * nb + jj) * (uint64_t)t + i, mod.m, mod.lemire_thr);
                 X[(size_t)(8u * nb + jj) * m2 + 1 + k + i] = val;
             }
         }
@@ -173,7 +175,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
             }
             uint64_t val;
             if (!lemire_sample(((uint64_t)hi << 32) | lo, mod.m, mod.lemire_thr, val))
-                val = f_drbg_retry<ROUNDS>(key, stream, b * (uint64_t)t + i, mod);
+                val = f_drbg_retry<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, b * (uint64_t)t + i, mod.m, mod.lemire_thr);
             X[1 + k + i] = val;
         }
     }
