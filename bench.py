@@ -132,7 +132,7 @@ def _median(xs):
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
 
-def cpu_baseline(w, dim, budget_s=12.0, samples=3):
+def cpu_baseline(w, dim, budget_s=10.0, samples=3):
     """The oracle's reference-faithful scalar port (share-gen + clerk-sum) on a bounded sample of the same workload:
     (i) ONE thread like the reference (it has no threading), median of `samples` runs; (ii) the same port over participants
     on the host's cores for a sweep of thread counts, median of `samples` runs each, the BEST reported as `all_cores`.
