@@ -94,7 +94,7 @@ extern "C" const char* sda_strerror(int status) {
 
 extern "C" const char* sda_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sda_abi_version(void) { return SDA_HIP_ABI_VERSION; }
-extern "C" const char* sda_version(void) { return "sda-hip 0.2.0 (gfx950)"; }
+extern "C" const char* sda_version(void) { return "sda-hip 0.3.0 (gfx950)"; }
 
 // -------------------------------------------------------------------------------------------------
 // device context
