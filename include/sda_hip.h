@@ -137,6 +137,20 @@ int sda_dev_download(void* h_dst, const void* d_src, size_t bytes);
 int sda_dev_memset(void* d_dst, int value, size_t bytes);
 int sda_dev_synchronize(void);
 
+/* ---- value representation -------------------------------------------------------------------------------
+ * SDA_VALUES_CANONICAL (default): every output is the canonical residue in [0, q) - equal to the reference's value modulo
+ * q, identical after RecipientOutput::positive() (receive.rs:13-21).  SDA_VALUES_RUST_SIGNED: the reference's OWN
+ * representatives, bit for bit - Rust's `%` on i64 truncates, so its intermediates live in (-q, q) with history-dependent
+ * signs: additive.rs:42-47 (the n-1 draws as they are, the last share the fold of (acc - r) % q),
+ * combiner.rs:20-26 and additive.rs:62-69 (result = (result + v) % q, participant after participant), full.rs:30,46-48,62
+ * and chacha.rs:41-44,88.  A fidelity mode for parity work and mixed deployments that compare intermediates: one lane
+ * per column, participants strictly in order; it serves the trait-shaped calls, generate_batch_dev, the combiner's
+ * begin / update[_dev] / finish[_dev], reconstruct[_dev] and unmask[_dev] (the dual-role launch, the wire-fed updates and
+ * mask_batch_dev answer SDA_ERR_UNSUPPORTED in this mode).  Packed Shamir's generator / reconstructor refuse it
+ * (SDA_ERR_UNSUPPORTED): their signed values are tss's, an un-vendored crate - compare those modulo the prime.  Set the
+ * mode right after *_new (changing a combiner's mode discards its running sums: begin again). */
+enum sda_value_mode { SDA_VALUES_CANONICAL = 0, SDA_VALUES_RUST_SIGNED = 1 };
+
 /* ---- opaque handles: one per (scheme, role), like the reference's boxed trait objects ------ */
 typedef struct sda_share_generator       sda_share_generator_t;
 typedef struct sda_share_combiner        sda_share_combiner_t;
@@ -151,6 +165,14 @@ typedef struct sda_secret_unmasker       sda_secret_unmasker_t;
  * ============================================================================================= */
 
 /* new_share_generator(&scheme) - sharing/mod.rs:35-55 */
+/* value representation of a handle's outputs (enum sda_value_mode above) */
+int  sda_share_generator_set_value_mode(sda_share_generator_t* g, int mode);
+int  sda_share_combiner_set_value_mode(sda_share_combiner_t* c, int mode);
+int  sda_secret_reconstructor_set_value_mode(sda_secret_reconstructor_t* r, int mode);
+int  sda_secret_masker_set_value_mode(sda_secret_masker_t* m, int mode);
+int  sda_mask_combiner_set_value_mode(sda_mask_combiner_t* c, int mode);
+int  sda_secret_unmasker_set_value_mode(sda_secret_unmasker_t* u, int mode);
+
 int  sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_share_generator_t** out);
 void sda_share_generator_free(sda_share_generator_t* g);
 

@@ -74,6 +74,12 @@ SIGNATURES = {
     "sda_version": (C.c_char_p, []),
     "sda_device_count": (C.c_int, []),
     "sda_set_device": (C.c_int, [C.c_int]),
+    "sda_share_generator_set_value_mode": (C.c_int, [_H, C.c_int]),
+    "sda_share_combiner_set_value_mode": (C.c_int, [_H, C.c_int]),
+    "sda_secret_reconstructor_set_value_mode": (C.c_int, [_H, C.c_int]),
+    "sda_secret_masker_set_value_mode": (C.c_int, [_H, C.c_int]),
+    "sda_mask_combiner_set_value_mode": (C.c_int, [_H, C.c_int]),
+    "sda_secret_unmasker_set_value_mode": (C.c_int, [_H, C.c_int]),
     "sda_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "sda_strerror": (C.c_char_p, [C.c_int]),
     "sda_last_error": (C.c_char_p, []),

@@ -133,12 +133,23 @@ def _check_mask(status: int) -> None:
     check(status)
 
 
+CANONICAL, RUST_SIGNED = 0, 1          # enum sda_value_mode
+
+
 class _Handle:
     _free = None
+    _value_mode = None                  # name of the C setter, for the six trait handles
 
     def __init__(self):
         self._h = C.c_void_p()
         self._lib = capi.load()
+
+    def set_value_mode(self, mode) -> "_Handle":
+        """CANONICAL (default): residues in [0, q).  RUST_SIGNED: the reference's own representatives, bit for bit
+        (Rust's truncated `%`: values in (-q, q), history-dependent signs) - additive sharing, the combiner, the masks."""
+        mode = {"canonical": CANONICAL, "rust_signed": RUST_SIGNED}.get(mode, mode)
+        check(getattr(self._lib, self._value_mode)(self._h, int(mode)))
+        return self
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -156,6 +167,7 @@ class _Handle:
 class ShareGenerator(_Handle):
     """sharing/mod.rs:14-17; impl batched.rs:18-53 over additive.rs / packed_shamir.rs."""
     _free = "sda_share_generator_free"
+    _value_mode = "sda_share_generator_set_value_mode"
 
     def __init__(self, scheme: LinearSecretSharingScheme):
         super().__init__()
@@ -218,6 +230,7 @@ class ShareGenerator(_Handle):
 class ShareCombiner(_Handle):
     """sharing/mod.rs:23-25; impl combiner.rs:15-29."""
     _free = "sda_share_combiner_free"
+    _value_mode = "sda_share_combiner_set_value_mode"
 
     def __init__(self, scheme: LinearSecretSharingScheme):
         super().__init__()
@@ -286,6 +299,7 @@ class ShareCombiner(_Handle):
 class SecretReconstructor(_Handle):
     """sharing/mod.rs:31-33; impl additive.rs:55-73 | batched.rs:68-97 + packed_shamir.rs:73-77."""
     _free = "sda_secret_reconstructor_free"
+    _value_mode = "sda_secret_reconstructor_set_value_mode"
 
     def __init__(self, scheme: LinearSecretSharingScheme, dimension: int):
         super().__init__()
@@ -319,6 +333,7 @@ class SecretReconstructor(_Handle):
 class SecretMasker(_Handle):
     """masking/mod.rs:13-15; impl none.rs:13-19, full.rs:21-35, chacha.rs:24-54."""
     _free = "sda_secret_masker_free"
+    _value_mode = "sda_secret_masker_set_value_mode"
 
     def __init__(self, scheme: LinearMaskingScheme):
         super().__init__()
@@ -367,6 +382,7 @@ class SecretMasker(_Handle):
 class MaskCombiner(_Handle):
     """masking/mod.rs:21-23; impl none.rs:21-26, full.rs:37-52, chacha.rs:56-77."""
     _free = "sda_mask_combiner_free"
+    _value_mode = "sda_mask_combiner_set_value_mode"
 
     def __init__(self, scheme: LinearMaskingScheme):
         super().__init__()
@@ -389,6 +405,7 @@ class MaskCombiner(_Handle):
 class SecretUnmasker(_Handle):
     """masking/mod.rs:29-31; impl none.rs:28-33, full.rs:54-67, chacha.rs:79-93."""
     _free = "sda_secret_unmasker_free"
+    _value_mode = "sda_secret_unmasker_set_value_mode"
 
     def __init__(self, scheme: LinearMaskingScheme):
         super().__init__()
@@ -442,30 +459,36 @@ class Aggregation:
 
 
 def full_aggregation(aggregation: Aggregation, inputs: Sequence[Sequence[int]], mask_rand=None, share_rand=None,
-                     clerk_subset: Optional[Sequence[int]] = None) -> dict:
+                     clerk_subset: Optional[Sequence[int]] = None, value_mode=CANONICAL) -> dict:
     """The three callers' data flow - participate.rs:52-76, the snapshot transposition
     (server/src/stores.rs:86-101), clerk.rs:85-86, receive.rs:101-156 - with the HIP core in place of
-    the reference's crypto module.  Returns every intermediate."""
+    the reference's crypto module.  Returns every intermediate.  value_mode=RUST_SIGNED asks every handle for the
+    reference's own signed representatives (packed Shamir's generator / reconstructor stay canonical: tss's values)."""
     crypto = CryptoModule()
     a = aggregation
     n = a.committee_sharing_scheme.output_size()
     masks, maskeds, shares = [], [], []
-    masker = crypto.new_secret_masker(a.masking_scheme)
+    signed_sharing = value_mode == RUST_SIGNED and isinstance(a.committee_sharing_scheme, Additive)
+    masker = crypto.new_secret_masker(a.masking_scheme).set_value_mode(value_mode)
     generator = crypto.new_share_generator(a.committee_sharing_scheme)
+    if signed_sharing:
+        generator.set_value_mode(RUST_SIGNED)
     for p, secrets in enumerate(inputs):
         if len(secrets) != a.vector_dimension:
             raise ValueError("The input length does not match the aggregation.")      # participate.rs:44-46
         m, ms = masker.mask(secrets, None if mask_rand is None else mask_rand[p])      # participate.rs:53-54
         masks.append(m); maskeds.append(ms)
         shares.append(generator.generate(ms, None if share_rand is None else share_rand[p]))   # :75-76
-    combiner = crypto.new_share_combiner(a.committee_sharing_scheme)
+    combiner = crypto.new_share_combiner(a.committee_sharing_scheme).set_value_mode(value_mode)
     clerk_sums = [combiner.combine([shares[p][c] for p in range(len(inputs))]) for c in range(n)]   # clerk.rs:85-86
-    mask = (crypto.new_mask_combiner(a.masking_scheme).combine(masks)
+    mask = (crypto.new_mask_combiner(a.masking_scheme).set_value_mode(value_mode).combine(masks)
             if a.masking_scheme.has_mask() else np.empty(0, dtype=np.int64))             # receive.rs:102-118
     subset = list(range(n)) if clerk_subset is None else list(clerk_subset)
     rec = crypto.new_secret_reconstructor(a.committee_sharing_scheme, a.vector_dimension)
+    if signed_sharing:
+        rec.set_value_mode(RUST_SIGNED)
     masked_output = rec.reconstruct([(c, clerk_sums[c]) for c in subset])                # receive.rs:140-144
-    output = crypto.new_secret_unmasker(a.masking_scheme).unmask((mask, masked_output))  # receive.rs:149-152
+    output = crypto.new_secret_unmasker(a.masking_scheme).set_value_mode(value_mode).unmask((mask, masked_output))  # receive.rs:149-152
     return {"masks": masks, "masked": maskeds, "shares": shares, "clerk_sums": clerk_sums,
             "combined_mask": mask, "masked_output": masked_output, "output": output,
             "positive": RecipientOutput(a.modulus, output).positive().values}

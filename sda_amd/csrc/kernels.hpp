@@ -125,6 +125,16 @@ hipError_t launch_combine_update(uint64_t* d_acc_lo, int64_t* d_acc_hi, const in
 hipError_t launch_combine_finish(const uint64_t* d_acc_lo, const int64_t* d_acc_hi, size_t count,
                                  const ModParams& mod, int64_t* d_out, hipStream_t s);
 
+// ---- the reference's own signed representatives (value mode SDA_VALUES_RUST_SIGNED) - signed_kernels.hip --------------
+// additive.rs:42-47 (L.rand REQUIRED: (n-1) draws per element; shares j < n-1 are the draws, untouched)
+hipError_t launch_additive_generate_signed(const GenLayout& L, uint32_t n, int64_t q, hipStream_t s);
+// combiner.rs:20-26: state[job][col] = (state + row) % q, rows in order; state is int64 [jobs][dimension]
+hipError_t launch_combine_update_signed(int64_t* d_state, const int64_t* d_shares, size_t jobs, size_t job_stride, size_t n_rows,
+                                        size_t row_stride, size_t dimension, int64_t q, hipStream_t s);
+// (a + b) % q / (a - b) % q with Rust's truncated remainder, sums formed exactly
+hipError_t launch_addsub_signed(const int64_t* d_a, const int64_t* d_b, size_t len, bool subtract, int64_t q, int64_t* d_out,
+                                hipStream_t s);
+
 // ---- dual-role launch: share generation of one tile + clerk-sum of the previous tile in ONE grid ----------
 // d_prev holds the previous tile's shares in the SAME layout as L.out (job stride = L.out_stride_clerk, row
 // stride = L.out_stride_participant), prev_rows participants; L.participants may be 0 (clerk-sum only) and

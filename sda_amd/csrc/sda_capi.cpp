@@ -278,6 +278,8 @@ int check_scheme_kind(const sda_sharing_scheme_t* s) {
 struct AccState {
     DevBuf lo, hi;
     size_t count = 0;
+    bool rust_signed = false;      // lo holds the reference's running values (int64, (-q, q)) instead of 128-bit sums
+    int64_t q = 0;                 // ... and this is the modulus of their `%` (set with the mode)
     int reset(size_t n, hipStream_t s) {
         SDA_TRY(lo.reserve(n * 8));
         SDA_TRY(hi.reserve(n * 8));
@@ -290,6 +292,26 @@ struct AccState {
     }
     void release() { lo.release(); hi.release(); count = 0; }
 };
+
+// one update / the final read-out of the running column sums, in either representation: exact 128-bit sums reduced once at
+// the end (canonical), or the reference's own `result = (result + v) % q` participant after participant (rust_signed)
+int acc_update(AccState& acc, const int64_t* d_shares, size_t jobs, size_t job_stride, size_t n_rows, size_t row_stride,
+               size_t dimension, hipStream_t s, unsigned max_wg_per_cu = 0, unsigned walk = 0) {
+    if (acc.rust_signed)
+        HIP_TRY(launch_combine_update_signed(acc.lo.as<int64_t>(), d_shares, jobs, job_stride, n_rows, row_stride, dimension, acc.q, s));
+    else
+        HIP_TRY(launch_combine_update(acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), d_shares, jobs, job_stride, n_rows, row_stride,
+                                      dimension, s, max_wg_per_cu, walk));
+    return SDA_OK;
+}
+int acc_finish(const AccState& acc, size_t count, const ModParams& mod, int64_t* d_out, hipStream_t s) {
+    if (acc.rust_signed) {
+        if (count) HIP_TRY(hipMemcpyAsync(d_out, acc.lo.p, count * 8, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIP_TRY(launch_combine_finish(acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), count, mod, d_out, s));
+    }
+    return SDA_OK;
+}
 
 // rows given as separate host vectors -> dense device tile uploads + combine_update
 int accumulate_host_rows(const Ctx& ctx, AccState& acc, DevBuf& tile, const int64_t* const* rows, size_t n_rows,
@@ -305,8 +327,7 @@ int accumulate_host_rows(const Ctx& ctx, AccState& acc, DevBuf& tile, const int6
         const size_t nr = std::min(rows_per_tile, n_rows - r0);
         for (size_t r = 0; r < nr; ++r)
             HIP_TRY(hipMemcpyAsync(tile.as<int64_t>() + r * stride, rows[r0 + r], dimension * 8, hipMemcpyHostToDevice, ctx.stream));
-        HIP_TRY(launch_combine_update(acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), tile.as<int64_t>(), 1, 0, nr, stride,
-                                      dimension, ctx.stream));
+        SDA_TRY(acc_update(acc, tile.as<int64_t>(), 1, 0, nr, stride, dimension, ctx.stream));
         HIP_TRY(hipStreamSynchronize(ctx.stream));          // the tile is reused
     }
     return SDA_OK;
@@ -318,7 +339,7 @@ int column_sum_host(const Ctx& ctx, AccState& acc, DevBuf& tile, DevBuf& d_out, 
     SDA_TRY(acc.reset(dimension, ctx.stream));
     SDA_TRY(accumulate_host_rows(ctx, acc, tile, rows, n_rows, dimension));
     SDA_TRY(d_out.reserve(dimension * 8));
-    HIP_TRY(launch_combine_finish(acc.lo.as<uint64_t>(), acc.hi.as<int64_t>(), dimension, mod, d_out.as<int64_t>(), ctx.stream));
+    SDA_TRY(acc_finish(acc, dimension, mod, d_out.as<int64_t>(), ctx.stream));
     HIP_TRY(hipMemcpyAsync(out, d_out.p, dimension * 8, hipMemcpyDeviceToHost, ctx.stream));
     return ctx.sync();
 }
@@ -462,6 +483,7 @@ struct sda_share_generator {
     DevBuf d_M, d_secrets, d_rand, d_out;
     // generate_combine_dev for shapes without a dual-role kernel: the clerk sum of the previous tile runs on this side stream
     // beside the share generation (fork / join with events), created on first use
+    bool rust_signed = false;            // SDA_VALUES_RUST_SIGNED (additive only): additive.rs:42-47 with Rust's own `%`
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int side_stream() {
@@ -729,6 +751,22 @@ extern "C" int sda_share_generator_set_drbg_master_key(sda_share_generator_t* g,
     g->drbg.set_master_key(key);
     return SDA_OK;
 }
+static int check_value_mode(int mode) {
+    if (mode != SDA_VALUES_CANONICAL && mode != SDA_VALUES_RUST_SIGNED) return fail(SDA_ERR_INVALID_ARGUMENT, "unknown value mode %d", mode);
+    return SDA_OK;
+}
+static const char* kNoSignedPacked =
+    "SDA_VALUES_RUST_SIGNED covers the arithmetic visible in the reference (additive sharing, the combiner, the masks); packed "
+    "Shamir's signed representatives are tss's, an un-vendored crate: compare those modulo the prime";
+
+extern "C" int sda_share_generator_set_value_mode(sda_share_generator_t* g, int mode) {
+    if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "generator is NULL");
+    SDA_TRY(check_value_mode(mode));
+    if (mode == SDA_VALUES_RUST_SIGNED && !g->additive) return fail(SDA_ERR_UNSUPPORTED, "%s", kNoSignedPacked);
+    g->rust_signed = mode == SDA_VALUES_RUST_SIGNED;
+    return SDA_OK;
+}
+
 extern "C" int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int rounds) {
     if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
     return g->drbg.set_rounds(rounds);
@@ -751,6 +789,21 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
     L.rand = d_rand; L.rand_stride = rand_stride;
     L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
     L.participants = participants; L.len = len; L.first_participant = first_participant;
+    if (g->additive && g->rust_signed) {
+        // the reference's representatives: shares 0..n-2 are the draws themselves, the last one the fold of (acc - r) % q.
+        // Draws that are not injected are materialised first - the same sda-drbg-v1 values the canonical kernel would use
+        if (!d_rand && g->n > 1) {
+            const size_t rstride = len * (g->n - 1);
+            SDA_TRY(g->d_rand.reserve(participants * rstride * 8));
+            HIP_TRY(launch_drbg_fill(g->d_rand.as<int64_t>(), rstride, participants, len, g->n - 1, first_participant, g->mod, key,
+                                     g->drbg.rounds, s));
+            L.rand = g->d_rand.as<int64_t>();
+            L.rand_stride = rstride;
+        }
+        if (g->n == 1) { L.rand = d_secrets; L.rand_stride = 0; }          // no draws at all: the pointer is never read
+        HIP_TRY(launch_additive_generate_signed(L, g->n, (int64_t)g->mod.m, s));
+        return SDA_OK;
+    }
     if (g->additive) {
         HIP_TRY(launch_additive_generate(L, g->n, g->mod, key, g->drbg.rounds, s));
         return SDA_OK;
@@ -900,6 +953,15 @@ extern "C" int sda_share_combiner_begin_dev(sda_share_combiner_t* c, size_t jobs
     return SDA_OK;
 }
 
+extern "C" int sda_share_combiner_set_value_mode(sda_share_combiner_t* c, int mode) {
+    if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
+    SDA_TRY(check_value_mode(mode));
+    c->begun = false;                                               // the running sums are kept in ONE representation: begin again
+    c->acc.rust_signed = mode == SDA_VALUES_RUST_SIGNED;            // combiner.rs:20-26 is the same loop for both sharing schemes
+    c->acc.q = (int64_t)c->mod.m;
+    return SDA_OK;
+}
+
 extern "C" int sda_share_combiner_update_dev(sda_share_combiner_t* c, const int64_t* d_shares, size_t job_stride,
                                              size_t n_rows, size_t row_stride, void* stream) {
     if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
@@ -907,9 +969,7 @@ extern "C" int sda_share_combiner_update_dev(sda_share_combiner_t* c, const int6
     if (n_rows == 0 || c->jobs == 0 || c->dimension == 0) return SDA_OK;
     if (!d_shares) return fail(SDA_ERR_INVALID_ARGUMENT, "d_shares is NULL");
     SDA_TRY(c->ctx.use());
-    HIP_TRY(launch_combine_update(c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_shares, c->jobs, job_stride, n_rows,
-                                  row_stride, c->dimension, c->ctx.pick(stream), c->max_wg_per_cu));
-    return SDA_OK;
+    return acc_update(c->acc, d_shares, c->jobs, job_stride, n_rows, row_stride, c->dimension, c->ctx.pick(stream), c->max_wg_per_cu);
 }
 
 // software-pipelined step: tile i+1 is generated while tile i is summed, in one dual-role launch
@@ -921,6 +981,8 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
                                                         size_t prev_participants, void* stream) {
     if (!g || !c) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
     if (!c->begun) return fail(SDA_ERR_STATE, "combiner: update before begin");
+    if (g->rust_signed || c->acc.rust_signed)
+        return fail(SDA_ERR_UNSUPPORTED, "the dual-role launch sums in 128 bits: SDA_VALUES_RUST_SIGNED takes generate_batch_dev + update_dev");
     const size_t B = (size_t)sda_share_generator_batch_count(g, len);
     if (c->jobs != g->n || c->dimension != B)
         return fail(SDA_ERR_INVALID_ARGUMENT, "combiner must have been begun with jobs = share_count (%u) and dimension = batches (%zu)", g->n, B);
@@ -1002,9 +1064,7 @@ extern "C" int sda_share_combiner_finish_dev(sda_share_combiner_t* c, int64_t* d
     if (c->jobs * c->dimension == 0) return SDA_OK;
     if (!d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "d_out is NULL");
     SDA_TRY(c->ctx.use());
-    HIP_TRY(launch_combine_finish(c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), c->jobs * c->dimension, c->mod, d_out,
-                                  c->ctx.pick(stream)));
-    return SDA_OK;
+    return acc_finish(c->acc, c->jobs * c->dimension, c->mod, d_out, c->ctx.pick(stream));
 }
 
 extern "C" int sda_share_combiner_begin(sda_share_combiner_t* c, size_t dimension) {
@@ -1100,6 +1160,15 @@ extern "C" void sda_secret_reconstructor_free(sda_secret_reconstructor_t* r) {
     delete r;
 }
 
+extern "C" int sda_secret_reconstructor_set_value_mode(sda_secret_reconstructor_t* r, int mode) {
+    if (!r) return fail(SDA_ERR_INVALID_ARGUMENT, "reconstructor is NULL");
+    SDA_TRY(check_value_mode(mode));
+    if (mode == SDA_VALUES_RUST_SIGNED && !r->additive) return fail(SDA_ERR_UNSUPPORTED, "%s", kNoSignedPacked);
+    r->acc.rust_signed = mode == SDA_VALUES_RUST_SIGNED;
+    r->acc.q = (int64_t)r->mod.m;
+    return SDA_OK;
+}
+
 // k x n' Lagrange matrix of tss reconstruct: nodes {1} U {w3^(idx+1)}, evaluated at w2^e, e = 1..k;
 // the column of node 1 (value 0) is dropped.  Identical for every batch, so it is built once per
 // clerk-index set instead of once per batch (reference: Newton interpolation per batch).
@@ -1136,8 +1205,8 @@ extern "C" int sda_secret_reconstructor_reconstruct_dev(sda_secret_reconstructor
         if (n_rows == 0 || row_len == 0) return SDA_OK;
         if (!d_shares || !d_out || out_cap < row_len) return fail(SDA_ERR_INVALID_ARGUMENT, "bad device buffers");
         SDA_TRY(r->acc.reset(row_len, s));
-        HIP_TRY(launch_combine_update(r->acc.lo.as<uint64_t>(), r->acc.hi.as<int64_t>(), d_shares, 1, 0, n_rows, row_stride, row_len, s));
-        HIP_TRY(launch_combine_finish(r->acc.lo.as<uint64_t>(), r->acc.hi.as<int64_t>(), row_len, r->mod, d_out, s));
+        SDA_TRY(acc_update(r->acc, d_shares, 1, 0, n_rows, row_stride, row_len, s));          // additive.rs:62-69
+        SDA_TRY(acc_finish(r->acc, row_len, r->mod, d_out, s));
         *out_len = row_len;
         return SDA_OK;
     }
@@ -1204,6 +1273,18 @@ struct MaskCore {
     AccState acc;
     DevBuf tile, d_a, d_b, d_out, d_seeds, d_flags, d_list;
     Drbg drbg;
+    bool rust_signed = false;      // SDA_VALUES_RUST_SIGNED: full.rs:30,46-48,62 / chacha.rs:43,88 with Rust's own `%`
+    int set_value_mode(int mode) {
+        if (mode != SDA_VALUES_CANONICAL && mode != SDA_VALUES_RUST_SIGNED) return fail(SDA_ERR_INVALID_ARGUMENT, "unknown value mode %d", mode);
+        rust_signed = mode == SDA_VALUES_RUST_SIGNED;
+        return SDA_OK;
+    }
+    // (a + b) % q or (a - b) % q in the handle's representation
+    int addsub(const int64_t* d_x, const int64_t* d_y, size_t len, bool subtract, int64_t* d_z, hipStream_t s) const {
+        if (rust_signed) HIP_TRY(launch_addsub_signed(d_x, d_y, len, subtract, (int64_t)mod.m, d_z, s));
+        else HIP_TRY(launch_addsub_mod(d_x, d_y, len, subtract, mod, d_z, s));
+        return SDA_OK;
+    }
 
     int init(const sda_masking_scheme_t* s) {
         if (!s) return fail(SDA_ERR_INVALID_ARGUMENT, "scheme is NULL");
@@ -1307,7 +1388,11 @@ extern "C" int sda_secret_masker_mask(sda_secret_masker_t* m, const int64_t* sec
         SDA_TRY(c.d_b.reserve(len * 8));
         SDA_TRY(c.d_out.reserve(len * 8));
         HIP_TRY(hipMemcpyAsync(c.d_a.p, secrets, len * 8, hipMemcpyHostToDevice, s));
-        if (rand) {
+        if (rand && c.rust_signed) {
+            // full.rs:25-30: the mask is the draws as they are, masked = (s + m) % q
+            HIP_TRY(hipMemcpyAsync(c.d_b.p, rand, len * 8, hipMemcpyHostToDevice, s));
+            SDA_TRY(c.addsub(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), len, false, c.d_out.as<int64_t>(), s));
+        } else if (rand) {
             HIP_TRY(hipMemcpyAsync(c.d_b.p, rand, len * 8, hipMemcpyHostToDevice, s));
             HIP_TRY(launch_addsub_mod(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), len, false, c.mod, c.d_out.as<int64_t>(), s));
             // canonical mask = (rand + 0) mod q
@@ -1321,6 +1406,8 @@ extern "C" int sda_secret_masker_mask(sda_secret_masker_t* m, const int64_t* sec
                                                         c.d_b.as<int64_t>(), len, c.d_out.as<int64_t>(), len, s);
             explicit_bzero(&key, sizeof key);
             HIP_TRY(he);
+            if (c.rust_signed)      // the draws are in [0, q) either way; only the sum takes the reference's sign (secrets are unchecked i64)
+                SDA_TRY(c.addsub(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), len, false, c.d_out.as<int64_t>(), s));
         }
         HIP_TRY(hipMemcpyAsync(mask_out, c.d_b.p, len * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(masked_out, c.d_out.p, len * 8, hipMemcpyDeviceToHost, s));
@@ -1349,7 +1436,7 @@ extern "C" int sda_secret_masker_mask(sda_secret_masker_t* m, const int64_t* sec
         SDA_TRY(c.d_out.reserve(len * 8));
         HIP_TRY(launch_combine_finish(c.acc.lo.as<uint64_t>(), c.acc.hi.as<int64_t>(), len, c.mod, c.d_b.as<int64_t>(), s));
         HIP_TRY(hipMemcpyAsync(c.d_a.p, secrets, len * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(launch_addsub_mod(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), len, false, c.mod, c.d_out.as<int64_t>(), s));
+        SDA_TRY(c.addsub(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), len, false, c.d_out.as<int64_t>(), s));    // chacha.rs:41-44
         HIP_TRY(hipMemcpyAsync(masked_out, c.d_out.p, len * 8, hipMemcpyDeviceToHost, s));
         SDA_TRY(c.ctx.sync());
     }
@@ -1365,6 +1452,7 @@ extern "C" int sda_secret_masker_mask_batch_dev(sda_secret_masker_t* m, const in
                                                 size_t masked_stride, void* stream) {
     if (!m) return fail(SDA_ERR_INVALID_ARGUMENT, "masker is NULL");
     MaskCore& c = m->core;
+    if (c.rust_signed) return fail(SDA_ERR_UNSUPPORTED, "SDA_VALUES_RUST_SIGNED is served by the trait-shaped mask(); the batched device form emits canonical residues");
     if (participants == 0 || len == 0) return SDA_OK;
     if (!d_secrets || !d_masked) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
     if (secrets_stride < len || masked_stride < len) return fail(SDA_ERR_INVALID_ARGUMENT, "stride < len");
@@ -1456,11 +1544,15 @@ extern "C" int sda_mask_combiner_combine(sda_mask_combiner_t* mc, const int64_t*
         if (!out || out_cap < dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small");
         for (size_t r = 0; r < n_rows; ++r)
             if (!rows[r]) return fail(SDA_ERR_INVALID_ARGUMENT, "rows[%zu] is NULL", r);
+        c.acc.rust_signed = c.rust_signed;                                    // full.rs:46-48 is the combiner's loop
+        c.acc.q = (int64_t)c.mod.m;
         SDA_TRY(column_sum_host(c.ctx, c.acc, c.tile, c.d_out, c.mod, rows, n_rows, dimension, out));
         *out_len = dimension;
         return SDA_OK;
     }
-    // ChaCha - chacha.rs:56-77: result has the CONFIGURED dimension (:58), also for zero seeds
+    // ChaCha - chacha.rs:56-77: result has the CONFIGURED dimension (:58), also for zero seeds.  Every mask is >= 0 and the
+    // running value starts at 0, so `result += m; result %= q` never leaves [0, q): both value modes give the same numbers
+    c.acc.rust_signed = false;
     const size_t dimension = (size_t)c.scheme.dimension;
     if (dimension == 0) return SDA_OK;
     if (!out || out_cap < dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "output buffer too small");
@@ -1478,6 +1570,16 @@ extern "C" int sda_mask_combiner_combine(sda_mask_combiner_t* mc, const int64_t*
     SDA_TRY(c.ctx.sync());
     *out_len = dimension;
     return SDA_OK;
+}
+
+extern "C" int sda_secret_masker_set_value_mode(sda_secret_masker_t* m, int mode) {
+    return m ? m->core.set_value_mode(mode) : fail(SDA_ERR_INVALID_ARGUMENT, "masker is NULL");
+}
+extern "C" int sda_mask_combiner_set_value_mode(sda_mask_combiner_t* c, int mode) {
+    return c ? c->core.set_value_mode(mode) : fail(SDA_ERR_INVALID_ARGUMENT, "mask combiner is NULL");
+}
+extern "C" int sda_secret_unmasker_set_value_mode(sda_secret_unmasker_t* u, int mode) {
+    return u ? u->core.set_value_mode(mode) : fail(SDA_ERR_INVALID_ARGUMENT, "unmasker is NULL");
 }
 
 extern "C" int sda_secret_unmasker_unmask(sda_secret_unmasker_t* u, const int64_t* mask, size_t mask_len,
@@ -1501,7 +1603,7 @@ extern "C" int sda_secret_unmasker_unmask(sda_secret_unmasker_t* u, const int64_
     SDA_TRY(c.d_out.reserve(masked_len * 8));
     HIP_TRY(hipMemcpyAsync(c.d_a.p, masked, masked_len * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c.d_b.p, mask, masked_len * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(launch_addsub_mod(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), masked_len, true, c.mod, c.d_out.as<int64_t>(), s));   // (ms - m) % q
+    SDA_TRY(c.addsub(c.d_a.as<int64_t>(), c.d_b.as<int64_t>(), masked_len, true, c.d_out.as<int64_t>(), s));   // (ms - m) % q
     HIP_TRY(hipMemcpyAsync(out, c.d_out.p, masked_len * 8, hipMemcpyDeviceToHost, s));
     return c.ctx.sync();
 }
@@ -1519,8 +1621,7 @@ extern "C" int sda_secret_unmasker_unmask_dev(sda_secret_unmasker_t* u, const in
     }
     if (!d_mask) return fail(SDA_ERR_INVALID_ARGUMENT, "d_mask is NULL");
     SDA_TRY(c.ctx.use());
-    HIP_TRY(launch_addsub_mod(d_masked, d_mask, len, true, c.mod, d_out, c.ctx.pick(stream)));
-    return SDA_OK;
+    return c.addsub(d_masked, d_mask, len, true, d_out, c.ctx.pick(stream));
 }
 
 extern "C" int sda_positive(const int64_t* values, size_t len, int64_t modulus, int64_t* out) {
@@ -1690,6 +1791,7 @@ extern "C" int sda_share_combiner_update_varint_dev(sda_share_combiner_t* c, sda
                                                     size_t rows, uint32_t* d_status, void* stream) {
     if (!c || !codec) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
     if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (c->acc.rust_signed) return fail(SDA_ERR_UNSUPPORTED, "the wire-fed updates sum in 128 bits: SDA_VALUES_RUST_SIGNED takes decode + update[_dev]");
     if (rows == 0 || c->jobs == 0) return SDA_OK;
     if (rows % c->jobs) return fail(SDA_ERR_INVALID_ARGUMENT, "rows (%zu) must be a multiple of the combiner's jobs (%zu): job-major rows", rows, c->jobs);
     if (!d_status) return fail(SDA_ERR_INVALID_ARGUMENT, "d_status is NULL");
@@ -1752,6 +1854,7 @@ extern "C" int sda_share_combiner_update_varint_rows_dev(sda_share_combiner_t* c
                                                          size_t rows, uint32_t* d_status, void* stream) {
     if (!c || !codec) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
     if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (c->acc.rust_signed) return fail(SDA_ERR_UNSUPPORTED, "the wire-fed updates sum in 128 bits: SDA_VALUES_RUST_SIGNED takes decode + update[_dev]");
     if (rows == 0 || c->jobs == 0) return SDA_OK;
     if (rows % c->jobs) return fail(SDA_ERR_INVALID_ARGUMENT, "rows (%zu) must be a multiple of the combiner's jobs (%zu): job-major rows", rows, c->jobs);
     if (!d_status || !d_bytes || !d_row_bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL device pointer");
@@ -1769,6 +1872,7 @@ extern "C" int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_var
                                                 size_t n_bytes) {
     if (!c || !codec) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL handle");
     if (!c->begun) return fail(SDA_ERR_STATE, "update before begin");
+    if (c->acc.rust_signed) return fail(SDA_ERR_UNSUPPORTED, "the wire-fed updates sum in 128 bits: SDA_VALUES_RUST_SIGNED takes decode + update[_dev]");
     if (c->jobs != 1) return fail(SDA_ERR_STATE, "the host form takes one participant's vector for ONE job (begin with jobs == 1)");
     if (n_bytes > 0 && !bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
     SDA_TRY(c->ctx.use());

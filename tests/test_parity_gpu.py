@@ -76,6 +76,104 @@ def test_reference_full_loop_vectors(gpu, idx):
     _run_scenario(load_golden("full_loop.json")["scenarios"][idx])
 
 
+def _run_scenario_rust_signed(sc):
+    """SDA_VALUES_RUST_SIGNED: every stage BIT FOR BIT equal to the oracle's `rust_signed` stages - the reference's own
+    representatives (Rust's truncated `%`), for the paths whose arithmetic is in /root/reference
+    (additive.rs, combiner.rs, full.rs, chacha.rs).  Packed Shamir's shares / reconstruction stay canonical (tss's signed
+    values are an un-vendored crate's): there the comparison is modulo the prime, as before."""
+    from sda_amd import crypto
+    a = sc["aggregation"]
+    agg = crypto.Aggregation(a["vector_dimension"], a["modulus"], _mask_scheme(a["masking_scheme"]),
+                             _scheme(a["committee_sharing_scheme"]))
+    mask_rand = sc.get("mask_rand")
+    if a["masking_scheme"]["kind"] == "None":
+        mask_rand = None
+    got = crypto.full_aggregation(agg, sc["inputs"], mask_rand, sc["share_rand"], sc["clerk_subset"], value_mode=crypto.RUST_SIGNED)
+    want = sc["stages"]["rust_signed"]
+    additive = a["committee_sharing_scheme"]["kind"] == "Additive"
+    q = a["committee_sharing_scheme"].get("modulus", a["committee_sharing_scheme"].get("prime_modulus"))
+    same = (lambda g, w: list(map(int, g)) == list(w)) if additive else (lambda g, w: [int(v) % q for v in g] == [v % q for v in w])
+    for p in range(len(sc["inputs"])):
+        assert list(map(int, got["masked"][p])) == want["masked"][p], f"masked secrets of participant {p}"        # exact, both schemes
+        if a["masking_scheme"]["kind"] != "None":
+            assert list(map(int, got["masks"][p])) == want["masks"][p]
+        for c, row in enumerate(got["shares"][p]):
+            assert same(row, want["shares"][p][c]), f"share {c} of participant {p}"
+    for c, row in enumerate(got["clerk_sums"]):
+        assert same(row, want["clerk_sums"][c]), f"clerk sum {c}"
+    assert list(map(int, got["combined_mask"])) == want["combined_mask"]
+    assert same(got["masked_output"], want["masked_output"])
+    assert same(got["output"], want["output"])
+    assert list(map(int, got["positive"])) == want["positive"] == sc.get("expected_positive", want["positive"])
+    return additive
+
+
+@pytest.mark.parametrize("name,idx", [("full_loop.json", i) for i in range(7)] + [("p62.json", i) for i in range(7)])
+def test_reference_signed_representatives_bit_for_bit(gpu, name, idx):
+    """F0-F4 (the reference's own scenarios) and the 62-bit scenarios in the reference's OWN value representation"""
+    sc = load_golden(name)["scenarios"][idx]
+    if "rust_signed" not in sc["stages"]:
+        pytest.skip("this scenario has no rust_signed stages (the reference's packed arithmetic overflows at this prime)")
+    _run_scenario_rust_signed(sc)
+
+
+@pytest.mark.parametrize("q", [433, P62, (1 << 62) - 57, 2])
+def test_signed_mode_random_any_i64_vs_oracle(gpu, q):
+    """the signed kernels against the oracle's rust_signed restatement on ANY i64 inputs (the reference never range-checks;
+    the oracle forms every sum exactly): additive generate with injected draws, combine over many participants (signs
+    depend on the history), additive reconstruct, full mask / unmask, ChaCha mask / unmask"""
+    from sda_amd import crypto
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(q % 1000)
+    n, dim, P = 4, 257, 37
+    big = lambda size: rng.integers(-(1 << 62) + 1, (1 << 62) - 1, size=size, dtype=np.int64)
+    small = lambda size: rng.integers(-q + 1, q, size=size, dtype=np.int64) if q < (1 << 62) else big(size)
+    sch = crypto.Additive(n, q)
+    gen = crypto.ShareGenerator(sch).set_value_mode("rust_signed")
+    osch = po.AdditiveSecretSharing(n, q, "rust_signed")
+    rows = []
+    for pick in (big, small):
+        secrets, rand = pick(dim), pick(dim * (n - 1))
+        got = gen.generate(secrets, rand)
+        want = po.generate(osch, [int(v) for v in secrets], [int(v) for v in rand])
+        assert [list(map(int, r)) for r in got] == want
+        rows.append(got)
+    comb = crypto.ShareCombiner(sch).set_value_mode("rust_signed")
+    vecs = [small(dim) for _ in range(P)] + [big(dim) for _ in range(3)]
+    want = po.combine([[int(v) for v in r] for r in vecs], q, "rust_signed")
+    assert list(map(int, comb.combine(vecs))) == want
+    comb.begin(dim)                                                   # the streaming form keeps the same state
+    comb.update(np.stack(vecs[:20])); comb.update(np.stack(vecs[20:]))
+    assert list(map(int, comb.finish())) == want
+    rec = crypto.SecretReconstructor(sch, dim).set_value_mode("rust_signed")
+    clerk = [small(dim) for _ in range(n)]
+    assert list(map(int, rec.reconstruct(list(enumerate(clerk))))) == osch.reconstruct([(i, [int(v) for v in r]) for i, r in enumerate(clerk)])
+    # masks
+    fm = po.FullMasker(q, "rust_signed")
+    m = crypto.SecretMasker(crypto.Full(q)).set_value_mode("rust_signed")
+    secrets, draws = big(dim), small(dim)
+    mask, masked = m.mask(secrets, draws)
+    wmask, wmasked = fm.mask([int(v) for v in secrets], [int(v) for v in draws])
+    assert list(map(int, mask)) == wmask and list(map(int, masked)) == wmasked
+    mc = crypto.MaskCombiner(crypto.Full(q)).set_value_mode("rust_signed")
+    assert list(map(int, mc.combine(vecs))) == fm.combine([[int(v) for v in r] for r in vecs])
+    um = crypto.SecretUnmasker(crypto.Full(q)).set_value_mode("rust_signed")
+    a_, b_ = big(dim), big(dim)
+    assert list(map(int, um.unmask((a_, b_)))) == fm.unmask([int(v) for v in a_], [int(v) for v in b_])
+    if q > 2:
+        cm = po.ChaChaMasker(q, dim, 128, "rust_signed")
+        m2 = crypto.SecretMasker(crypto.ChaCha(q, dim, 128)).set_value_mode("rust_signed")
+        seed = [1, 2, 3, 0xFFFFFFFF]
+        mask, masked = m2.mask(secrets, seed)
+        wmask, wmasked = cm.mask([int(v) for v in secrets], seed)
+        assert list(map(int, mask)) == wmask and list(map(int, masked)) == wmasked
+    # what the mode does not cover says so
+    from sda_amd import capi
+    with pytest.raises(capi.SdaError) as e:
+        crypto.ShareGenerator(crypto.PackedShamir(3, 8, 1, P62, W[8], W[9])).set_value_mode("rust_signed")
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("idx", range(7))
 def test_p62_vectors(gpu, idx):
     """62-bit prime configurations (BASELINE configs 2-4 shapes) incl. un-range-checked i64 inputs."""
