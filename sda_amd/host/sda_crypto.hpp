@@ -98,6 +98,8 @@ struct LinearMaskingScheme {
 struct ShareGenerator {
     sda_share_generator_t* h = nullptr;
     explicit ShareGenerator(const LinearSecretSharingScheme& s) { detail::check(sda_share_generator_new(&s.c, &h)); }
+    // SDA_VALUES_RUST_SIGNED: the reference's own signed representatives (sda_hip.h "value representation")
+    void set_value_mode(int mode) { detail::check(sda_share_generator_set_value_mode(h, mode)); }
     ~ShareGenerator() { sda_share_generator_free(h); }
     ShareGenerator(const ShareGenerator&) = delete;
     /// generate(&mut self, secrets) -> Vec<Vec<Share>>: outer index = clerk (batched.rs:46-48)
@@ -115,6 +117,8 @@ struct ShareGenerator {
 struct ShareCombiner {
     sda_share_combiner_t* h = nullptr;
     explicit ShareCombiner(const LinearSecretSharingScheme& s) { detail::check(sda_share_combiner_new(&s.c, &h)); }
+    // SDA_VALUES_RUST_SIGNED: the reference's own signed representatives (sda_hip.h "value representation")
+    void set_value_mode(int mode) { detail::check(sda_share_combiner_set_value_mode(h, mode)); }
     ~ShareCombiner() { sda_share_combiner_free(h); }
     ShareCombiner(const ShareCombiner&) = delete;
     std::vector<Share> combine(const std::vector<std::vector<Share>>& shares) const {
@@ -246,6 +250,7 @@ struct SecretReconstructor {
         detail::check(sda_secret_reconstructor_new(&s.c, dim, &h));
     }
     ~SecretReconstructor() { sda_secret_reconstructor_free(h); }
+    void set_value_mode(int mode) { detail::check(sda_secret_reconstructor_set_value_mode(h, mode)); }
     SecretReconstructor(const SecretReconstructor&) = delete;
     std::vector<Secret> reconstruct(const std::vector<std::pair<size_t, std::vector<Share>>>& indexed_shares) const {
         std::vector<size_t> idx(indexed_shares.size()), lens(indexed_shares.size());
@@ -267,6 +272,8 @@ struct SecretReconstructor {
 struct SecretMasker {
     sda_secret_masker_t* h = nullptr;
     explicit SecretMasker(const LinearMaskingScheme& s) { detail::check(sda_secret_masker_new(&s.c, &h)); }
+    // SDA_VALUES_RUST_SIGNED: the reference's own signed representatives (sda_hip.h "value representation")
+    void set_value_mode(int mode) { detail::check(sda_secret_masker_set_value_mode(h, mode)); }
     ~SecretMasker() { sda_secret_masker_free(h); }
     SecretMasker(const SecretMasker&) = delete;
     std::pair<std::vector<Mask>, std::vector<MaskedSecret>> mask(const std::vector<Secret>& secrets,
@@ -289,6 +296,7 @@ struct MaskCombiner {
         detail::check(sda_mask_combiner_new(&s.c, &h));
     }
     ~MaskCombiner() { sda_mask_combiner_free(h); }
+    void set_value_mode(int mode) { detail::check(sda_mask_combiner_set_value_mode(h, mode)); }
     MaskCombiner(const MaskCombiner&) = delete;
     std::vector<Mask> combine(const std::vector<std::vector<Mask>>& masks) const {
         std::vector<size_t> lens;
@@ -304,6 +312,8 @@ struct MaskCombiner {
 struct SecretUnmasker {
     sda_secret_unmasker_t* h = nullptr;
     explicit SecretUnmasker(const LinearMaskingScheme& s) { detail::check(sda_secret_unmasker_new(&s.c, &h)); }
+    // SDA_VALUES_RUST_SIGNED: the reference's own signed representatives (sda_hip.h "value representation")
+    void set_value_mode(int mode) { detail::check(sda_secret_unmasker_set_value_mode(h, mode)); }
     ~SecretUnmasker() { sda_secret_unmasker_free(h); }
     SecretUnmasker(const SecretUnmasker&) = delete;
     std::vector<Secret> unmask(const std::pair<std::vector<Mask>, std::vector<MaskedSecret>>& values) const {

@@ -65,6 +65,30 @@ int main() {
     const std::vector<std::vector<int64_t>> readme = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}};
     EXPECT(run({10, 433, LinearMaskingScheme::None(), add}, readme) == (std::vector<int64_t>{0, 2, 2, 4, 4, 6, 6, 8, 8, 10}),
            "README walkthrough (README.md:157)");
+    // the reference's own value representation (Rust's truncated %): additive.rs:42-47 leaves the n-1 draws as they are
+    // and folds the last share into (-q, q) - here 1 - r1 - r2 is negative unless both draws are tiny - and the clerks'
+    // and the recipient's sums keep the sign of their running totals; positive() lands on the same output
+    {
+        ShareGenerator gen(add);
+        gen.set_value_mode(SDA_VALUES_RUST_SIGNED);
+        const std::vector<int64_t> secrets = {1, 2, 3, 4};
+        const auto shares = gen.generate(secrets);
+        bool shape = shares.size() == 3, fold = true, some_negative = false;
+        for (size_t i = 0; shape && i < 4; ++i) {
+            fold = fold && shares[0][i] >= 0 && shares[0][i] < 433 && shares[1][i] >= 0 && shares[1][i] < 433 &&
+                   shares[2][i] == ((secrets[i] - shares[0][i]) % 433 - shares[1][i]) % 433;       // C's % truncates like Rust's
+            some_negative = some_negative || shares[2][i] < 0;
+        }
+        EXPECT(shape && fold, "rust_signed additive shares are the reference's fold");
+        EXPECT(some_negative, "rust_signed: the folded share keeps Rust's sign");
+        ShareCombiner comb(add);
+        comb.set_value_mode(SDA_VALUES_RUST_SIGNED);
+        std::vector<std::pair<size_t, std::vector<Share>>> sums;
+        for (size_t c = 0; c < 3; ++c) sums.push_back({c, comb.combine({shares[c], shares[c]})});     // two identical participants
+        SecretReconstructor rec(add, 4);
+        rec.set_value_mode(SDA_VALUES_RUST_SIGNED);
+        EXPECT((RecipientOutput{433, rec.reconstruct(sums)}.positive().values) == want, "rust_signed round trip");
+    }
     // the same loop over the wire format: every share vector varint-encoded (sodium.rs:36-41), each clerk streaming
     // the opened payloads into its running sum (clerk.rs:78-86 without materialising them)
     {
