@@ -240,10 +240,11 @@ class Env:
                 ident = (C.c_uint8 * 128)()
                 if self.rank == 0 and self.lib.sda_comm_unique_id(ident) != capi.OK:
                     ok = 0
-                box = [bytes(ident)]
+                box = [bytes(ident), ok]
                 if self.use_dist:
                     dist.broadcast_object_list(box, src=0)
-                if self.lib.sda_comm_init((C.c_uint8 * 128)(*box[0]), self.rank, self.world, C.byref(self.comm)) != capi.OK:
+                ok = box[1]                                          # no id (RCCL not loadable on rank 0): nobody enters the collective init
+                if ok and self.lib.sda_comm_init((C.c_uint8 * 128)(*box[0]), self.rank, self.world, C.byref(self.comm)) != capi.OK:
                     ok = 0
                 C.CDLL(None).fflush(None)
             finally:
