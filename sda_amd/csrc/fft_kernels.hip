@@ -159,24 +159,26 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 X[(size_t)(8u * nb + jj) * m2 + 1 + k + i] = val;
             }
         }
-    } else {                                  // G == 1: this batch uses its two words of each block
+    } else {                                  // G = 1, 2, 4 batches of ONE block group of 8: each block serves G of its 8 word pairs
         const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
-        const uint64_t b = b_first;
-        const int cc = (int)((b & 7) >> 1), e = (int)(b & 1);
+        const uint32_t off = (uint32_t)(b_first & 7);                       // a multiple of G
         for (uint32_t i = tid; i < t; i += T) {
-            const uint64_t I = (b >> 3) * (uint64_t)t + i;
+            const uint64_t I = (b_first >> 3) * (uint64_t)t + i;
             uint32_t o[16];
             chacha_block_lane<ROUNDS>(kk, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream, (uint32_t)(stream >> 32) & 0xFFFFFFu, o);
-            uint32_t hi = 0, lo = 0;
+            for (uint32_t jj = 0; jj < G; ++jj) {
+                const uint32_t w8 = off + jj, want_hi = 8u * (w8 & 1u) + (w8 >> 1), want_lo = want_hi + 4u;
+                uint32_t hi = 0, lo = 0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) {
-                if (w == 8 * e + cc) hi = o[w];
-                if (w == 8 * e + 4 + cc) lo = o[w];
+                for (int w = 0; w < 16; ++w) {                              // o[] lives in registers: select, do not index
+                    if ((uint32_t)w == want_hi) hi = o[w];
+                    if ((uint32_t)w == want_lo) lo = o[w];
+                }
+                uint64_t val;
+                if (!lemire_sample(((uint64_t)hi << 32) | lo, mod.m, mod.lemire_thr, val))
+                    val = f_drbg_retry<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, (b_first + jj) * (uint64_t)t + i, mod.m, mod.lemire_thr);
+                X[(size_t)jj * m2 + 1 + k + i] = val;
             }
-            uint64_t val;
-            if (!lemire_sample(((uint64_t)hi << 32) | lo, mod.m, mod.lemire_thr, val))
-                val = f_drbg_retry<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, b * (uint64_t)t + i, mod.m, mod.lemire_thr);
-            X[1 + k + i] = val;
         }
     }
     __syncthreads();
@@ -302,7 +304,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
         const bool last = left == 2;
         for (uint32_t u = tid; u < G * ninth; u += T) {
             uint32_t j, q;
-            if (last && G >= 8) { j = u & (G - 1); q = u >> F.lgG; }
+            if (last && G > 1) { j = u & (G - 1); q = u >> F.lgG; }
             else { j = f_div(u, ninth, magic_ninth); q = u - j * ninth; }
             const uint32_t blk = f_div(q, t3, magic), jj = q - blk * t3;
             uint64_t* y = Y + (size_t)j * m3 + (size_t)blk * (9 * t3) + jj;
@@ -337,7 +339,14 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
 #pragma unroll
                     for (int e = 0; e < 9; ++e) {
                         const uint32_t pos = jj + (uint32_t)e * t3;
-                        if (pos) __builtin_nontemporal_store((int64_t)f_csub(f_red2(o[e], c.p2), c.p), op + (size_t)(pos - 1) * L.out_stride_clerk + b);
+                        if (pos) {
+                            const int64_t val = (int64_t)f_csub(f_red2(o[e], c.p2), c.p);
+                            int64_t* dst = op + (size_t)(pos - 1) * L.out_stride_clerk + b;
+                            // 64-byte segments (8 batches per row and workgroup): non-temporal.  Fewer batches per workgroup
+                            // leave 8- to 32-byte pieces of a line to DIFFERENT workgroups: those must meet in the L2
+                            // (write-back) - as non-temporal partial writes they cost 30000x (PSS_155_19682_100, measured)
+                            if (G >= 8) __builtin_nontemporal_store(val, dst); else *dst = val;
+                        }
                     }
                 }
             }
@@ -352,7 +361,9 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
         const uint32_t sj = u >> F.lgG, jj = u & (G - 1);   // batch fastest: G consecutive values per clerk row
         const uint64_t b = b_first + jj;
         if (b >= batches) continue;
-        __builtin_nontemporal_store((int64_t)f_csub(f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2), c.p), op + (size_t)sj * L.out_stride_clerk + b);
+        const int64_t val = (int64_t)f_csub(f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2), c.p);
+        int64_t* dst = op + (size_t)sj * L.out_stride_clerk + b;
+        if (G >= 8) __builtin_nontemporal_store(val, dst); else *dst = val;
     }
 }
 

@@ -597,12 +597,21 @@ static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, ui
     // per 500-participant tile of PSS_155_728_100, its barriers no longer hidden by a second workgroup, and the same
     // WRITE_SIZE: the 1.35x write amplification of round 2 came from write-back stores, not from half lines - the
     // non-temporal stores of the last pass bring it to 1.02x in either form.)
-    if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 8, true) <= half_cu) { G = 8; tw_lds = 1; }
-    else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 8, false) <= half_cu) { G = 8; tw_lds = 0; }
-    else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, true) <= half_cu) { G = 1; tw_lds = 1; }
-    else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, false) <= whole_cu) { G = 1; tw_lds = 0; }
-    else return false;
-    return true;
+    // the most batches per workgroup (8, 4, 2, 1: a power of two inside one CSPRNG block group of 8) that still leaves two
+    // workgroups per CU, twiddles in LDS when they fit too; a single batch may take the whole CU (PSS_155_19682_100: 157 KB)
+    G = 0;
+    for (uint32_t cand = 8; cand >= 1 && !G; cand >>= 1)
+        for (uint32_t tw = 2; tw-- > 0 && !G;)
+            if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, cand, tw != 0) <= half_cu) { G = cand; tw_lds = tw; }
+    if (!G && fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, false) <= whole_cu) { G = 1; tw_lds = 0; }
+    if (const char* fg = getenv("SDA_FFT_G")) {                          // A/B only: fewer batches per workgroup
+        const uint32_t want = (uint32_t)atoi(fg);
+        if (want == 1 || want == 2 || want == 4 || want == 8) {
+            if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, true) <= half_cu) { G = want; tw_lds = 1; }
+            else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, false) <= whole_cu) { G = want; tw_lds = 0; }
+        }
+    }
+    return G != 0;
 }
 
 // a constant and its Shoup companion floor(w 2^64 / p)
@@ -642,7 +651,7 @@ static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G,
     HIP_TRY(hipMemcpy(g->d_fft.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     FftPlan& F = g->fplan;
     F.k = g->k; F.t = g->t; F.n = g->n; F.m2 = (uint32_t)m2; F.a = a; F.m3 = (uint32_t)m3; F.b = b; F.G = G;
-    F.lgG = G == 16 ? 4 : G == 8 ? 3 : 0;
+    F.lgG = G == 16 ? 4 : G == 8 ? 3 : G == 4 ? 2 : G == 2 ? 1 : 0;
     F.tw_lds = tw_lds;
     F.nz_mask = 0;
     for (uint32_t e0 = 0; e0 < 3; ++e0)
