@@ -270,6 +270,7 @@ def _root(p, order):
     (P62, 70, 57, 242, None, None, 70 * 19 + 3, False),                  # 128 of 243: first-level butterflies in two of three groups, odd radix-2 count
     (P62, 100, 155, 2186, None, None, 100 * 3 + 7, False),               # n + 1 = 3^7: one batch per workgroup with the twiddles in LDS, single level + two radix-9 passes
     (TSS_P2, 100, 155, 19682, 4318906, 1814687, 250, False),             # PSS_155_19682_100: one batch fills the LDS (G = 1)
+    (4611686018374987777, 100, 155, 19682, None, None, 130, False),      # the same shape over the largest 62-bit prime with roots of order 256 and 3^9
     (P62, 3, 4, 8, W[8], W[9], 1000, True), (P62, 8, 7, 26, W[16], W[27], 6151, True),   # small tss-valid shapes, forced
     (433, 3, 4, 8, 354, 150, 7, True)])
 def test_transform_share_generation_vs_oracle(gpu, monkeypatch, p, k, t, n, w2, w3, dim, force):
