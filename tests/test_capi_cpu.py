@@ -155,6 +155,13 @@ def test_abi_misuse_returns_codes_not_crashes(built):
     assert lib.sda_share_combiner_update_varint_rows_dev(None, None, None, 16, None, 1, None, None) == bad
     assert lib.sda_secret_masker_mask_batch_dev(None, None, 1, 1, 1, 0, None, 1, None, 1, None) == bad
     assert lib.sda_secret_unmasker_unmask_dev(None, None, None, 1, None, None) == bad
+    # round 3: value mode setters, sealed-box key helper, communicator queries, device identity
+    for f in ("sda_share_generator_set_value_mode", "sda_share_combiner_set_value_mode", "sda_secret_reconstructor_set_value_mode",
+              "sda_secret_masker_set_value_mode", "sda_mask_combiner_set_value_mode", "sda_secret_unmasker_set_value_mode"):
+        assert getattr(lib, f)(None, 1) == bad
+    assert lib.sda_sealedbox_public_key(None, None, None) == bad
+    assert lib.sda_comm_device(None) == -1 and lib.sda_comm_world(None) == 0 and lib.sda_comm_rank(None) == -1
+    assert lib.sda_device_pci_bus_id(0, None, 0) == bad
     assert lib.sda_varint_slot_size(3) == 32 and lib.sda_varint_slot_size(0) == 0 and lib.sda_varint_max_encoded_size(3) == 30
     assert lib.sda_last_error() != b""
     # free functions accept NULL
