@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void k(const long long* __restrict__ in, long 
 
 // MODE 4: the dual-role launch's traffic without its arithmetic - every 15th workgroup sums 512 columns x 500 rows of a
 // second share buffer (16 x 16-byte nt loads in flight per lane), the others run the gen pattern on `out`
+template <int NTLOAD, int NTSTORE, int NTSECRET>
 __global__ __launch_bounds__(256) void kmix(const long long* __restrict__ in, long long* __restrict__ out,
                                             const long long* __restrict__ prev, size_t dim, size_t B, size_t Bs, size_t P,
                                             size_t chunks, unsigned long long n_gen, unsigned long long n_comb,
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void kmix(const long long* __restrict__ in, lo
         for (size_t r = split * 500; r < (split + 1) * 500; r += 16) {
             ll2 v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = r + u < (split + 1) * 500 ? __builtin_nontemporal_load(reinterpret_cast<const ll2*>(base + (r + u) * Bs)) : ll2{0, 0};
+            for (int u = 0; u < 16; ++u) v[u] = r + u < (split + 1) * 500 ? (NTLOAD ? __builtin_nontemporal_load(reinterpret_cast<const ll2*>(base + (r + u) * Bs)) : *reinterpret_cast<const ll2*>(base + (r + u) * Bs)) : ll2{0, 0};
 #pragma unroll
             for (int u = 0; u < 16; ++u) { a += v[u].x; c += v[u].y; }
         }
@@ -66,12 +67,13 @@ __global__ __launch_bounds__(256) void kmix(const long long* __restrict__ in, lo
     long long acc = 0;
     const long long* sp = in + p * dim + b0 * 3;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { v[i] = *reinterpret_cast<const ll2*>(sp + 2 * i); acc += v[i].x ^ v[i].y; }
+    for (int i = 0; i < 3; ++i) { v[i] = NTSECRET ? __builtin_nontemporal_load(reinterpret_cast<const ll2*>(sp + 2 * i)) : *reinterpret_cast<const ll2*>(sp + 2 * i); acc += v[i].x ^ v[i].y; }
     long long* op = out + p * Bs + b0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         ll2 w; w.x = acc + j; w.y = acc - j;
-        __builtin_nontemporal_store(w, reinterpret_cast<ll2*>(op + (size_t)j * P * Bs));
+        if (NTSTORE) __builtin_nontemporal_store(w, reinterpret_cast<ll2*>(op + (size_t)j * P * Bs));
+        else *reinterpret_cast<ll2*>(op + (size_t)j * P * Bs) = w;
     }
 }
 
@@ -116,7 +118,7 @@ int main() {
             float best = 1e9f;
             for (int r = 0; r < 5; ++r) {
                 CHK(hipEventRecord(e0));
-                kmix<<<dim3((unsigned)grid), dim3(256)>>>(in, out, prev, dim, B, Bs, P, chunks, n_gen, n_comb, col_blocks, sink, Gs[gi]);
+                kmix<1, 1, 0><<<dim3((unsigned)grid), dim3(256)>>>(in, out, prev, dim, B, Bs, P, chunks, n_gen, n_comb, col_blocks, sink, Gs[gi]);
                 CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
                 float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (r && ms < best) best = ms;
             }
@@ -124,6 +126,21 @@ int main() {
             snprintf(name, sizeof name, "dual-role traffic, runs of %u (106.2 GB)", Gs[gi]);
             printf("%-44s %7.3f ms  %6.2f TB/s\n", name, best, (rd + 2 * wr) / (best * 1e-3) / 1e12);
         }
+        // cache-policy variants of the same traffic (strict alternation): which of the three streams is non-temporal
+#define VARIANT(L, S, C)                                                                                                       \
+        {                                                                                                                      \
+            float best = 1e9f;                                                                                                 \
+            for (int r = 0; r < 5; ++r) {                                                                                      \
+                CHK(hipEventRecord(e0));                                                                                       \
+                kmix<L, S, C><<<dim3((unsigned)grid), dim3(256)>>>(in, out, prev, dim, B, Bs, P, chunks, n_gen, n_comb, col_blocks, sink, 1); \
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));                                                         \
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (r && ms < best) best = ms;                                \
+            }                                                                                                                  \
+            printf("share reads nt=%d, share writes nt=%d, secret reads nt=%d: %7.3f ms  %6.2f TB/s\n", L, S, C, best,        \
+                   (rd + 2 * wr) / (best * 1e-3) / 1e12);                                                                      \
+        }
+        VARIANT(1, 1, 0) VARIANT(0, 1, 0) VARIANT(1, 0, 0) VARIANT(0, 0, 0) VARIANT(1, 1, 1) VARIANT(0, 1, 1)
+#undef VARIANT
     }
     return 0;
 }
