@@ -77,6 +77,54 @@ __global__ __launch_bounds__(256) void kmix(const long long* __restrict__ in, lo
     }
 }
 
+// the same mix with a workgroup covering NP x 512 batches of one participant (NP consecutive 4 KB pieces per clerk row)
+template <int NP, int PER>
+__global__ __launch_bounds__(256) void kmix_wide(const long long* __restrict__ in, long long* __restrict__ out,
+                                                 const long long* __restrict__ prev, size_t dim, size_t B, size_t Bs, size_t P,
+                                                 size_t chunks, unsigned long long n_gen, unsigned long long n_comb,
+                                                 unsigned col_blocks, long long* sink) {
+    // every PER-th workgroup is a clerk-sum item until they run out; PER is ODD (workgroup b runs on XCD b mod 8: an even
+    // period parks every clerk-sum item on one or two XCDs) and at most the natural ratio 14 / NP + 1
+    const unsigned long long b = blockIdx.x, per = PER;
+    const unsigned long long grp = b / per, off = b - grp * per;
+    if (off == 0 && grp < n_comb) {
+        const size_t bx = grp % col_blocks, t = grp / col_blocks, job = t % 8, split = t / 8;
+        const size_t c0 = 2 * (bx * 256 + threadIdx.x);
+        if (c0 + 1 >= B) return;
+        const long long* base = prev + job * P * Bs + c0;
+        long long a = 0, c = 0;
+        for (size_t r = split * 500; r < (split + 1) * 500; r += 16) {
+            ll2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = r + u < (split + 1) * 500 ? __builtin_nontemporal_load(reinterpret_cast<const ll2*>(base + (r + u) * Bs)) : ll2{0, 0};
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { a += v[u].x; c += v[u].y; }
+        }
+        if ((a ^ c) == 0x1234567) *sink = a;
+        return;
+    }
+    const unsigned long long before = grp + (off > 0 ? 1 : 0);
+    const unsigned long long idx = b - (before < n_comb ? before : n_comb);
+    if (idx >= n_gen) return;
+    const size_t p = idx / chunks, chunk = idx - p * chunks;
+#pragma unroll
+    for (int h = 0; h < NP; ++h) {
+        const size_t pair = (chunk * NP + h) * 256 + threadIdx.x, b0 = 2 * pair;
+        if (b0 + 1 >= B || b0 * 3 + 6 > dim) continue;
+        ll2 v[3];
+        long long acc = 0;
+        const long long* sp = in + p * dim + b0 * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[i] = *reinterpret_cast<const ll2*>(sp + 2 * i); acc += v[i].x ^ v[i].y; }
+        long long* op = out + p * Bs + b0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ll2 w; w.x = acc + j; w.y = acc - j;
+            __builtin_nontemporal_store(w, reinterpret_cast<ll2*>(op + (size_t)j * P * Bs));
+        }
+    }
+}
+
 template <int MODE>
 int run(const char* name, const long long* in, long long* out, size_t dim, size_t B, size_t Bs, size_t P, long long* sink, double bytes) {
     const size_t chunks = (B / 2 + 255) / 256;
@@ -141,6 +189,21 @@ int main() {
         }
         VARIANT(1, 1, 0) VARIANT(0, 1, 0) VARIANT(1, 0, 0) VARIANT(0, 0, 0) VARIANT(1, 1, 1) VARIANT(0, 1, 1)
 #undef VARIANT
+#define WIDE(NP, PER)                                                                                                               \
+        {                                                                                                                      \
+            const size_t wchunks = (chunks + NP - 1) / NP;                                                                     \
+            const unsigned long long wn_gen = wchunks * P, wgrid = wn_gen + n_comb;                                            \
+            float best = 1e9f;                                                                                                 \
+            for (int r = 0; r < 5; ++r) {                                                                                      \
+                CHK(hipEventRecord(e0));                                                                                       \
+                kmix_wide<NP, PER><<<dim3((unsigned)wgrid), dim3(256)>>>(in, out, prev, dim, B, Bs, P, wchunks, wn_gen, n_comb, col_blocks, sink); \
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));                                                         \
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (r && ms < best) best = ms;                                \
+            }                                                                                                                  \
+            printf("share-gen workgroup covers %d x 512 batches, period %d: %7.3f ms  %6.2f TB/s\n", NP, PER, best, (rd + 2 * wr) / (best * 1e-3) / 1e12); \
+        }
+        WIDE(1, 15) WIDE(1, 13) WIDE(2, 7) WIDE(2, 5) WIDE(4, 3)
+#undef WIDE
     }
     return 0;
 }
