@@ -121,3 +121,29 @@ def test_comm_plan_multi_process_cpp(world, length, tmp_path):
     out = subprocess.run([exe, str(world), str(length), str(P62)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "comm plan ok" in out.stdout
+
+
+def test_bench_leg_planning_covers_the_baseline_jobs_exactly():
+    """bench.py --gpus N: BASELINE config 4 (1,000,000 participants) and config 5 (100,000) sharded over N = 2, 4, 8 ranks -
+    every rank's share splits into whole sub-tiles within the resident-tile bound, and steps x sub-tiles x tile x ranks is
+    exactly the job (the label is derived from that product); the headline's 100,000 per GPU likewise for the driver's
+    and the default step counts"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_planning", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world in (2, 4, 8):
+        for job, tile, steps in ((1_000_000, 1500, 10), (100_000, 125, 10)):
+            per_gpu = -(-job // world)
+            n_sub, p_sub = bench.plan_steps(per_gpu, steps, tile)
+            assert p_sub <= tile and steps * n_sub * p_sub * world == job, (world, job, n_sub, p_sub)
+    for steps in (20, 50):
+        n_sub, p_sub = bench.plan_steps(100_000, steps, bench.TILE_MAX)
+        assert p_sub <= bench.TILE_MAX and steps * n_sub * p_sub == 100_000
+    # a job that does not divide is rounded UP (never fewer participants than the label says), still inside the bound
+    n_sub, p_sub = bench.plan_steps(1001, 10, 7)
+    assert p_sub <= 7 and 10 * n_sub * p_sub >= 1001
+    # exchange sizes stated in DESIGN.md 6: [n][B] partial sums of 8 bytes
+    assert 8 * 26 * -(-(1 << 20) // 8) == 27_262_976 and 8 * 8 * -(-(1 << 24) // 3) == 357_913_984
