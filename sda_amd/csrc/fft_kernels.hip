@@ -4,8 +4,8 @@
 //
 // This is the path for LARGE tss-valid shapes (k + t > 32, e.g. tss's PSS_155_728_100: k=100, t=155, n=728), where the
 // dense n x (k+t) matrix form costs n (k+t) multiply-accumulates per batch (185,640) against ~2,200 butterflies here.
-// One workgroup owns a group of G batches (8 = the batches one CSPRNG block serves, or 1 when a batch alone fills the
-// LDS); values live in LDS as lazily reduced UNSIGNED 64-bit numbers.
+// One workgroup owns a group of G batches (8 = the batches one CSPRNG block serves; 4, 2 or 1 of one block group when 8 do
+// not leave two workgroups per CU their LDS); values live in LDS as lazily reduced UNSIGNED 64-bit numbers.
 //
 // Arithmetic (round 3; exactness and every bound: tests/test_fft_model.py).  p < 2^62, so 4p < 2^64: values are kept in
 // [0, 4p) ("relaxed") or [0, 2p) ("reduced") and a butterfly needs a conditional subtraction of 2p only where a third
