@@ -790,9 +790,13 @@ def main():
         # BASELINE config 4's shape on one GPU (t=2 k=8 n=26; 4 steps of 1500 of its 1,000,000 participants; the sharded job
         # itself is a leg of the N > 1 run)
         c4 = run("packed26", 4, 1, participants=6000, tile=1500)
+        # tss's own shipped parameter set PSS_155_728_100 (k=100 t=155 n=728) through the transform kernel, clerk sum on the
+        # side stream (4 steps of 500 participants)
+        pss = run("packed_pss728", 4, 1, participants=2000)
         line["additional_workloads"] = {"additive": {k: add[k] for k in keep if k in add},
                                         "packed_dim16m": {k: big[k] for k in keep if k in big},
-                                        "packed26": {k: c4[k] for k in keep if k in c4}}
+                                        "packed26": {k: c4[k] for k in keep if k in c4},
+                                        "packed_pss728": {k: pss[k] for k in keep if k in pss}}
     if env.world > 1 and not args.no_additional and args.workload == "packed":
         # The two BASELINE configurations that are DEFINED on several GPUs, sharded over the ranks that
         # are here: config 4 = 1,000,000 participants of packed Shamir t=2 k=8 n=26; config 5 = 100,000 participants at
