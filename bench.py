@@ -10,8 +10,9 @@ prime, 100k participants (the configuration the north-star target is quoted on).
 cover ALL of them: a step = 100000 / K participants, issued as resident sub-tiles of <= 2500
 (50 steps x 2000; 20 steps x 2 x 2500); `config.workload` is derived from what was processed and
 `config.inputs` says what was shared (default: one resident tile replayed; --inputs distinct: 100k different
-participants).  `--workload additive` = config 2 (configs[1]); at N=1 a short run of it and of config 5's
-dimension are attached to the JSON line as `additional_workloads`.
+participants).  `--workload additive` = config 2 (configs[1]); at N=1 short runs of it, of config 5's dimension (with
+the reveal), of config 4's shape and of tss's PSS_155_728_100 (transform kernel) are attached to the JSON line as
+`additional_workloads`.
 
 N > 1: one process per GPU (torchrun), participants sharded across ranks, no collective on the data path,
 ONE modular reduce of the partial clerk sums over RCCL at the end of the timed region - the library's own
