@@ -219,6 +219,11 @@ class Env:
             device_index = int(os.environ["SDA_BENCH_DEVICE"])
         else:
             device_index = 0 if share in ("1", "try") else self.local_rank
+        if device_index >= torch.cuda.device_count():
+            # --gpus N on a box with fewer devices: nothing this run could print would be the N-GPU measurement
+            print(f"[bench] rank {self.rank}: device {device_index} does not exist ({torch.cuda.device_count()} visible); FATAL - "
+                  f"set SDA_SHARE_GPU=1 only to rehearse the N > 1 path on a one-GPU box", file=sys.stderr, flush=True)
+            os._exit(3)
         torch.cuda.set_device(device_index)
         self.dev = torch.device("cuda", device_index)
         self.use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run
@@ -407,7 +412,12 @@ def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, s
     return {
         "metric": "share-gen + clerk-sum elements/sec (mod q)", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak",
+        "scaling_note": "WEAK: every GPU processes the whole per-GPU workload named in config.workload (BASELINE config 3: 100,000 "
+                        "participants PER GPU unless --participants says otherwise), so `value` grows with N at fixed time; the "
+                        "legs under additional_workloads at N > 1 (BASELINE configs 4 and 5) are STRONG-scaled instead: their "
+                        "job is fixed and its participants are divided over the N ranks (each leg says so in its own `scaling`)",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": describe(w, dim, participants_total, world), "baseline_config": w["desc"], "name": name,
                    "dim": dim, "participants_total": participants_total, "participants_per_step_per_gpu": n_sub * P,
                    "sub_tiles_per_step": n_sub, "tile_participants": P,
@@ -434,17 +444,26 @@ def _profiles_json(fname):
 
 
 def _traffic(name, P, dim, key):
-    """PMC HBM bytes per launch (profiles/traffic.json: tools/make_traffic.py over the current round's rocprofv3 --pmc
-    passes, measured at one tile size per workload; bytes scale with the tile)"""
-    for kk, v in _profiles_json("traffic.json").items():
-        parts = kk.split(":")
-        if len(parts) == 3 and parts[0] == name and parts[2] == f"dim{dim}":
-            scale = P / int(parts[1][4:])
-            if key in v:
-                return v[key] * scale
-            if key == "fused_bytes_per_launch" and "gen_bytes_per_launch" in v and "comb_bytes_per_launch" in v:
-                return (v["gen_bytes_per_launch"] + v["comb_bytes_per_launch"]) * scale      # two launches per call
+    """PMC HBM bytes per launch - a MEASUREMENT of exactly this (workload, tile, dimension) or None.  profiles/traffic.json is
+    written by tools/make_traffic.py from the round's rocprofv3 --pmc passes (FETCH_SIZE doubled as the microarchitecture
+    guide prescribes, WRITE_SIZE as reported), one entry per profiled (workload, tile, dim); a run at any other tile gets
+    `traffic: null` rather than a scaled figure (round 3 scaled; a changed default tile would then have extrapolated silently)."""
+    v = _profiles_json("traffic.json").get(f"{name}:tile{P}:dim{dim}")
+    if not v:
+        return None
+    if key in v:
+        return v[key]
+    if key == "fused_bytes_per_launch" and "gen_bytes_per_launch" in v and "comb_bytes_per_launch" in v:
+        return v["gen_bytes_per_launch"] + v["comb_bytes_per_launch"]                      # two launches per call
     return None
+
+
+def _traffic_note(name, P, dim, got):
+    if got is not None:
+        return f"measured: profiles/traffic.json[{name}:tile{P}:dim{dim}] (rocprofv3 --pmc passes of this command form)"
+    have = sorted(k for k in _profiles_json("traffic.json") if k.startswith(name + ":"))
+    return (f"null: no counter pass was taken at tile {P}, dim {dim} for this workload "
+            f"(profiled: {', '.join(have) if have else 'none'}); not extrapolated")
 
 
 # which ceiling is active when no counter evidence has been collected for a workload (profiles/bounds.json missing)
@@ -597,6 +616,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
                        "note": "one launch = share-gen of a tile (8 + 8n/k B/element) + clerk-sum of the previous tile "
                                "(8n/k B/element); K tiles take K+1 launches (the first only generates, the last only "
                                "sums), achieved = K x algorithmic_bytes_per_launch / sum of the K+1 launch durations"}
+    res["roofline"]["traffic_note"] = _traffic_note(name, P, dim, res["roofline"]["traffic"])
     res["roofline"].update(_bound(name, "fused", res["roofline"]))
     res["verified_reconstruct_equals_sum"] = verified
     res["verified_against"] = ("column sums of all %d distinct participants" % (world * tiles * P) if distinct else
@@ -708,6 +728,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
                        "traffic": _traffic(name, P, dim, "gen_bytes_per_launch" if dominant_gen else "comb_bytes_per_launch"),
                        "algorithmic_bytes_per_launch": per_launch * (gen_b if dominant_gen else comb_b),
                        "avg_launch_ms": gen_ms if dominant_gen else comb_ms}
+    res["roofline"]["traffic_note"] = _traffic_note(name, P, dim, res["roofline"]["traffic"])
     res["roofline"].update(_bound(name, "serial_gen" if dominant_gen else "serial_comb", res["roofline"]))
     res["kernels"] = {"share_gen": {"avg_ms": gen_ms, "bytes_per_element": gen_b, "GBps": gen_gbs,
                                     "frac_of_hbm_peak": gen_gbs / HBM_PEAK_GBS},
@@ -720,6 +741,49 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     del secrets, shares, sums, total
     torch.cuda.empty_cache()
     return res
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here - the same script, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them, stdout inherited (only rank 0 writes to it:
+    the ONE JSON line) - wait for all of them and return the WORST exit code (so a refused communicator stays exit code 3).
+    A rank that dies takes the others with it after a grace period instead of leaving them in a collective."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")) for r in range(n)]
+
+    def stop(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    signal.signal(signal.SIGTERM, stop)
+    first_bad, failed_at, stopped = 0, None, False
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            if not first_bad:
+                bad = [c for c in (p.poll() for p in procs) if c not in (None, 0)]
+                if bad:
+                    first_bad = 128 - bad[0] if bad[0] < 0 else bad[0]   # the rank that failed FIRST is the cause
+                    failed_at = time.monotonic()
+            if failed_at is not None and not stopped and time.monotonic() - failed_at > 15.0:
+                stop()                                   # the survivors wait for a rank that will never come
+                stopped = True
+    except KeyboardInterrupt:
+        stop()
+        raise
+    codes = [p.wait() for p in procs]
+    if first_bad:
+        return first_bad
+    return max([128 - c if c < 0 else c for c in codes] + [0])
 
 
 def main():
@@ -751,16 +815,23 @@ def main():
                     help="replay: one resident tile re-shared by every sub-tile (inputs resident before timing); distinct: "
                          "every sub-tile shares different participants, generated on a side stream inside the timed region")
     ap.add_argument("--leg-participants", type=int, default=0,
-                    help="N > 1 legs: participants of the WHOLE job over all ranks (default: the BASELINE configuration's: "
-                         "1,000,000 for config 4, 100,000 for config 5); rehearsals pass something small")
-    ap.add_argument("--leg-dim", type=int, default=0, help="N > 1 legs: vector dimension (default: the configuration's)")
+                    help="config 4 / config 5 legs (N = 1: full job on one GPU; N > 1: job sharded over the ranks): participants "
+                         "of the WHOLE job (default: the BASELINE configuration's: 1,000,000 for config 4, 100,000 for "
+                         "config 5); rehearsals pass something small")
+    ap.add_argument("--leg-dim", type=int, default=0, help="config 4 / config 5 legs: vector dimension (default: the configuration's)")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("--steps must be >= 1 and --warmup >= 0")
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: become the launcher of its own N ranks (one process per GPU); the ranks
+        # are this same script with the environment torch.distributed.run would give them
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: one rank per GPU")
     # stdout carries ONE JSON line and nothing else: gloo and RCCL print banners to the C stdout of every rank, so the
     # process's fd 1 points at stderr for the whole run and the line is written to the real stdout at the very end
     sys.stdout.flush()
@@ -785,18 +856,23 @@ def main():
     if env.world == 1 and not args.no_additional and args.workload == "packed":
         # BASELINE config 2 (additive 3-way, 10k participants = 5 steps of 2000)
         add = run("additive", 5, 2)
-        # BASELINE config 5's shape on one GPU (dim 16,777,216; 4 steps of 125 participants) - carries the reveal time
-        # at that dimension
-        big = run("packed_dim16m", 4, 1, participants=500)
-        # BASELINE config 4's shape on one GPU (t=2 k=8 n=26; 4 steps of 1500 of its 1,000,000 participants; the sharded job
-        # itself is a leg of the N > 1 run)
-        c4 = run("packed26", 4, 1, participants=6000, tile=1500)
+        # BASELINE configs 4 and 5 at their FULL job size on this one GPU (they are defined on 8 GPUs; with one GPU they are
+        # "the largest single-GPU configuration" and fit by streaming resident tiles): config 4 = 1,000,000 participants of
+        # t=2 k=8 n=26 as 800 tiles of 1250 (~15 s); config 5 = 100,000 participants at dim 16,777,216 as 800 tiles of 125,
+        # Lagrange reveal over the 16 Mi secrets included (~16 s).  --leg-participants / --leg-dim shrink them (tests).
+        job4 = args.leg_participants or 1_000_000
+        job5 = args.leg_participants or 100_000
+        c4 = run("packed26", 10, 1, participants=job4, dim=args.leg_dim or 0, tile=1250)
+        c4["config"]["job"] = f"BASELINE config 4 at full job size on ONE GPU: {job4} participants, streamed as resident tiles"
+        big = run("packed_dim16m", 10, 1, participants=job5, dim=args.leg_dim or 0, tile=125)
+        big["config"]["job"] = (f"BASELINE config 5 at full job size on ONE GPU: {job5} participants at dim "
+                                f"{big['config']['dim']}, Lagrange reveal included (reveal.ms)")
         # tss's own shipped parameter set PSS_155_728_100 (k=100 t=155 n=728) through the transform kernel, clerk sum on the
         # side stream (4 steps of 500 participants)
         pss = run("packed_pss728", 4, 1, participants=2000)
         line["additional_workloads"] = {"additive": {k: add[k] for k in keep if k in add},
-                                        "packed_dim16m": {k: big[k] for k in keep if k in big},
-                                        "packed26": {k: c4[k] for k in keep if k in c4},
+                                        "config4_full": {k: c4[k] for k in keep if k in c4},
+                                        "config5_full": {k: big[k] for k in keep if k in big},
                                         "packed_pss728": {k: pss[k] for k in keep if k in pss}}
     if env.world > 1 and not args.no_additional and args.workload == "packed":
         # The two BASELINE configurations that are DEFINED on several GPUs, sharded over the ranks that
@@ -816,10 +892,10 @@ def main():
             legs["config4_packed26" if leg == "packed26" else "config5_packed_dim16m"] = {k: r[k] for k in keep + ("scaling",) if k in r}
         line["additional_workloads"] = legs
     if env.rank == 0:
-        if not args.no_cpu_baseline and env.world == 1:
-            line["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.dim or WORKLOADS[args.workload].get("dim", 1 << 20))
-        else:
-            line["cpu_baseline"] = None
+        # rank 0's host cores, at any world size (the other ranks wait at the closing barrier): the reference's CPU path
+        # timed beside the GPU figure on the same box
+        line["cpu_baseline"] = (None if args.no_cpu_baseline else
+                                cpu_baseline(WORKLOADS[args.workload], args.dim or WORKLOADS[args.workload].get("dim", 1 << 20)))
     # tear the communicator down with the C stdout pointed at stderr (RCCL may print there), so that the JSON line is
     # the one and LAST thing on stdout
     sys.stdout.flush()

@@ -40,6 +40,7 @@ struct L31Params {
     int32_t  p1;      // p >> 31
     uint32_t pinvB;   // -p^{-1} mod 2^31
     uint32_t pad;
+    uint64_t np, np2; // 2^64 - p and 2^64 - 2p: x + np wraps exactly when x >= p (the conditional subtractions)
 };
 
 // strides in elements
@@ -49,6 +50,11 @@ struct GenLayout {
     int64_t* out;             size_t out_stride_participant; size_t out_stride_clerk;
     size_t participants;      size_t len;             // secrets per participant
     uint64_t first_participant;                       // DRBG stream id of participant 0
+    // packed Shamir with the device CSPRNG (rand == nullptr), "systematic" share map: output rows 0 .. direct_rows-1 ARE
+    // the t draws of each batch (direct_rows = t) and the matrix the kernel is handed has the other n - direct_rows rows
+    // (the polynomial through (1, 0), the secrets at omega_secrets^1..k and the draws at omega_shares^1..t).  0: every
+    // row is a dot product with the n-row tss matrix (draws are the values at omega_secrets^(k+1..k+t)).
+    uint32_t direct_rows;
 };
 
 // ---- share generation ---------------------------------------------------------------------------

@@ -468,8 +468,12 @@ struct sda_share_generator {
     uint32_t n = 0, k = 1, t = 0;        // shares, secrets per batch, random draws per batch
     ModParams mod;
     MontParams mont{0, 0};
-    std::vector<uint64_t> Mmont;         // n x (k+t), Montgomery form
+    std::vector<uint64_t> Mmont;         // n x (k+t), Montgomery form: tss's share map (draws = values at omega_secrets^(k+1..k+t))
+    std::vector<uint64_t> Msys;          // (n-t) x (k+t), Montgomery form: the systematic share map (draws = shares 0..t-1)
+    bool sys_default = false;            // the device CSPRNG's draws are shares 0..t-1 (every matrix-form kernel; not the transform)
+    bool sys = false;                    // ... and the handle has not been switched back (sda_share_generator_set_csprng_share_map)
     MatArg* matarg = nullptr;            // fast path (kernarg copy)
+    MatArg* matarg_sys = nullptr;        // the same for Msys
     bool fast = false;
     bool l31 = false;                    // balanced-31-bit-limb kernel, matrix in the kernarg segment
     bool l31g = false;                   // the same with run-time (k, t) and the matrix in global memory (d_M)
@@ -480,7 +484,7 @@ struct sda_share_generator {
     L31Params lp{};
     Drbg drbg;
     Ctx ctx;
-    DevBuf d_M, d_secrets, d_rand, d_out;
+    DevBuf d_M, d_Msys, d_secrets, d_rand, d_out;
     // generate_combine_dev for shapes without a dual-role kernel: the clerk sum of the previous tile runs on this side stream
     // beside the share generation (fork / join with events), created on first use
     bool rust_signed = false;            // SDA_VALUES_RUST_SIGNED (additive only): additive.rs:42-47 with Rust's own `%`
@@ -517,6 +521,24 @@ static int build_packed_share_matrix(const sda_sharing_scheme_t& s, uint64_t p, 
     return SDA_OK;
 }
 
+// The systematic share map of the device CSPRNG (include/sda_hip.h, "CSPRNG share map"): the same polynomial family - degree
+// <= t + k, f(1) = 0, f(w2^i) = secret_i - parametrised by its values at the first t SHARE points instead of tss's t extra
+// nodes w2^(k+1..k+t): shares 0..t-1 are the draws themselves, and this (n - t) x (k + t) matrix gives the other shares from
+// [secrets ; draws].  For fixed secrets both parametrisations are bijections onto the same t-dimensional family (t + k + 1
+// distinct points fix a polynomial of degree <= t + k), so uniform draws give the same joint distribution of shares as tss's
+// construction (packed_shamir.rs:42).  Unavailable (returns false, no error) when a share point collides with a node.
+static bool build_systematic_share_matrix(const sda_sharing_scheme_t& s, uint64_t p, std::vector<uint64_t>& out) {
+    const uint64_t k = s.secret_count, t = s.privacy_threshold, n = s.share_count;
+    if (t == 0 || n < t) return false;
+    const uint64_t w2 = h_canon(s.omega_secrets, p), w3 = h_canon(s.omega_shares, p);
+    std::vector<uint64_t> nodes(k + t + 1), evals(n - t);
+    for (uint64_t e = 0; e <= k; ++e) nodes[e] = h_powmod(w2, e, p);
+    for (uint64_t j = 0; j < t; ++j) nodes[k + 1 + j] = h_powmod(w3, j + 1, p);
+    for (uint64_t j = t; j < n; ++j) evals[j - t] = h_powmod(w3, j + 1, p);
+    if (!h_all_distinct(nodes)) return false;
+    return h_lagrange_matrix_mont(nodes, evals, 0, p, out);
+}
+
 // The scheme descriptor travels over the network in the reference protocol (Aggregation resource): every field is
 // bounded on its own BEFORE any sum is formed, so no u64 wrap-around can slip through.
 static int validate_packed(const sda_sharing_scheme_t& s) {
@@ -537,18 +559,12 @@ static int validate_packed(const sda_sharing_scheme_t& s) {
 
 // Constants of the balanced-limb kernel: matrix entries in Montgomery form with R = 2^62, centred to
 // (-p/2, p/2] and split into balanced limbs m1 * 2^31 + m0, m0 in [-2^30, 2^30).
-static int build_l31(sda_share_generator* g) {
-    const uint64_t p = g->mod.m;
+static void l31_pack_matrix(const std::vector<uint64_t>& Mm, uint64_t p, std::vector<uint64_t>& packed) {
     const uint64_t B = 1ull << 31;
-    uint64_t inv;
-    if (!h_invmod(p % B, B, inv)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not invertible mod 2^31");
-    g->lp.p = p; g->lp.p2 = 2 * p; g->lp.h = (p + 1) / 2;
-    g->lp.p0 = (int32_t)(p % B); g->lp.p1 = (int32_t)(p >> 31);
-    g->lp.pinvB = (uint32_t)((B - inv) % B); g->lp.pad = 0;
-    std::vector<uint64_t> packed(g->Mmont.size() + 3, 0);               // three zero entries past the end (see l31_dot_rt)
-    const uint64_t r64_inv_to_r62 = h_powmod(4 % p, p - 2, p);          // Mmont holds M * 2^64: divide by 4
-    for (size_t i = 0; i < g->Mmont.size(); ++i) {
-        const uint64_t mr = h_mulmod(g->Mmont[i], r64_inv_to_r62, p);   // M * 2^62 mod p
+    packed.assign(Mm.size() + 3, 0);                                    // three zero entries past the end (see l31_dot_rt)
+    const uint64_t r64_inv_to_r62 = h_powmod(4 % p, p - 2, p);          // Mm holds M * 2^64: divide by 4
+    for (size_t i = 0; i < Mm.size(); ++i) {
+        const uint64_t mr = h_mulmod(Mm[i], r64_inv_to_r62, p);         // M * 2^62 mod p
         __int128 c = mr > (p - 1) / 2 ? (__int128)mr - (__int128)p : (__int128)mr;
         int64_t c64 = (int64_t)c;
         int64_t m0 = (int64_t)(((uint64_t)c64 & (B - 1)));
@@ -556,15 +572,30 @@ static int build_l31(sda_share_generator* g) {
         const int64_t m1 = (c64 - m0) / (int64_t)B;
         packed[i] = (uint64_t)(uint32_t)(int32_t)m0 | ((uint64_t)(uint32_t)(int32_t)m1 << 32);
     }
+}
+
+static int l31_params(uint64_t p, L31Params& lp);
+
+// one matrix in the form the limb-31 kernels take: the kernarg copy (compiled / run-time (k, t) kernels) or device memory
+static int l31_place_matrix(sda_share_generator* g, const std::vector<uint64_t>& Mm, MatArg*& arg, DevBuf& dev) {
+    std::vector<uint64_t> packed;
+    l31_pack_matrix(Mm, g->mod.m, packed);
     if (g->l31g) {                                                      // matrix in global memory
-        SDA_TRY(g->d_M.reserve(packed.size() * 8));
-        HIP_TRY(hipMemcpy(g->d_M.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
+        SDA_TRY(dev.reserve(packed.size() * 8));
+        HIP_TRY(hipMemcpy(dev.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
         return SDA_OK;
     }
-    g->matarg = new (std::nothrow) MatArg();
-    if (!g->matarg) return fail(SDA_ERR_ALLOC, "out of memory");
-    memset(g->matarg, 0, sizeof(MatArg));
-    memcpy(g->matarg->e, packed.data(), g->Mmont.size() * 8);
+    arg = new (std::nothrow) MatArg();
+    if (!arg) return fail(SDA_ERR_ALLOC, "out of memory");
+    memset(arg, 0, sizeof(MatArg));
+    memcpy(arg->e, packed.data(), Mm.size() * 8);
+    return SDA_OK;
+}
+
+static int build_l31(sda_share_generator* g) {
+    SDA_TRY(l31_params(g->mod.m, g->lp));
+    SDA_TRY(l31_place_matrix(g, g->Mmont, g->matarg, g->d_M));
+    if (g->sys_default) SDA_TRY(l31_place_matrix(g, g->Msys, g->matarg_sys, g->d_Msys));
     return SDA_OK;
 }
 
@@ -576,6 +607,7 @@ static int l31_params(uint64_t p, L31Params& lp) {
     lp.p = p; lp.p2 = 2 * p; lp.h = (p + 1) / 2;
     lp.p0 = (int32_t)(p % B); lp.p1 = (int32_t)(p >> 31);
     lp.pinvB = (uint32_t)((B - inv) % B); lp.pad = 0;
+    lp.np = (uint64_t)0 - p; lp.np2 = (uint64_t)0 - 2 * p;
     return SDA_OK;
 }
 
@@ -622,18 +654,24 @@ static void shoup_pair(uint64_t w, uint64_t p, uint64_t& out_w, uint64_t& out_s)
 
 // the limb-GEMM kernel's constants: centred Montgomery-form (R = 2^64) entries in balanced base-256 digits (the kernel cuts its
 // Toeplitz rows out of them), [n][8 * ceil((k + t) / 8)] zero padded
-static int build_mfma(sda_share_generator* g) {
+static int mfma_place_matrix(sda_share_generator* g, const std::vector<uint64_t>& Mm, DevBuf& dev) {
     const uint32_t kt = g->k + g->t, width = 8 * ((kt + 7) / 8);
-    std::vector<uint64_t> tab((size_t)g->n * width, 0);
-    for (uint32_t j = 0; j < g->n; ++j)
+    const size_t rows = Mm.size() / kt;
+    std::vector<uint64_t> tab(rows * width, 0);
+    for (size_t j = 0; j < rows; ++j)
         for (uint32_t i = 0; i < kt; ++i) {
-            uint64_t m = g->Mmont[(size_t)j * kt + i];
+            uint64_t m = Mm[j * kt + i];
             if (m > (g->mod.m >> 1)) m -= g->mod.m;                          // centred representative, two's complement
             const uint64_t bal = (m + 0x8080808080808080ull) ^ 0x8080808080808080ull;
-            tab[(size_t)j * width + i] = bal;
+            tab[j * width + i] = bal;
         }
-    SDA_TRY(g->d_M.reserve(tab.size() * 8));
-    HIP_TRY(hipMemcpy(g->d_M.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    SDA_TRY(dev.reserve(tab.size() * 8 + 8));
+    HIP_TRY(hipMemcpy(dev.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    return SDA_OK;
+}
+static int build_mfma(sda_share_generator* g) {
+    SDA_TRY(mfma_place_matrix(g, g->Mmont, g->d_M));
+    if (g->sys_default) SDA_TRY(mfma_place_matrix(g, g->Msys, g->d_Msys));
     return SDA_OK;
 }
 
@@ -709,21 +747,36 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
             // the limb GEMM on the matrix cores: measured ahead of the limb-31 kernel from k + t = 15 with n = 26 (+12 %),
             // behind it for k + t = 10 and below (SDA_FORCE_MFMA=1 takes it for every compiled shape, SDA_NO_MFMA=1 never)
             g->mfma = true; g->l31 = g->l31g = g->fast = false;
+            g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
             st = build_mfma(g);
         } else if (g->l31 || g->l31g) {
+            g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
             st = build_l31(g);
         } else if (g->fast) {
+            g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
             g->matarg = new (std::nothrow) MatArg();
-            if (!g->matarg) st = fail(SDA_ERR_ALLOC, "out of memory");
+            if (g->sys_default) g->matarg_sys = new (std::nothrow) MatArg();
+            if (!g->matarg || (g->sys_default && !g->matarg_sys)) st = fail(SDA_ERR_ALLOC, "out of memory");
             else {
                 memset(g->matarg, 0, sizeof(MatArg));
                 memcpy(g->matarg->e, g->Mmont.data(), g->Mmont.size() * 8);
+                if (g->sys_default) {
+                    memset(g->matarg_sys, 0, sizeof(MatArg));
+                    memcpy(g->matarg_sys->e, g->Msys.data(), g->Msys.size() * 8);
+                }
             }
         } else {
+            g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
             st = g->d_M.reserve(g->Mmont.size() * 8);
             if (st == SDA_OK && hipMemcpy(g->d_M.p, g->Mmont.data(), g->Mmont.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
                 st = fail(SDA_ERR_HIP, "uploading the share matrix failed");
+            if (st == SDA_OK && g->sys_default) {
+                st = g->d_Msys.reserve(g->Msys.size() * 8 + 8);
+                if (st == SDA_OK && hipMemcpy(g->d_Msys.p, g->Msys.data(), g->Msys.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+                    st = fail(SDA_ERR_HIP, "uploading the systematic share matrix failed");
+            }
         }
+        g->sys = g->sys_default;
     }
     if (st != SDA_OK) { sda_share_generator_free(g); return st; }
     *out = g;
@@ -733,13 +786,14 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
 extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
     if (!g) return;
     if (g->ctx.device >= 0) (void)hipSetDevice(g->ctx.device);
-    g->d_M.release(); g->d_fft.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
+    g->d_M.release(); g->d_Msys.release(); g->d_fft.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
     if (g->aux) { (void)hipStreamSynchronize(g->aux); (void)hipStreamDestroy(g->aux); }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     g->ctx.destroy();
     g->drbg.wipe();
     delete g->matarg;
+    delete g->matarg_sys;
     delete g;
 }
 
@@ -781,6 +835,19 @@ extern "C" int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int
     return g->drbg.set_rounds(rounds);
 }
 
+extern "C" int sda_share_generator_csprng_share_map(const sda_share_generator_t* g) {
+    return g && g->sys ? SDA_SHARE_MAP_SYSTEMATIC : SDA_SHARE_MAP_TSS_NODES;
+}
+extern "C" int sda_share_generator_set_csprng_share_map(sda_share_generator_t* g, int map) {
+    if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "generator is NULL");
+    if (map != SDA_SHARE_MAP_TSS_NODES && map != SDA_SHARE_MAP_SYSTEMATIC) return fail(SDA_ERR_INVALID_ARGUMENT, "unknown share map %d", map);
+    if (map == SDA_SHARE_MAP_SYSTEMATIC && !g->sys_default)
+        return fail(SDA_ERR_UNSUPPORTED, "the systematic share map exists for packed Shamir with privacy_threshold > 0 on the "
+                                         "matrix-form kernels (not the transform kernel, not additive sharing)");
+    g->sys = map == SDA_SHARE_MAP_SYSTEMATIC;
+    return SDA_OK;
+}
+
 // one call of the generator under the CSPRNG key `key` (the call key, or the stream key in deterministic mode)
 static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, const int64_t* d_secrets,
                                size_t participants, size_t len, size_t secrets_stride,
@@ -798,6 +865,9 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
     L.rand = d_rand; L.rand_stride = rand_stride;
     L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
     L.participants = participants; L.len = len; L.first_participant = first_participant;
+    // the device CSPRNG's draws are shares 0..t-1 themselves (systematic share map); injected randomness keeps tss's map
+    const bool sys = !d_rand && !g->additive && g->sys && g->t > 0;
+    L.direct_rows = sys ? g->t : 0;
     if (g->additive && g->rust_signed) {
         // the reference's representatives: shares 0..n-2 are the draws themselves, the last one the fold of (acc - r) % q.
         // Draws that are not injected are materialised first - the same sda-drbg-v1 values the canonical kernel would use
@@ -818,15 +888,15 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
         return SDA_OK;
     }
     if (g->l31) {
-        HIP_TRY(launch_packed_generate_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, key, g->drbg.rounds, s));
+        HIP_TRY(launch_packed_generate_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds, s));
         return SDA_OK;
     }
     if (g->fast) {
-        HIP_TRY(launch_packed_generate(L, g->n, g->k, g->t, g->mod, g->mont, *g->matarg, key, g->drbg.rounds, s));
+        HIP_TRY(launch_packed_generate(L, g->n, g->k, g->t, g->mod, g->mont, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds, s));
         return SDA_OK;
     }
     if (g->l31g) {
-        HIP_TRY(launch_packed_generate_l31_global(L, g->n, g->k, g->t, g->mod, g->lp, g->d_M.as<uint64_t>(), key,
+        HIP_TRY(launch_packed_generate_l31_global(L, g->n, g->k, g->t, g->mod, g->lp, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key,
                                                   g->drbg.rounds, s));
         return SDA_OK;
     }
@@ -835,7 +905,8 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
         return SDA_OK;
     }
     if (g->mfma) {
-        HIP_TRY(launch_packed_generate_mfma(L, g->n, g->k, g->t, g->mod, g->mont, g->d_M.as<uint64_t>(), key, g->drbg.rounds, s));
+        HIP_TRY(launch_packed_generate_mfma(L, g->n, g->k, g->t, g->mod, g->mont, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key,
+                                            g->drbg.rounds, s));
         return SDA_OK;
     }
     // any-shape path: materialise the CSPRNG draws first (identical values to the fused path)
@@ -848,7 +919,7 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
         L.rand = g->d_rand.as<int64_t>();
         L.rand_stride = rstride;
     }
-    HIP_TRY(launch_packed_generate_generic(L, g->n, g->k, g->t, g->mod, g->mont, g->d_M.as<uint64_t>(), s));
+    HIP_TRY(launch_packed_generate_generic(L, g->n, g->k, g->t, g->mod, g->mont, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), s));
     return SDA_OK;
 }
 
@@ -1003,6 +1074,8 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     L.secrets = d_secrets; L.secrets_stride = secrets_stride; L.rand = nullptr; L.rand_stride = 0;
     L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
     L.participants = len ? participants : 0; L.len = len; L.first_participant = first_participant;
+    const bool sys = !g->additive && g->sys && g->t > 0;                      // the dual-role launch always draws on the device
+    L.direct_rows = sys ? g->t : 0;
     if (L.participants) SDA_TRY(check_streams(first_participant, participants));
     DrbgKey key = g->drbg.call_key();
     bool fused = false;
@@ -1011,11 +1084,11 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
         he = launch_fused_additive(L, g->n, g->mod, key, g->drbg.rounds, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(),
                                    d_prev, prev_participants, c->jobs, c->dimension, s, &fused);
     } else if (g->l31) {
-        he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, *g->matarg, key, g->drbg.rounds,
+        he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds,
                                      c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
                                      c->dimension, s, &fused);
     } else if (g->mfma) {
-        he = launch_fused_packed_mfma(L, g->n, g->k, g->t, g->mod, g->mont, g->d_M.as<uint64_t>(), key, g->drbg.rounds,
+        he = launch_fused_packed_mfma(L, g->n, g->k, g->t, g->mod, g->mont, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key, g->drbg.rounds,
                                       c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
                                       c->dimension, s, &fused);
     }

@@ -110,6 +110,16 @@ __device__ __forceinline__ void store2(int64_t* p, uint64_t a, uint64_t b) {
     __builtin_nontemporal_store(v, reinterpret_cast<ll2*>(p));   // shares are written once, read much later
 }
 
+// one lane's two adjacent batches of a clerk row
+template <bool VEC>
+__device__ __forceinline__ void store_pair(int64_t* o, uint64_t a, uint64_t b, bool in0, bool in1) {
+    if (VEC && in1) store2(o, a, b);
+    else {
+        if (in0) o[0] = (int64_t)a;
+        if (in1) o[1] = (int64_t)b;
+    }
+}
+
 // work item -> (participant, chunk)
 __device__ __forceinline__ void split_item(uint64_t item, uint64_t chunks, uint64_t& p, uint64_t& chunk) {
     p = item / chunks;
@@ -243,16 +253,16 @@ __global__ __launch_bounds__(kThreads) void packed_gen_kernel(GenLayout L, uint3
     }
 
     int64_t* op = L.out + p * L.out_stride_participant + b0;
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint64_t* row = &M.e[(size_t)j * KT];
+    const uint32_t direct = L.rand ? 0u : L.direct_rows;                     // 0 or T (systematic share map)
+    if (direct) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) store_pair<VEC>(op + (size_t)i * L.out_stride_clerk, v0[K + i], v1[K + i], in0, in1);
+    }
+    for (uint32_t j = direct; j < n; ++j) {
+        const uint64_t* row = &M.e[(size_t)(j - direct) * KT];
         const uint64_t a = mont_dot<KT>(row, v0, mont.p, mont.pinv);
         const uint64_t b = mont_dot<KT>(row, v1, mont.p, mont.pinv);
-        int64_t* o = op + (size_t)j * L.out_stride_clerk;
-        if (VEC && in1) store2(o, a, b);
-        else {
-            if (in0) o[0] = (int64_t)a;
-            if (in1) o[1] = (int64_t)b;
-        }
+        store_pair<VEC>(op + (size_t)j * L.out_stride_clerk, a, b, in0, in1);
     }
 }
 
@@ -353,9 +363,13 @@ __device__ __forceinline__ int64_t l31_group5(const uint64_t* __restrict__ row, 
     return mad_sv(P.p1, q1, C2) + (C1a >> 31) + (C1b >> 31) + ((E + (int64_t)(uint64_t)lows) >> 31);
 }
 
-// x in [0, 4p) -> [0, 2p)
-// (a borrow-based select was measured 2 % slower than hipcc's compare + select form)
-__device__ __forceinline__ uint64_t condsub(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
+// x in [0, 2m) -> [0, m) given neg_m = 2^64 - m: y = x - m wraps (y > x) exactly when x < m.  One 64-bit add, one compare
+// and the select - four VALU instructions; the `x >= m ? x - m : x` form costs hipcc seven (it materialises m in VGPRs
+// for a masked subtraction).
+__device__ __forceinline__ uint64_t condsub_neg(uint64_t x, uint64_t neg_m) {
+    const uint64_t y = x + neg_m;
+    return y < x ? y : x;
+}
 
 // sum_i M_i * v_i mod p for any KT: groups of <= 4 terms - or of 5 where that saves a group (KT = 5, 9, 10, 13, 14, 15,
 // ...) - partial results kept lazily in [0, 2p)
@@ -376,11 +390,12 @@ __device__ __forceinline__ uint64_t l31_dot(const uint64_t* __restrict__ row, co
         else if (left == 3) { top = l31_group<3>(row + g, v0 + g, v1 + g, P); used = 3; }
         else if (left == 2) { top = l31_group<2>(row + g, v0 + g, v1 + g, P); used = 2; }
         else { top = l31_group<1>(row + g, v0 + g, v1 + g, P); used = 1; }
-        const uint64_t u = condsub((uint64_t)top + P.p2, P.p2);           // (0.25p, 3.75p) -> [0, 2p)
-        r = grp == 0 ? u : condsub(r + u, P.p2);                          // [0, 2p)
+        const uint64_t lifted = (uint64_t)top + P.p2;                     // top in (-1.75p, 1.75p): wraps exactly when top < 0
+        const uint64_t u = lifted < (uint64_t)top ? lifted : (uint64_t)top;  // [0, 2p)
+        r = grp == 0 ? u : condsub_neg(r + u, P.np2);                     // [0, 2p)
         g += used;
     }
-    return condsub(r, P.p);
+    return condsub_neg(r, P.np);
 }
 
 template <int K, int T, int ROUNDS, bool VEC>
@@ -437,16 +452,16 @@ __device__ __forceinline__ void packed_gen_l31_body(const GenLayout& L, uint32_t
     }
 
     int64_t* op = L.out + p * L.out_stride_participant + b0;
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint64_t* row = &M.e[(size_t)j * KT];
+    const uint32_t direct = L.rand ? 0u : L.direct_rows;                     // 0 or T (systematic share map)
+    if (direct) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) store_pair<VEC>(op + (size_t)i * L.out_stride_clerk, s0[K + i], s1[K + i], in0, in1);
+    }
+    for (uint32_t j = direct; j < n; ++j) {
+        const uint64_t* row = &M.e[(size_t)(j - direct) * KT];
         const uint64_t a = l31_dot<KT>(row, a0, a1, lp);
         const uint64_t b = l31_dot<KT>(row, c0, c1, lp);
-        int64_t* o = op + (size_t)j * L.out_stride_clerk;
-        if (VEC && in1) store2(o, a, b);
-        else {
-            if (in0) o[0] = (int64_t)a;
-            if (in1) o[1] = (int64_t)b;
-        }
+        store_pair<VEC>(op + (size_t)j * L.out_stride_clerk, a, b, in0, in1);
     }
 }
 
@@ -600,7 +615,9 @@ __device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_
     split_item(item, chunks, p, chunk);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, col = lane & 15u, g = lane >> 4;
     uint32_t* tile = tiles[wave];
-    for (uint32_t i = threadIdx.x; i < n * KS * 8; i += kThreads) mconst[i] = Mbal[i];
+    const uint32_t direct = L.rand ? 0u : L.direct_rows;                     // 0 or t: rows 0..t-1 are the draws (systematic share map)
+    const uint32_t n_mat = n - direct;                                       // rows of the constant table
+    for (uint32_t i = threadIdx.x; i < n_mat * KS * 8; i += kThreads) mconst[i] = Mbal[i];
     for (uint32_t i = lane; i < (uint32_t)(kMfmaWaveBatches * ROWDW); i += 64) tile[i] = 0;       // unused terms stay zero
     __syncthreads();
 
@@ -618,6 +635,8 @@ __device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_
         if (l < 4) sel_lo |= sb << (8 * l); else sel_hi |= sb << (8 * (l - 4));
     }
     const int32_t mul3 = g == 3 ? 0 : (1 << 24);                                                 // column 15 does not exist
+    // 16-byte stores of the direct rows need even strides and an aligned base (b0 and the pair offset are even)
+    const bool pair_vec = ((reinterpret_cast<uintptr_t>(op) & 15u) == 0) && (L.out_stride_clerk % 2 == 0);
 
     for (uint32_t it = 0; it < iters; ++it) {
         const uint64_t b0 = ((chunk * iters + it) * (kThreads / 64) + wave) * kMfmaWaveBatches;   // wave-uniform
@@ -638,6 +657,15 @@ __device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_
                     uint32_t* row = tile + (8 * G + 2 * (lane & 3u)) * ROWDW + 2 * (k + i);
                     *reinterpret_cast<uint64_t*>(row) = balanced_bytes(centred(r0, mod.m));
                     *reinterpret_cast<uint64_t*>(row + ROWDW) = balanced_bytes(centred(r1, mod.m));
+                    if (direct) {                                            // draw i of these two batches IS their share i
+                        const uint64_t bb = b0 + 8 * G + 2 * (lane & 3u);
+                        int64_t* o = op + (size_t)i * L.out_stride_clerk + bb;
+                        if (pair_vec && bb + 1 < batches) store2(o, r0, r1);
+                        else {
+                            if (bb < batches) o[0] = (int64_t)r0;
+                            if (bb + 1 < batches) o[1] = (int64_t)r1;
+                        }
+                    }
                 }
             };
             if constexpr (K != 0) {
@@ -664,13 +692,13 @@ __device__ __forceinline__ void packed_gen_mfma_body(const GenLayout& L, uint32_
         // two accumulator sets in turn: the next clerk's products are issued before this clerk's are consumed, so the matrix
         // cores work under the VALU tail
         v4i dA[4], dB[4];
-        mfma_clerk_products<KS>(dA, mconst, 0, g, sel_lo, sel_hi, bfrag);
-        for (uint32_t j = 0; j < n; j += 2) {
-            if (j + 1 < n) mfma_clerk_products<KS>(dB, mconst, j + 1, g, sel_lo, sel_hi, bfrag);
-            mfma_clerk_finish(dA, mul3, mont, live, orow + (size_t)j * L.out_stride_clerk);
-            if (j + 1 < n) {
-                if (j + 2 < n) mfma_clerk_products<KS>(dA, mconst, j + 2, g, sel_lo, sel_hi, bfrag);
-                mfma_clerk_finish(dB, mul3, mont, live, orow + (size_t)(j + 1) * L.out_stride_clerk);
+        if (n_mat) mfma_clerk_products<KS>(dA, mconst, 0, g, sel_lo, sel_hi, bfrag);
+        for (uint32_t j = 0; j < n_mat; j += 2) {                            // table row j = output row direct + j
+            if (j + 1 < n_mat) mfma_clerk_products<KS>(dB, mconst, j + 1, g, sel_lo, sel_hi, bfrag);
+            mfma_clerk_finish(dA, mul3, mont, live, orow + (size_t)(direct + j) * L.out_stride_clerk);
+            if (j + 1 < n_mat) {
+                if (j + 2 < n_mat) mfma_clerk_products<KS>(dA, mconst, j + 2, g, sel_lo, sel_hi, bfrag);
+                mfma_clerk_finish(dB, mul3, mont, live, orow + (size_t)(direct + j + 1) * L.out_stride_clerk);
             }
         }
     }
@@ -697,11 +725,12 @@ __device__ __forceinline__ uint64_t l31_dot_rt(const uint64_t* __restrict__ row,
     for (int g = 0; g < KTMAX; g += 4) {
         if ((uint32_t)g < kt) {
             const int64_t top = l31_group<4>(row + g, v0 + g, v1 + g, P);
-            const uint64_t u = condsub((uint64_t)top + P.p2, P.p2);
-            r = g == 0 ? u : condsub(r + u, P.p2);
+            const uint64_t lifted = (uint64_t)top + P.p2;
+            const uint64_t u = lifted < (uint64_t)top ? lifted : (uint64_t)top;
+            r = g == 0 ? u : condsub_neg(r + u, P.np2);
         }
     }
-    return condsub(r, P.p);
+    return condsub_neg(r, P.np);
 }
 
 template <int KTMAX, int ROUNDS>
@@ -720,6 +749,8 @@ __device__ __forceinline__ void packed_gen_l31_rt_body(const GenLayout& L, uint3
     const uint64_t e0 = b0 * k;
     const uint64_t stream = L.first_participant + p;
     const QuadCol qc = quad_col(key);
+    int64_t* op = L.out + p * L.out_stride_participant + b0;
+    const uint32_t direct = rp ? 0u : L.direct_rows;                         // 0 or t
     int32_t a0[KTMAX], a1[KTMAX], c0[KTMAX], c1[KTMAX];
 #pragma unroll
     for (int i = 0; i < KTMAX; ++i) {
@@ -734,14 +765,21 @@ __device__ __forceinline__ void packed_gen_l31_rt_body(const GenLayout& L, uint3
                 y = in1 ? canon_i64(rp[(b0 + 1) * t + (i - k)], mod.m, mod.mu) : 0;
             } else {
                 drbg_pair<ROUNDS>(key, qc, stream, pair, t, (uint32_t)i - k, mod, x, y);
+                if (direct) {                                                // systematic share map: draw i - k IS share i - k
+                    int64_t* o = op + (size_t)((uint32_t)i - k) * L.out_stride_clerk;
+                    if (vec && in1) store2(o, x, y);
+                    else {
+                        if (in0) o[0] = (int64_t)x;
+                        if (in1) o[1] = (int64_t)y;
+                    }
+                }
             }
         }
         centre_limbs(x, lp, a0[i], a1[i]);
         centre_limbs(y, lp, c0[i], c1[i]);
     }
-    int64_t* op = L.out + p * L.out_stride_participant + b0;
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint64_t* row = Mrows + (size_t)j * kt;
+    for (uint32_t j = direct; j < n; ++j) {
+        const uint64_t* row = Mrows + (size_t)(j - direct) * kt;
         const uint64_t a = l31_dot_rt<KTMAX>(row, a0, a1, kt, lp);
         const uint64_t b = l31_dot_rt<KTMAX>(row, c0, c1, kt, lp);
         int64_t* o = op + (size_t)j * L.out_stride_clerk;
@@ -782,7 +820,10 @@ __global__ __launch_bounds__(kThreads) void packed_gen_generic_kernel(GenLayout 
     const int64_t* sp = L.secrets + p * L.secrets_stride;
     const int64_t* rp = L.rand + p * L.rand_stride;
     const uint32_t kt = k + t;
-    for (uint32_t j = 0; j < n; ++j) {
+    const uint32_t direct = L.direct_rows;                                   // 0 or t: L.rand then holds the CSPRNG's draws
+    for (uint32_t j = 0; j < direct; ++j)
+        L.out[p * L.out_stride_participant + (size_t)j * L.out_stride_clerk + b] = (int64_t)canon_i64(rp[b * t + j], mod.m, mod.mu);
+    for (uint32_t j = direct; j < n; ++j) {
         U128 acc{0, 0};
         uint32_t since = 0;
         for (uint32_t i = 0; i < kt; ++i) {
@@ -793,7 +834,7 @@ __global__ __launch_bounds__(kThreads) void packed_gen_generic_kernel(GenLayout 
             } else {
                 v = canon_i64(rp[b * t + (i - k)], mod.m, mod.mu);
             }
-            mac128(acc, Mm[(size_t)j * kt + i], v);
+            mac128(acc, Mm[(size_t)(j - direct) * kt + i], v);
             if (++since == 4) { mont_acc_condsub(acc, mont.p); since = 0; }
         }
         mont_acc_condsub(acc, mont.p);

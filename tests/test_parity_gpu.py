@@ -1471,6 +1471,63 @@ def test_bench_multi_gpu_legs_configs_4_and_5(gpu):
     assert c5["reveal"]["dim"] == 98304 and c5["reveal"]["ms"] > 0
 
 
+def test_bench_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with NO launcher around it (the form the driver used for its N = 1 record): the script
+    starts its two ranks itself, stdout is exactly ONE JSON line with n_gpus 2, the `rccl` record, a `roofline` and a
+    non-null `cpu_baseline` (rank 0's host cores, at any world size); the two multi-GPU legs are attached.  Ranks share
+    this box's one GPU (SDA_SHARE_GPU=1).  Without the switch the same command is exit code 3 and prints no line: a
+    one-GPU box cannot produce a two-GPU measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--participants", "120", "--dim", "65536",
+            "--leg-participants", "400", "--leg-dim", "98304"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SDA_SHARE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=900,
+                         env=dict(env, SDA_SHARE_GPU="1"), cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must be the ONE JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified_reconstruct_equals_sum"] is True and line["scaling"] == "weak"
+    assert "WEAK" in line["scaling_note"] and "STRONG" in line["scaling_note"]
+    assert line["rccl"]["unique_devices"] == 1 and line["roofline"]["frac"] > 0
+    assert line["cpu_baseline"] is not None and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1
+    assert set(line["additional_workloads"]) == {"config4_packed26", "config5_packed_dim16m"}
+    for leg in line["additional_workloads"].values():
+        assert leg["verified_reconstruct_equals_sum"] is True and leg["config"]["participants_total"] == 400
+    refused = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=600,
+                             env=env, cwd=root)
+    assert refused.returncode == 3, (refused.returncode, refused.stderr[-1500:])
+    assert "FATAL" in refused.stderr
+    assert not [l for l in refused.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu):
+    """N = 1: BASELINE configs 4 and 5 ride on the default line as `config4_full` / `config5_full` - the whole job on one
+    GPU, streamed as resident tiles, verified against the column sums (here shrunk through --leg-participants / --leg-dim;
+    the driver's run uses 1,000,000 and 100,000 participants)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--participants", "64", "--dim", "65536",
+           "--no-cpu-baseline", "--leg-participants", "300", "--leg-dim", "98304"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    legs = line["additional_workloads"]
+    assert {"config4_full", "config5_full", "additive", "packed_pss728"} <= set(legs)
+    for key, (k, t, n) in (("config4_full", (8, 2, 26)), ("config5_full", (3, 1, 8))):
+        cfg = legs[key]["config"]
+        assert (cfg["secret_count"], cfg["privacy_threshold"], cfg["share_count"]) == (k, t, n)
+        assert cfg["participants_total"] == 300 and cfg["dim"] == 98304 and "full job size on ONE GPU" in cfg["job"]
+        assert legs[key]["verified_reconstruct_equals_sum"] is True
+        assert legs[key]["roofline"]["traffic"] is None and legs[key]["roofline"]["traffic_note"].startswith("null")
+    assert legs["config5_full"]["reveal"]["dim"] == 98304
+
+
 def test_bench_distinct_inputs_mode(gpu):
     """--inputs distinct: every sub-tile shares different participants (tile i+1's secrets generated on a side stream
     while tile i runs); the result is verified against the column sums of ALL of them."""
