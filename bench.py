@@ -232,6 +232,14 @@ class Env:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")                                      # control plane only
         self.lib = capi.load()
+        # A/B runs (tools/*.sh) and the one-rank RCCL test select non-default kernels by environment variable; the release
+        # library reads none, so the bench - a measurement tool - hands them to its test-only entry point (sda_hip_debug.h)
+        for name in ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
+                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES"):
+            if os.environ.get(name):
+                v = os.environ[name]
+                capi.check(self.lib.sda_debug_set_knob(name.encode(), int(v) if v.lstrip("-").isdigit() else 1))
+        self.csprng_share_map = os.environ.get("SDA_BENCH_SHARE_MAP", "")   # "tss": A/B against the round-3 share map
         capi.check(self.lib.sda_set_device(device_index))
         self.comm = C.c_void_p()
         self.exchange = "none (one rank)" if self.world == 1 else "host-staged over gloo (ranks share one GPU)"
@@ -342,10 +350,20 @@ def _setup(env, name, dim, P, row_align, rounds):
     Bs = (B + row_align - 1) // row_align * row_align      # 128-byte aligned rows (row_align = 16 elements)
     gen = crypto.ShareGenerator(scheme)
     gen.set_drbg_key(KEY)                                   # deterministic mode: reproducible run, verified below
+    if env.csprng_share_map == "tss" and w["kind"] == "packed":
+        gen.set_csprng_share_map(gen.SHARE_MAP_TSS_NODES)
     if rounds != 20:
         gen.set_drbg_rounds(rounds)
     comb = crypto.ShareCombiner(scheme)
     return w, n, k, t, scheme, B, Bs, gen, comb
+
+
+def _share_map_name(gen, w):
+    if w["kind"] != "packed":
+        return "n/a (additive sharing: shares 0..n-2 are the draws by definition, additive.rs:42-47)"
+    return ("systematic: the t draws of a batch are its shares 0..t-1, n - t dot products per batch (include/sda_hip.h)"
+            if gen.csprng_share_map() == gen.SHARE_MAP_SYSTEMATIC else
+            "tss nodes: draws are the values at omega_secrets^(k+1..k+t), n dot products per batch")
 
 
 def _expected_sums(env, secrets, P, dim, firsts):
@@ -403,7 +421,7 @@ def _verify(env, scheme, secrets, total, P, dim, B, firsts):
     return verified, reveal
 
 
-def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, schedule):
+def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, schedule, share_map=None):
     world = env.world
     participants_total = world * steps * n_sub * P
     elements = float(participants_total) * dim
@@ -423,6 +441,7 @@ def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, s
                    "sub_tiles_per_step": n_sub, "tile_participants": P,
                    "share_count": n, "secret_count": k, "privacy_threshold": t, "modulus": P62,
                    "randomness": f"on-device ChaCha{rounds} (sda-drbg-v1, deterministic bench key)",
+                   "csprng_share_map": share_map,
                    "row_stride_elements": Bs, "schedule": schedule,
                    "parallelism": f"participants sharded x{world}, one modular reduce of the clerk sums at the end",
                    "exchange": env.exchange},
@@ -601,7 +620,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
                 "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid (shares "
                 "materialised in HBM by one launch, read back by the next); K+1 launches for K tiles" if has_dual else
                 "sda_share_generator_generate_combine_dev without a dual-role kernel for this shape: clerk-sum of tile i-1, then "
-                "share-gen of tile i, two launches per call")
+                "share-gen of tile i, two launches per call", share_map=_share_map_name(gen, w))
     res["config"]["inputs"] = INPUT_MODES[inputs]
     res["config"]["distinct_participants"] = world * tiles * P if distinct else world * P
     res["roofline"] = {"kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -720,7 +739,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
                   "packed_gen_l31_kernel" if w["k"] + w["t"] <= 32 else "packed_gen_fft_kernel")
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
                 "share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares" if overlap
-                else "one stream, serial")
+                else "one stream, serial", share_map=_share_map_name(gen, w))
     res["config"]["inputs"] = INPUT_MODES["replay"]
     res["roofline"] = {"kernel": gen_kernel if dominant_gen else "combine_update_kernel",
                        "achieved": gen_gbs if dominant_gen else comb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SDA_HIP_ABI_VERSION 3
+#define SDA_HIP_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum sda_status {
@@ -148,7 +148,15 @@ int sda_dev_synchronize(void);
  * begin / update[_dev] / finish[_dev], reconstruct[_dev] and unmask[_dev] (the dual-role launch, the wire-fed updates and
  * mask_batch_dev answer SDA_ERR_UNSUPPORTED in this mode).  Packed Shamir's generator / reconstructor refuse it
  * (SDA_ERR_UNSUPPORTED): their signed values are tss's, an un-vendored crate - compare those modulo the prime.  Set the
- * mode right after *_new (changing a combiner's mode discards its running sums: begin again). */
+ * mode right after *_new (CHANGING a combiner's mode discards its running sums: begin again; setting the mode it already has
+ * is a no-op).  Memory: generate_batch_dev in this mode without injected randomness first materialises every draw of the
+ * tile in the handle's one scratch buffer - participants * len * (share_count - 1) * 8 bytes (2000 participants x 1 Mi x
+ * n = 8 would ask for 117 GB) - so size tiles accordingly and keep such calls on ONE stream per handle at a time.
+ *
+ * Streams and the transform shapes.  For packed shapes served by the transform kernel (k + t > 32) generate_combine_dev
+ * issues the clerk sum of the previous tile on a low-priority side stream the GENERATOR owns and joins it back into the
+ * `stream` of that call only: while generate_combine_dev is in use, every call on that combiner (update_dev, finish_dev)
+ * must use the same stream; sda_share_combiner_set_residency does not apply to the side-stream sum (it runs a fixed grid). */
 enum sda_value_mode { SDA_VALUES_CANONICAL = 0, SDA_VALUES_RUST_SIGNED = 1 };
 
 /* ---- opaque handles: one per (scheme, role), like the reference's boxed trait objects ------ */
@@ -192,6 +200,23 @@ uint64_t sda_share_generator_rand_count(const sda_share_generator_t* g, size_t l
 int sda_share_generator_set_drbg_key(sda_share_generator_t* g, const uint8_t key[32]);
 int sda_share_generator_set_drbg_master_key(sda_share_generator_t* g, const uint8_t key[32]);
 int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int rounds);
+
+/* CSPRNG share map (packed Shamir, rand == NULL only; ABI 4).  tss draws the polynomial's t free parameters as its values
+ * at omega_secrets^(k+1 .. k+t) (packed_shamir.rs:42 -> tss share: values = [0] ++ secrets ++ randomness).  A caller who
+ * INJECTS randomness gets exactly that map.  When the library draws by itself, every matrix-form kernel uses the
+ * SYSTEMATIC parametrisation of the same polynomial family instead: the t draws of a batch ARE its shares 0 .. t-1 (the
+ * values at omega_shares^1 .. omega_shares^t) and shares t .. n-1 are the values, at omega_shares^(t+1 .. n), of the one
+ * polynomial of degree <= t + k with f(1) = 0, f(omega_secrets^i) = secret_i (i = 1..k) and f(omega_shares^(j+1)) = draw_j
+ * (j < t).  t + k + 1 distinct points fix such a polynomial, so for fixed secrets draws <-> tss randomness is a bijection
+ * and uniform draws give the SAME joint distribution of the n shares; t of the n modular dot products per batch
+ * disappear ((3,4,8): half of them).  SDA_SHARE_MAP_TSS_NODES is kept for the transform kernel (tss-valid shapes with
+ * k + t > 32, where the draws are inputs of tss's own transform), for t = 0, when a share point collides with a node,
+ * and on request (set_csprng_share_map: A/B measurements, round-3 fixtures).  Draw range: the device CSPRNG draws
+ * uniformly from [0, p); tss 0.2 draws from [0, p - 1) (rand's Range::new(0, prime - 1)) - the library's range is the
+ * one the secrecy argument wants (uniform over the field), and no reconstruction can tell the two apart. */
+enum sda_share_map { SDA_SHARE_MAP_TSS_NODES = 0, SDA_SHARE_MAP_SYSTEMATIC = 1 };
+int sda_share_generator_csprng_share_map(const sda_share_generator_t* g);          /* the map rand == NULL calls use */
+int sda_share_generator_set_csprng_share_map(sda_share_generator_t* g, int map);   /* SDA_ERR_UNSUPPORTED where it does not exist */
 
 /* generate(&mut self, secrets) -> Vec<Vec<Share>>   - sharing/mod.rs:14-17, batched.rs:18-53.
  *   secrets[len]               any i64

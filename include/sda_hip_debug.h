@@ -1,0 +1,32 @@
+/* sda_hip_debug.h - TEST / MEASUREMENT ONLY entry points of libsda_hip.so.  Not part of the drop-in boundary (include/sda_hip.h):
+ * nothing a Rust shim binds.  The release library reads no environment variable; the kernels behind one C-ABI call are all
+ * bit-exact with each other, and which one serves a shape is the library's decision.  The parity tests still have to reach the
+ * non-default kernels (the any-shape fallback, the 64-bit Montgomery form, the transform kernel on small tss-valid shapes, the
+ * limb GEMM on shapes it is not the default for, both varint decode forms), and the A/B measurements of DESIGN.md have to
+ * switch between them: that is what these knobs are for.  They are process-global and read when a handle is created (path
+ * selection) or at the call (stream / grid choices).
+ *
+ * knob names (value 0 = default behaviour):
+ *   SDA_FORCE_GENERIC 1        packed share generation through packed_gen_generic_kernel
+ *   SDA_FORCE_MONT64 1         ... through the superseded 64-bit Montgomery kernel
+ *   SDA_FORCE_FFT 1            the transform kernel for every tss-valid shape (default: k + t > 32)
+ *   SDA_FORCE_MFMA 1 / SDA_NO_MFMA 1   the limb GEMM for every shape it covers / never
+ *   SDA_NO_SIDE_STREAM 1       transform shapes: clerk sum on the caller's stream instead of the low-priority side stream
+ *   SDA_SIDE_STREAM_WGS n, SDA_SIDE_STREAM_PRIORITY 1 (= high)   side-stream grid and priority
+ *   SDA_FFT_G n, SDA_FFT_THREADS n   batches per workgroup / threads of the transform kernel
+ *   SDA_VARINT_PATH 1 (stream) / 2 (scan)   pin one varint decode form
+ *   SDA_FORCE_COLLECTIVES 1    a one-rank communicator still goes through RCCL send/recv to itself
+ * Built with -DSDA_AB_KNOBS (tools/build_ab_variant.sh; never by __graft_entry__.build()) an unset knob falls back to the
+ * environment variable of the same name. */
+#ifndef SDA_HIP_DEBUG_H
+#define SDA_HIP_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+int  sda_debug_set_knob(const char* name, long value);   /* SDA_ERR_INVALID_ARGUMENT for an unknown name */
+void sda_debug_reset_knobs(void);
+int  sda_debug_env_knobs_compiled_in(void);              /* 1 only in an SDA_AB_KNOBS build */
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -84,6 +84,31 @@ def packed_generate(p, k, t, n, w2, w3, secrets, rand):
     return out
 
 
+def packed_generate_systematic(p, k, t, n, w2, w3, secrets, draws, want_implied=False):
+    """the library's CSPRNG share map (include/sda_hip.h): draws = shares 0..t-1, the rest by interpolation through
+    (1, 0), the secrets at w2^i and the draws at w3^(j+1).  -> [n][B] (and, on request, the [B * t] randomness tss's own
+    share() would need for the same shares)"""
+    s, sp = _i64(secrets)
+    r, rp = _i64(draws)
+    B = (s.size + k - 1) // k
+    assert r.size == B * t
+    out = np.empty((n, B), dtype=np.int64)
+    imp = np.empty(B * t, dtype=np.int64) if want_implied else None
+    st = lib().sdao_packed_generate_systematic(C.c_int64(p), k, t, n, C.c_int64(w2), C.c_int64(w3), sp, C.c_size_t(s.size), rp,
+                                               out.ctypes.data_as(I64P), imp.ctypes.data_as(I64P) if want_implied else None)
+    if st != 0:
+        raise ValueError(f"sdao_packed_generate_systematic failed ({st})")
+    return (out, imp) if want_implied else out
+
+
+def packed_generate_csprng(p, k, t, n, w2, w3, secrets, draws, share_map=1):
+    """what a generator WITHOUT injected randomness produces from its CSPRNG draws: share_map 1 = systematic (the
+    matrix-form kernels' default), 0 = tss's nodes (the transform kernel; on request)"""
+    if share_map == 1 and t > 0:
+        return packed_generate_systematic(p, k, t, n, w2, w3, secrets, draws)
+    return packed_generate(p, k, t, n, w2, w3, secrets, draws)
+
+
 def packed_reconstruct(p, k, t, w2, w3, dimension, indices, shares):
     sh = np.ascontiguousarray(shares, dtype=np.int64)
     assert sh.ndim == 2 and sh.shape[0] == len(indices)

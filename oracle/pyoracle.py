@@ -294,6 +294,33 @@ class PackedSecretSharing:
         return [sum(a * (b % p) for a, b in zip(row, shares)) % p
                 for row in self.reconstruct_matrix(indices)]
 
+    # ---- the library's CSPRNG share map (no reference counterpart: the reference draws from OsRng) ---------
+    def share_systematic(self, secrets, draws) -> List[int]:
+        """include/sda_hip.h "CSPRNG share map": the t draws ARE shares 0..t-1; the other shares are the values at
+        omega_shares^(t+1..n) of the polynomial of degree <= t+k through (1, 0), (omega_secrets^i, secret_i) and
+        (omega_shares^(j+1), draw_j).  Restated with tss's own Newton interpolation (the product uses a Lagrange
+        matrix): canonical residues."""
+        p, t, k = self.prime, self.threshold, self.secret_count
+        assert len(secrets) == k and len(draws) == t
+        points = ([1] + [pow(self.omega_secrets, i, p) for i in range(1, k + 1)] +
+                  [pow(self.omega_shares, j + 1, p) for j in range(t)])
+        assert len(set(points)) == len(points), "a share point collides with a node"
+        values = [0] + [s % p for s in secrets] + [d % p for d in draws]
+        poly = tss_newton_interpolation_general(points, values, p, canon)
+        rest = [tss_newton_evaluate(poly, pow(self.omega_shares, j + 1, p), p, canon) for j in range(t, self.share_count)]
+        return [d % p for d in draws] + rest
+
+    def implied_tss_randomness(self, secrets, draws) -> List[int]:
+        """the randomness tss's `share` would have needed to produce share_systematic(secrets, draws): the same
+        polynomial's values at omega_secrets^(k+1..k+t).  share_lagrange(secrets, that) == share_systematic(secrets, draws)
+        - the two parametrisations describe the same sharings."""
+        p, t, k = self.prime, self.threshold, self.secret_count
+        points = ([1] + [pow(self.omega_secrets, i, p) for i in range(1, k + 1)] +
+                  [pow(self.omega_shares, j + 1, p) for j in range(t)])
+        values = [0] + [s % p for s in secrets] + [d % p for d in draws]
+        poly = tss_newton_interpolation_general(points, values, p, canon)
+        return [tss_newton_evaluate(poly, pow(self.omega_secrets, k + 1 + j, p), p, canon) for j in range(t)]
+
     # ---- what the oracle exposes to the schemes below -----------------------------------
     def share(self, secrets, randomness, mode):
         if mode == "rust_signed" and self.is_fft_shape() and self.prime * self.prime < 2 ** 62:

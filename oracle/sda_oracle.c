@@ -181,6 +181,57 @@ int sdao_packed_generate(int64_t prime, int k, int t, int n, int64_t omega_secre
     return st;
 }
 
+/* The library's CSPRNG share map (include/sda_hip.h "CSPRNG share map"; no reference counterpart - the reference draws
+ * from OsRng inside tss): per batch the t draws ARE shares 0..t-1 and shares t..n-1 are the values at w3^(t+1..n) of the
+ * polynomial of degree <= t+k through (1, 0), (w2^i, secret_i) i = 1..k, (w3^(j+1), draw_j) j < t.  Restated with a
+ * per-batch Newton interpolation (the product multiplies by one precomputed Lagrange matrix).  implied (may be NULL):
+ * [B][t] = the same polynomial's values at w2^(k+1..k+t), i.e. the randomness tss's own share() would have needed for
+ * these very shares - sdao_packed_generate(secrets, implied) must reproduce `out`. */
+int sdao_packed_generate_systematic(int64_t prime, int k, int t, int n, int64_t omega_secrets, int64_t omega_shares,
+                                    const int64_t* secrets, size_t len, const int64_t* draws, int64_t* out, int64_t* implied) {
+    const uint64_t p = (uint64_t)prime;
+    if (n < t) return SDAO_ERR_INVALID;
+    const size_t np = (size_t)(k + t + 1);
+    const size_t B = (len + (size_t)k - 1) / (size_t)k;
+    uint64_t* pts = (uint64_t*)malloc(sizeof(uint64_t) * np);
+    uint64_t* dd = (uint64_t*)malloc(sizeof(uint64_t) * np);
+    uint64_t* invd = (uint64_t*)malloc(sizeof(uint64_t) * np * np);
+    const uint64_t w2 = canon(omega_secrets, p), w3 = canon(omega_shares, p);
+    for (int i = 0; i <= k; ++i) pts[i] = powmod(w2, (uint64_t)i, p);
+    for (int j = 0; j < t; ++j) pts[k + 1 + j] = powmod(w3, (uint64_t)j + 1, p);
+    int st = SDAO_OK;
+    for (size_t i = 0; i < np && st == SDAO_OK; ++i)
+        for (size_t j = 0; j < i; ++j)
+            if (invmod((pts[i] + p - pts[j]) % p, p, &invd[i * np + j])) { st = SDAO_ERR_INVALID; break; }   /* colliding points */
+    for (size_t b = 0; b < B && st == SDAO_OK; ++b) {
+        dd[0] = 0;
+        for (int i = 0; i < k; ++i) {
+            size_t e = b * (size_t)k + (size_t)i;
+            dd[1 + i] = e < len ? canon(secrets[e], p) : 0;                  /* pad, batched.rs:37-43 */
+        }
+        for (int j = 0; j < t; ++j) {
+            dd[k + 1 + j] = canon(draws[b * (size_t)t + (size_t)j], p);
+            out[(size_t)j * B + b] = (int64_t)dd[k + 1 + j];                 /* share j = draw j */
+        }
+        for (size_t j = 1; j < np; ++j)
+            for (size_t i = np - 1; i >= j; --i)
+                dd[i] = mulmod((dd[i] + p - dd[i - 1]) % p, invd[i * np + (i - j)], p);
+        for (int q = t; q < n + (implied ? t : 0); ++q) {
+            const int is_share = q < n;
+            const uint64_t x = is_share ? powmod(w3, (uint64_t)q + 1, p) : powmod(w2, (uint64_t)(k + 1 + (q - n)), p);
+            uint64_t acc = 0, prod = 1;
+            for (size_t i = 0; i < np; ++i) {
+                acc = (acc + mulmod(dd[i], prod, p)) % p;
+                prod = mulmod(prod, (x + p - pts[i]) % p, p);
+            }
+            if (is_share) out[(size_t)q * B + b] = (int64_t)acc;
+            else implied[b * (size_t)t + (size_t)(q - n)] = (int64_t)acc;
+        }
+    }
+    free(pts); free(dd); free(invd);
+    return st;
+}
+
 /* batched.rs:68-97 driving packed_shamir.rs:73-77 -> tss reconstruct: per batch, Newton interpolation
  * through (1,0) and (w3^(idx+1), share) and evaluation at w2^e, e=1..k - recomputed for EVERY batch,
  * as the reference does.  shares: row c at shares + c*stride. */

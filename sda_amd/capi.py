@@ -71,6 +71,10 @@ SIGNATURES = {
     "sda_scheme_reconstruction_threshold": (C.c_uint64, [_SS]),
     "sda_masking_has_mask": (C.c_int, [_MS]),
     "sda_abi_version": (C.c_int, []),
+    # include/sda_hip_debug.h - test / measurement only
+    "sda_debug_set_knob": (C.c_int, [C.c_char_p, C.c_long]),
+    "sda_debug_reset_knobs": (None, []),
+    "sda_debug_env_knobs_compiled_in": (C.c_int, []),
     "sda_version": (C.c_char_p, []),
     "sda_device_count": (C.c_int, []),
     "sda_set_device": (C.c_int, [C.c_int]),
@@ -97,6 +101,8 @@ SIGNATURES = {
     "sda_share_generator_set_drbg_key": (C.c_int, [_H, c_u8p]),
     "sda_share_generator_set_drbg_master_key": (C.c_int, [_H, c_u8p]),
     "sda_share_generator_set_drbg_rounds": (C.c_int, [_H, C.c_int]),
+    "sda_share_generator_csprng_share_map": (C.c_int, [_H]),
+    "sda_share_generator_set_csprng_share_map": (C.c_int, [_H, C.c_int]),
     "sda_share_generator_generate": (C.c_int, [_H, c_i64p, C.c_size_t, c_i64p, C.c_size_t, c_i64p, C.c_size_t]),
     "sda_share_generator_generate_batch_dev": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                                          C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p,

@@ -190,6 +190,16 @@ class ShareGenerator(_Handle):
     def set_drbg_rounds(self, rounds: int):
         check(self._lib.sda_share_generator_set_drbg_rounds(self._h, rounds))
 
+    SHARE_MAP_TSS_NODES, SHARE_MAP_SYSTEMATIC = 0, 1
+
+    def csprng_share_map(self) -> int:
+        """the parametrisation calls WITHOUT injected randomness use (include/sda_hip.h, "CSPRNG share map"): 1 = the t draws
+        of a batch are its shares 0..t-1, 0 = tss's (draws are the values at omega_secrets^(k+1..k+t))"""
+        return int(self._lib.sda_share_generator_csprng_share_map(self._h))
+
+    def set_csprng_share_map(self, which: int):
+        check(self._lib.sda_share_generator_set_csprng_share_map(self._h, which))
+
     def batch_count(self, length: int) -> int:
         return int(self._lib.sda_share_generator_batch_count(self._h, length))
 

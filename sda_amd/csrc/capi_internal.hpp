@@ -7,3 +7,16 @@
 int capi_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));   // sets sda_last_error(), returns code
 int capi_make_mod(int64_t modulus, sda::ModParams& mod);                                  // validated Barrett / Lemire constants
 int capi_device_ready();                                                                  // a device exists; make the selected one current
+
+// ---- path-selection knobs (A/B measurements and parity tests of the non-default kernels) -----------------------------------
+// A release build of the library reads NO environment variable: a knob changes only through the test-only entry point
+// sda_debug_set_knob (include/sda_hip_debug.h).  Built with -DSDA_AB_KNOBS (tools/build_ab_variant.sh, never build()), a
+// knob left unset falls back to the environment variable of the same name, for shell-driven A/B runs.
+namespace sda {
+enum Knob {
+    KNOB_FORCE_GENERIC, KNOB_FORCE_MONT64, KNOB_FORCE_FFT, KNOB_FORCE_MFMA, KNOB_NO_MFMA, KNOB_NO_SIDE_STREAM,
+    KNOB_SIDE_STREAM_WGS, KNOB_SIDE_STREAM_PRIORITY_HIGH, KNOB_FFT_G, KNOB_FFT_THREADS, KNOB_VARINT_PATH /* 1 stream, 2 scan */,
+    KNOB_FORCE_COLLECTIVES, KNOB_COUNT
+};
+long knob(Knob k);             // 0 = unset / default
+}  // namespace sda

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "chacha.hpp"
+#include "capi_internal.hpp"
 #include "kernels.hpp"
 #include "modarith.hpp"
 
@@ -379,9 +380,9 @@ hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, 
     const size_t lds = fft_lds_bytes(F.m2, F.m3, F.G, F.tw_lds != 0);
     // 512 threads = 4 waves per SIMD with the two workgroups a CU's LDS holds (PSS_155_728_100, round 2: 58 ms per 500 x 1 Mi
     // tile against 66 with 256 threads, 79 with 1024, 120 with 128)
-    static const char* env_threads = getenv("SDA_FFT_THREADS");                 // A/B only
-    unsigned threads = (F.G == 1 && F.m3 > 2187) || F.G > 8 ? 1024u : 512u;
-    if (env_threads && atoi(env_threads) >= 64 && atoi(env_threads) <= 1024 && atoi(env_threads) % 64 == 0) threads = (unsigned)atoi(env_threads);
+    const long want_threads = knob(KNOB_FFT_THREADS);                           // A/B only
+    unsigned threads = (F.G == 1 && F.m3 > 2187) ? 1024u : 512u;
+    if (want_threads >= 64 && want_threads <= 1024 && want_threads % 64 == 0) threads = (unsigned)want_threads;
     if (rounds != 20 && rounds != 12 && rounds != 8) return hipErrorInvalidValue;
     auto kern = F.tw_lds ? (rounds == 20 ? packed_gen_fft_kernel<20, true> : rounds == 12 ? packed_gen_fft_kernel<12, true> : packed_gen_fft_kernel<8, true>)
                          : (rounds == 20 ? packed_gen_fft_kernel<20, false> : rounds == 12 ? packed_gen_fft_kernel<12, false> : packed_gen_fft_kernel<8, false>);

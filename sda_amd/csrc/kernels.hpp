@@ -43,6 +43,15 @@ struct L31Params {
     uint64_t np, np2; // 2^64 - p and 2^64 - 2p: x + np wraps exactly when x >= p (the conditional subtractions)
 };
 
+// Constants of the narrow-modulus path (p < 2^31: one signed 32-bit limb per residue, R = 2^32); see narrow_gen.inc.hpp.
+// MatArg then holds int32 constants (896 entries): centred representatives of M_ji * 2^32 mod p, rows back to back.
+struct N31Params {
+    uint32_t p;        // modulus < 2^31
+    uint32_t pinv;     // -p^-1 mod 2^32
+    uint32_t h;        // (p + 1) / 2: v >= h is centred to v - p
+    uint32_t pad;
+};
+
 // strides in elements
 struct GenLayout {
     const int64_t* secrets;   size_t secrets_stride;
@@ -73,6 +82,14 @@ bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n);
 hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
                                       const ModParams& mod, const L31Params& lp, const MatArg& Ml31,
                                       const DrbgKey& key, int rounds, hipStream_t s);
+
+// packed Shamir over a NARROW prime (p < 2^31, the reference's own valid domain): run-time (k, t), k + t <= 16, ChaCha20 only
+bool packed_n31_path_available(uint32_t k, uint32_t t, uint32_t rows, uint64_t p);
+hipError_t launch_packed_generate_n31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                      const N31Params& np, const MatArg& M, const DrbgKey& key, hipStream_t s);
+hipError_t launch_fused_packed_n31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod, const N31Params& np,
+                                   const MatArg& M, const DrbgKey& key, uint64_t* acc_lo, int64_t* acc_hi, const int64_t* d_prev,
+                                   size_t prev_rows, size_t jobs, size_t dimension, hipStream_t s, bool* fused);
 
 // packed Shamir as a limb GEMM on the matrix cores (v_mfma_i32_16x16x64_i8 on balanced base-256 digits), compiled shapes
 bool packed_mfma_path_available(uint32_t k, uint32_t t, uint32_t n);

@@ -1,0 +1,138 @@
+// Narrow-modulus packed-Shamir share generation (p < 2^31) - included by sda_kernels.hip inside namespace sda, after the
+// dual-role helpers (it uses drbg_pair, store2, split_item, FuseArgs / fuse_dispatch of that file).
+//
+// Why: the reference's packed path multiplies i64 residues WITHOUT widening (tss 0.2; the note at additive.rs:37-39 "we
+// assume that the values are really i32"), so its whole valid domain is p^2 + p < 2^63 - p = 433 (full_loop.rs:57-64),
+// tss's shipped 746497 and 5038849.  The 62-bit kernels pay two-limb arithmetic for those primes too: four v_mad_i64_i32
+// per term and a ~20-instruction radix-2^31 reduction per five terms.  Here a residue is ONE signed 32-bit limb:
+//   * values and Montgomery-form constants (R = 2^32) are centred to [-(p-1)/2, (p-1)/2], |.| < 2^30;
+//   * a dot product is ONE v_mad_i64_i32 per term into a signed 64-bit sum, GROUP terms at a time with
+//     GROUP * p < 2^33 (4 terms for any p < 2^31, 16 below 2^29 - a whole (8,7) row);
+//   * Montgomery reduction of the sum S is three 32-bit instructions: q = lo(S) * (-p^-1) (signed), and the exact quotient
+//     (S + q p) / 2^32 = hi(S) + mulhi(q, p) + (lo(S) != 0) - the low words cancel, so the carry is known without
+//     forming the 65-bit sum; |result| < GROUP p^2 / 2^34 + p / 2 < p, made canonical with one masked add.
+// Bounds and exactness: tests/test_narrow_model.py (big-int model, extreme operands).  Draws are the same sda-drbg-v1
+// stream (64-bit Lemire sampling), so the oracle's restatement serves both widths; only ROUNDS = 20 is instantiated
+// (the other round counts exist for A/B runs of the wide kernels).
+//
+// k and t are kernel arguments (KTMAX = 4 / 8 / 12 / 16 bounds k + t); the matrix travels in the kernarg segment as
+// int32 constants (MatArg reinterpreted: 896 entries), rows back to back, zero padded by three entries.
+
+__device__ __forceinline__ int32_t n31_centre(uint64_t v, const N31Params& P) {          // canonical [0, p) -> centred
+    const uint32_t x = (uint32_t)v;
+    return (int32_t)(x >= P.h ? x - P.p : x);
+}
+
+// S (|S| < 2^62, any exact multiple structure) -> S * 2^-32 mod p, canonical [0, p)
+__device__ __forceinline__ uint32_t n31_redc(int64_t S, const N31Params& P) {
+    const uint32_t sl = (uint32_t)S;
+    const int32_t sh = (int32_t)(S >> 32);
+    const int32_t q = (int32_t)(sl * P.pinv);
+    int32_t t = sh + __mulhi(q, (int32_t)P.p) + (sl != 0 ? 1 : 0);                       // in (-p, p)
+    t += (t >> 31) & (int32_t)P.p;
+    return (uint32_t)t;
+}
+
+// sum over i < kt of row[i] * v[i] mod p (Montgomery-form constants): groups of GROUP terms, each reduced on its own
+template <int KTMAX, int GROUP>
+__device__ __forceinline__ uint32_t n31_dot(const int32_t* __restrict__ row, const int32_t (&v)[KTMAX], uint32_t kt,
+                                            const N31Params& P) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int g0 = 0; g0 < KTMAX; g0 += GROUP) {
+        if ((uint32_t)g0 < kt) {                                               // wave-uniform
+            int64_t S = 0;
+#pragma unroll
+            for (int c0 = g0; c0 < g0 + GROUP && c0 < KTMAX; c0 += 4) {
+                if ((uint32_t)c0 < kt) {                                       // terms beyond kt have zero VALUES: whole chunks of four
+#pragma unroll
+                    for (int i = c0; i < c0 + 4 && i < KTMAX; ++i) S = (c0 == g0 && i == c0) ? mul_sv(row[i], v[i]) : mad_sv(row[i], v[i], S);
+                }
+            }
+            const uint32_t r = n31_redc(S, P);
+            if (g0 == 0) acc = r;
+            else {
+                const uint32_t s = acc + r;                                    // < 2p < 2^32
+                const uint32_t d = s - P.p;
+                acc = d < s ? d : s;                                           // min(s, s - p): s - p wraps exactly when s < p
+            }
+        }
+    }
+    return acc;
+}
+
+template <int KTMAX, int GROUP, int ROUNDS>
+__device__ __forceinline__ void packed_gen_n31_body(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                                    const N31Params& np, const int32_t* __restrict__ Mrows, const DrbgKey& key,
+                                                    uint64_t chunks, uint64_t batches, bool vec, uint64_t item) {
+    const uint32_t kt = k + t;
+    uint64_t p, chunk;
+    split_item(item, chunks, p, chunk);
+    const uint64_t pair = chunk * kThreads + threadIdx.x;
+    const uint64_t b0 = 2 * pair;
+    const bool in0 = b0 < batches, in1 = b0 + 1 < batches;
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
+    const uint64_t e0 = b0 * k;
+    const uint64_t stream = L.first_participant + p;
+    const QuadCol qc = quad_col(key);
+    int64_t* op = L.out + p * L.out_stride_participant + b0;
+    const uint32_t direct = rp ? 0u : L.direct_rows;                         // 0 or t (systematic share map)
+    int32_t x[KTMAX], y[KTMAX];
+#pragma unroll
+    for (int i = 0; i < KTMAX; ++i) {
+        uint64_t a = 0, b = 0;
+        if ((uint32_t)i < k) {                                               // wave-uniform
+            const uint64_t ea = e0 + i, eb = e0 + k + i;
+            a = ea < L.len ? canon_i64(sp[ea], mod.m, mod.mu) : 0;           // zero padding (batched.rs:37-43)
+            b = eb < L.len ? canon_i64(sp[eb], mod.m, mod.mu) : 0;
+        } else if ((uint32_t)i < kt) {
+            if (rp) {
+                a = in0 ? canon_i64(rp[b0 * t + (i - k)], mod.m, mod.mu) : 0;
+                b = in1 ? canon_i64(rp[(b0 + 1) * t + (i - k)], mod.m, mod.mu) : 0;
+            } else {
+                drbg_pair<ROUNDS>(key, qc, stream, pair, t, (uint32_t)i - k, mod, a, b);
+                if (direct) {                                                // draw i - k IS share i - k
+                    int64_t* o = op + (size_t)((uint32_t)i - k) * L.out_stride_clerk;
+                    if (vec && in1) store2(o, a, b);
+                    else {
+                        if (in0) o[0] = (int64_t)a;
+                        if (in1) o[1] = (int64_t)b;
+                    }
+                }
+            }
+        }
+        x[i] = n31_centre(a, np);
+        y[i] = n31_centre(b, np);
+    }
+    for (uint32_t j = direct; j < n; ++j) {
+        const int32_t* row = Mrows + (size_t)(j - direct) * kt;
+        const uint64_t a = n31_dot<KTMAX, GROUP>(row, x, kt, np);
+        const uint64_t b = n31_dot<KTMAX, GROUP>(row, y, kt, np);
+        int64_t* o = op + (size_t)j * L.out_stride_clerk;
+        if (vec && in1) store2(o, a, b);
+        else {
+            if (in0) o[0] = (int64_t)a;
+            if (in1) o[1] = (int64_t)b;
+        }
+    }
+}
+
+template <int KTMAX, int GROUP, int ROUNDS>
+__global__ __launch_bounds__(kThreads) void packed_gen_n31_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t, ModParams mod,
+                                                                  N31Params np, MatArg M, DrbgKey key, uint64_t chunks,
+                                                                  uint64_t batches, bool vec) {
+    packed_gen_n31_body<KTMAX, GROUP, ROUNDS>(L, n, k, t, mod, np, reinterpret_cast<const int32_t*>(&M.e[0]), key, chunks, batches, vec,
+                                              blockIdx.x);
+}
+
+// the dual-role launch (share-gen of tile i + clerk-sum of tile i-1 in one grid) for the narrow kernel
+template <int KTMAX, int GROUP, int ROUNDS>
+__global__ __launch_bounds__(kThreads) void fused_packed_n31_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t, ModParams mod,
+                                                                    N31Params np, MatArg M, DrbgKey key, uint64_t chunks,
+                                                                    uint64_t batches, FuseArgs F) {
+    uint64_t idx;
+    if (!fuse_dispatch(F, blockIdx.x, idx))
+        packed_gen_n31_body<KTMAX, GROUP, ROUNDS>(L, n, k, t, mod, np, reinterpret_cast<const int32_t*>(&M.e[0]), key, chunks, batches,
+                                                  true, idx);
+}

@@ -12,6 +12,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <string.h>
 #include <sys/random.h>
 
@@ -94,7 +95,44 @@ extern "C" const char* sda_strerror(int status) {
 
 extern "C" const char* sda_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sda_abi_version(void) { return SDA_HIP_ABI_VERSION; }
-extern "C" const char* sda_version(void) { return "sda-hip 0.3.0 (gfx950)"; }
+
+// ---- path-selection knobs (capi_internal.hpp) --------------------------------------------------------------------------
+namespace {
+const char* const kKnobNames[sda::KNOB_COUNT] = {
+    "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
+    "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES"};
+std::atomic<long> g_knobs[sda::KNOB_COUNT];
+}  // namespace
+long sda::knob(sda::Knob k) {
+    const long v = g_knobs[k].load(std::memory_order_relaxed);
+#ifdef SDA_AB_KNOBS
+    if (v == 0)
+        if (const char* e = getenv(kKnobNames[k])) {
+            if (k == KNOB_VARINT_PATH) return !strcmp(e, "stream") ? 1 : !strcmp(e, "scan") ? 2 : 0;
+            if (k == KNOB_SIDE_STREAM_PRIORITY_HIGH) return e[0] == 'h';
+            const long n = atol(e);
+            return n ? n : 1;                                   // "set" counts as 1 for the boolean knobs
+        }
+#endif
+    return v;
+}
+extern "C" int sda_debug_set_knob(const char* name, long value) {
+    if (!name) return fail(SDA_ERR_INVALID_ARGUMENT, "name is NULL");
+    for (int k = 0; k < sda::KNOB_COUNT; ++k)
+        if (!strcmp(name, kKnobNames[k])) { g_knobs[k].store(value, std::memory_order_relaxed); return SDA_OK; }
+    return fail(SDA_ERR_INVALID_ARGUMENT, "unknown knob %s", name);
+}
+extern "C" void sda_debug_reset_knobs(void) {
+    for (auto& k : g_knobs) k.store(0, std::memory_order_relaxed);
+}
+extern "C" int sda_debug_env_knobs_compiled_in(void) {
+#ifdef SDA_AB_KNOBS
+    return 1;
+#else
+    return 0;
+#endif
+}
+extern "C" const char* sda_version(void) { return "sda-hip 0.4.0 (gfx950)"; }
 
 // -------------------------------------------------------------------------------------------------
 // device context
@@ -491,17 +529,25 @@ struct sda_share_generator {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int side_stream() {
-        if (aux) return SDA_OK;
+        if (aux && ev_fork && ev_join) return SDA_OK;
         // a stream of another priority class gets a hardware queue of its own (plain streams are dealt round-robin over a
         // few queues and this one landed on the default stream's: both kernels then ran back to back, rocprofv3 queue ids)
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         // LOW priority: the transform kernel's workgroups (8 waves + 77 KB of LDS each) must keep being dispatched first; the
         // clerk sum takes the wave slots and registers they leave (at high priority it starved them: no gain, measured)
-        const char* pr = getenv("SDA_SIDE_STREAM_PRIORITY");                        // A/B only: "high"
-        HIP_TRY(hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, pr && pr[0] == 'h' ? greatest : least));
-        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        hipStream_t st = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipError_t e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, knob(KNOB_SIDE_STREAM_PRIORITY_HIGH) ? greatest : least);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+        if (e != hipSuccess) {                                   // all three or none: a half-built set would fail every later call
+            if (e1) (void)hipEventDestroy(e1);
+            if (e0) (void)hipEventDestroy(e0);
+            if (st) (void)hipStreamDestroy(st);
+            return fail(SDA_ERR_HIP, "side stream setup failed: %s", hipGetErrorString(e));
+        }
+        aux = st; ev_fork = e0; ev_join = e1;
         return SDA_OK;
     }
 };
@@ -636,8 +682,8 @@ static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, ui
         for (uint32_t tw = 2; tw-- > 0 && !G;)
             if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, cand, tw != 0) <= half_cu) { G = cand; tw_lds = tw; }
     if (!G && fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, false) <= whole_cu) { G = 1; tw_lds = 0; }
-    if (const char* fg = getenv("SDA_FFT_G")) {                          // A/B only: fewer batches per workgroup
-        const uint32_t want = (uint32_t)atoi(fg);
+    if (const long fg = knob(KNOB_FFT_G)) {                               // A/B only: fewer batches per workgroup
+        const uint32_t want = (uint32_t)fg;
         if (want == 1 || want == 2 || want == 4 || want == 8) {
             if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, true) <= half_cu) { G = want; tw_lds = 1; }
             else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, false) <= whole_cu) { G = want; tw_lds = 0; }
@@ -731,19 +777,19 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
     }
     if (st == SDA_OK) st = g->ctx.init();
     if (st == SDA_OK && !g->additive) {
-        g->l31 = packed_l31_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64");
-        g->fast = !g->l31 && packed_fast_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC");
-        g->l31g = !g->l31 && !g->fast && packed_l31_global_path_available(g->k, g->t) && !getenv("SDA_FORCE_GENERIC") &&
-                  !getenv("SDA_FORCE_MONT64");
+        g->l31 = packed_l31_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64);
+        g->fast = !g->l31 && packed_fast_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC);
+        g->l31g = !g->l31 && !g->fast && packed_l31_global_path_available(g->k, g->t) && !knob(KNOB_FORCE_GENERIC) &&
+                  !knob(KNOB_FORCE_MONT64);
         // the transform form: every tss-valid shape with k + t > 32 (beyond that the matrix kernels run at one wave per SIMD
         // or not at all); SDA_FORCE_FFT=1 selects it for any tss-valid shape (A/B runs, parity tests of small shapes)
         uint32_t fa = 0, fb = 0, fG = 0, ftw = 0;
-        if (!getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64") && ((uint64_t)g->k + g->t > 32 || getenv("SDA_FORCE_FFT")) &&
+        if (!knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64) && ((uint64_t)g->k + g->t > 32 || knob(KNOB_FORCE_FFT)) &&
             fft_shape(g, fa, fb, fG, ftw)) {
             g->fft = true; g->l31 = g->l31g = g->fast = false;
             st = build_fft(g, fa, fb, fG, ftw);
-        } else if (packed_mfma_path_available(g->k, g->t, g->n) && !getenv("SDA_FORCE_GENERIC") && !getenv("SDA_FORCE_MONT64") &&
-                   !getenv("SDA_NO_MFMA") && (g->k + g->t >= 12 || getenv("SDA_FORCE_MFMA"))) {
+        } else if (packed_mfma_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64) &&
+                   !knob(KNOB_NO_MFMA) && (g->k + g->t >= 12 || knob(KNOB_FORCE_MFMA))) {
             // the limb GEMM on the matrix cores: measured ahead of the limb-31 kernel from k + t = 15 with n = 26 (+12 %),
             // behind it for k + t = 10 and below (SDA_FORCE_MFMA=1 takes it for every compiled shape, SDA_NO_MFMA=1 never)
             g->mfma = true; g->l31 = g->l31g = g->fast = false;
@@ -872,8 +918,13 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
         // the reference's representatives: shares 0..n-2 are the draws themselves, the last one the fold of (acc - r) % q.
         // Draws that are not injected are materialised first - the same sda-drbg-v1 values the canonical kernel would use
         if (!d_rand && g->n > 1) {
-            const size_t rstride = len * (g->n - 1);
-            SDA_TRY(g->d_rand.reserve(participants * rstride * 8));
+            // every draw of the tile is materialised in the handle's one scratch buffer: participants * len * (n - 1) * 8
+            // bytes (sda_hip.h, "value modes": a fidelity mode - size tiles for it, one call at a time per handle)
+            size_t rstride = 0, total = 0;
+            if (__builtin_mul_overflow(len, (size_t)(g->n - 1), &rstride) || __builtin_mul_overflow(participants, rstride, &total) ||
+                total > (SIZE_MAX >> 3))
+                return fail(SDA_ERR_INVALID_ARGUMENT, "participants * len * (share_count - 1) draws do not fit a buffer");
+            SDA_TRY(g->d_rand.reserve(total * 8));
             HIP_TRY(launch_drbg_fill(g->d_rand.as<int64_t>(), rstride, participants, len, g->n - 1, first_participant, g->mod, key,
                                      g->drbg.rounds, s));
             L.rand = g->d_rand.as<int64_t>();
@@ -1036,6 +1087,7 @@ extern "C" int sda_share_combiner_begin_dev(sda_share_combiner_t* c, size_t jobs
 extern "C" int sda_share_combiner_set_value_mode(sda_share_combiner_t* c, int mode) {
     if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
     SDA_TRY(check_value_mode(mode));
+    if (c->acc.rust_signed == (mode == SDA_VALUES_RUST_SIGNED)) return SDA_OK;   // unchanged: a running sum stays valid
     c->begun = false;                                               // the running sums are kept in ONE representation: begin again
     c->acc.rust_signed = mode == SDA_VALUES_RUST_SIGNED;            // combiner.rs:20-26 is the same loop for both sharing schemes
     c->acc.q = (int64_t)c->mod.m;
@@ -1099,7 +1151,7 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     // that shape the clerk sum of the previous tile is issued on a side stream and runs in the wave slots the transform
     // kernel leaves free: fork after whatever precedes this call on `stream`, join before anything that follows it
     const bool both = prev_participants > 0 && participants > 0 && len > 0;
-    if (st == SDA_OK && !fused && both && g->fft && !getenv("SDA_NO_SIDE_STREAM")) {
+    if (st == SDA_OK && !fused && both && g->fft && !knob(KNOB_NO_SIDE_STREAM)) {
         st = g->side_stream();
         if (st == SDA_OK) {
             hipError_t e = hipEventRecord(g->ev_fork, s);
@@ -1112,16 +1164,19 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
         if (st == SDA_OK) {
             // one clerk-sum workgroup per CU (4 waves, 72 registers: what two transform workgroups leave free on every SIMD),
             // walking the job in grid strides
-            static const char* ww = getenv("SDA_SIDE_STREAM_WGS");                 // A/B only
-            const unsigned walk = ww ? (unsigned)atoi(ww) : 256u;
+            const long ww = knob(KNOB_SIDE_STREAM_WGS);                            // A/B only
+            const unsigned walk = ww > 0 ? (unsigned)ww : 256u;
             hipError_t e = launch_combine_update(c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, c->jobs, out_stride_clerk,
                                                  prev_participants, out_stride_participant, c->dimension, g->aux, 0, walk);
             if (e != hipSuccess) st = fail(SDA_ERR_HIP, "clerk-sum launch on the side stream failed: %s", hipGetErrorString(e));
         }
-        // join even after a failure, so that `stream` never runs ahead of work already queued on the side stream
-        hipError_t e = hipEventRecord(g->ev_join, g->aux);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, g->ev_join, 0);
-        if (e != hipSuccess && st == SDA_OK) st = fail(SDA_ERR_HIP, "join from the side stream failed: %s", hipGetErrorString(e));
+        // join even after a failure, so that `stream` never runs ahead of work already queued on the side stream (nothing to
+        // join when the side stream itself could not be set up)
+        if (g->aux && g->ev_join) {
+            hipError_t e = hipEventRecord(g->ev_join, g->aux);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, g->ev_join, 0);
+            if (e != hipSuccess && st == SDA_OK) st = fail(SDA_ERR_HIP, "join from the side stream failed: %s", hipGetErrorString(e));
+        }
     } else {
         if (st == SDA_OK && !fused && prev_participants > 0)
             st = sda_share_combiner_update_dev(c, d_prev, out_stride_clerk, prev_participants, out_stride_participant, stream);
@@ -1790,9 +1845,9 @@ static int varint_count_scan(sda_varint_codec_t* c, const uint8_t* d_bytes, size
 // Row streaming needs a wave per row to keep the chip busy; fewer rows take the three-pass scan form,
 // which parallelises inside a row.  SDA_VARINT_PATH=stream|scan pins one form (A/B runs, parity tests).
 static bool varint_use_stream(size_t rows) {
-    if (const char* e = getenv("SDA_VARINT_PATH")) {
-        if (!strcmp(e, "stream")) return rows > 0;
-        if (!strcmp(e, "scan")) return false;
+    if (const long e = knob(KNOB_VARINT_PATH)) {
+        if (e == 1) return rows > 0;
+        if (e == 2) return false;
     }
     // measured (profiles/r01/wire_bench.json, rows of 349526 values): 1024 rows - decode equal, fused clerk sum 100
     // vs 123 Gvalues/s; 2000 rows - 229 vs 153 and 195 vs 125; 16000 rows - 260 vs 156 and 304 vs 127

@@ -158,7 +158,7 @@ extern "C" int sda_modular_allreduce_dev(sda_comm_t* c, int64_t modulus, const i
     red.stream = s;
     // a single rank needs no exchange: canonicalise through the same kernel (SDA_FORCE_COLLECTIVES=1 sends the one
     // slice to itself through RCCL anyway - the 1-GPU test of the RCCL path)
-    if (c->world == 1 && !getenv("SDA_FORCE_COLLECTIVES")) return red.modsum(d_partial, 1, len, len, d_out);
+    if (c->world == 1 && !sda::knob(sda::KNOB_FORCE_COLLECTIVES)) return red.modsum(d_partial, 1, len, len, d_out);
     const SlicePlan pl(c->world, len);
     const size_t need = ((size_t)c->world + 1) * pl.seg;
     if (need > c->scratch_elems) {

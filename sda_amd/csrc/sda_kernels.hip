@@ -1023,6 +1023,8 @@ __global__ __launch_bounds__(kThreads) void fused_additive_kernel(GenLayout L, u
     if (!fuse_dispatch(F, blockIdx.x, idx)) additive_gen_body<ROUNDS, true>(L, n, mod, key, chunks, idx);
 }
 
+#include "narrow_gen.inc.hpp"
+
 __global__ __launch_bounds__(kThreads) void combine_finish_kernel(const uint64_t* __restrict__ acc_lo,
                                                                   const int64_t* __restrict__ acc_hi, size_t count,
                                                                   ModParams mod, int64_t* __restrict__ out) {
@@ -1903,6 +1905,53 @@ hipError_t launch_fused_packed_mfma(const GenLayout& L, uint32_t n, uint32_t k, 
          : rounds == 12 ? fused_mfma_kt<0, 0, 12>(L, n, k, t, mod, mont, d_Mbal, key, F, chunks, batches, s)
                         : fused_mfma_kt<0, 0, 8>(L, n, k, t, mod, mont, d_Mbal, key, F, chunks, batches, s);
 }
+
+// ---- narrow-modulus kernels (narrow_gen.inc.hpp) ---------------------------------------------------------------------
+bool packed_n31_path_available(uint32_t k, uint32_t t, uint32_t rows, uint64_t p) {
+    return p < (1ull << 31) && k >= 1 && k + t <= 16 && (uint64_t)rows * (k + t) + 3 <= 2 * SDA_MAT_ARG_MAX;
+}
+
+#define SDA_N31_DISPATCH(KERNEL, GRID, ...)                                                                              \
+    do {                                                                                                                 \
+        const uint32_t kt_ = k + t;                                                                                      \
+        const bool g16_ = np.p < (1u << 29);        /* GROUP * p < 2^33: 16 terms per reduction below 2^29, else 4 */    \
+        const dim3 grid_((unsigned)(GRID)), block_(kThreads);                                                            \
+        if (kt_ <= 4) KERNEL<4, 4, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__);                                            \
+        else if (kt_ <= 8) { if (g16_) KERNEL<8, 16, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); else KERNEL<8, 4, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); }   \
+        else if (kt_ <= 12) { if (g16_) KERNEL<12, 16, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); else KERNEL<12, 4, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); } \
+        else { if (g16_) KERNEL<16, 16, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); else KERNEL<16, 4, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); }               \
+    } while (0)
+
+hipError_t launch_packed_generate_n31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
+                                      const N31Params& np, const MatArg& M, const DrbgKey& key, hipStream_t s) {
+    const uint64_t batches = ceil_div(L.len, k);
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        const bool vec = aligned16(S.out) && S.out_stride_participant % 2 == 0 && S.out_stride_clerk % 2 == 0;
+        SDA_N31_DISPATCH(packed_gen_n31_kernel, chunks * S.participants, S, n, k, t, mod, np, M, key, chunks, batches, vec);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_fused_packed_n31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod, const N31Params& np,
+                                   const MatArg& M, const DrbgKey& key, uint64_t* acc_lo, int64_t* acc_hi, const int64_t* d_prev,
+                                   size_t prev_rows, size_t jobs, size_t dimension, hipStream_t s, bool* fused) {
+    *fused = false;
+    if (L.rand) return hipSuccess;
+    const uint64_t batches = ceil_div(L.len, k);
+    const uint64_t chunks = ceil_div(ceil_div(batches, 2), kThreads);
+    FuseArgs F;
+    if (!fuse_plan(L, chunks, acc_lo, acc_hi, d_prev, prev_rows, jobs, dimension, F)) return hipSuccess;
+    *fused = true;
+    SDA_N31_DISPATCH(fused_packed_n31_kernel, F.grid, L, n, k, t, mod, np, M, key, chunks, batches, F);
+    return hipGetLastError();
+}
+#undef SDA_N31_DISPATCH
 
 hipError_t launch_fused_additive(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,
                                  uint64_t* acc_lo, int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs,

@@ -50,6 +50,8 @@ PROV_KATS = {
 }
 PROV_P62 = {"everything": "oracle-generated (62-bit prime scenarios; the reference's own packed-Shamir arithmetic overflows there, SURVEY.md App. A.3)"}
 PROV_DRBG = {"cases, call_keys": "oracle-generated (sda-drbg-v1 is the product's own stream layout; the reference uses OsRng)",
+             "share_map_cases": "oracle-generated (the systematic CSPRNG share map is the product's own, include/sda_hip.h; each case is "
+                                "tied to tss's map - recalled, SURVEY.md App. B - through the implied randomness)",
              "the ChaCha20 block function underneath": "published-RFC (RFC 7539 2.3.2, pinned in tests/test_oracle.py::test_chacha_kats)"}
 
 
@@ -183,6 +185,35 @@ def main():
         drbg["cases"].append({"stream": stream, "batches": batches, "T": T, "modulus": m, "rounds": rounds,
                               "values": po.drbg_fill(key, stream, batches, T, m, rounds)})
     drbg["call_keys"] = [{"call_index": i, "key_hex": po.drbg_call_key(key, i).hex()} for i in (0, 1, 2, (1 << 32) + 5)]
+    # ---- the CSPRNG share map (include/sda_hip.h): draws of sda-drbg-v1 -> the shares a generator WITHOUT injected randomness
+    # hands out.  Systematic map (every matrix-form kernel): shares 0..t-1 = the draws, the rest by interpolation; each case
+    # also carries the randomness tss's own map would need for the same shares (the two describe the same sharings).
+    rnd = random.Random(20260929)
+    drbg["share_map_cases"] = []
+    for (k, t, n, m, w2, w3, stream, dim) in [(3, 1, 8, P, po.P62_OMEGA[8], po.P62_OMEGA[9], 0, 14),
+                                              (3, 4, 8, P, po.P62_OMEGA[8], po.P62_OMEGA[9], 3, 10),
+                                              (8, 2, 26, P, po.P62_OMEGA[16], po.P62_OMEGA[27], 2 ** 40 + 1, 17),
+                                              (8, 7, 26, P, po.P62_OMEGA[16], po.P62_OMEGA[27], 9, 16),
+                                              (3, 4, 8, 433, 354, 150, 1, 7)]:
+        pss = po.PackedSecretSharing(t, n, k, m, w2, w3)
+        B = (dim + k - 1) // k
+        secrets = [rnd.randrange(m) for _ in range(dim)]
+        draws = po.drbg_fill(key, stream, B, t, m)
+        shares = [[] for _ in range(n)]
+        implied = []
+        for b in range(B):
+            batch = secrets[b * k:(b + 1) * k]
+            batch += [0] * (k - len(batch))
+            d = draws[b * t:(b + 1) * t]
+            sh = pss.share_systematic(batch, d)
+            imp = pss.implied_tss_randomness(batch, d)
+            assert sh == pss.share_lagrange(batch, imp) and sh[:t] == d
+            implied += imp
+            for j in range(n):
+                shares[j].append(sh[j])
+        drbg["share_map_cases"].append({"secret_count": k, "privacy_threshold": t, "share_count": n, "modulus": m,
+                                        "omega_secrets": w2, "omega_shares": w3, "stream": stream, "secrets": secrets,
+                                        "draws": draws, "systematic_shares": shares, "implied_tss_randomness": implied})
     with open(os.path.join(OUT, "drbg.json"), "w") as f:
         json.dump({"generator": "tests/golden/gen_golden.py", "provenance": PROV_DRBG, "spec": "sda-drbg-v1 (DESIGN.md)", **drbg}, f, indent=1)
     print("wrote", sorted(x for x in os.listdir(OUT) if x.endswith(".json")))

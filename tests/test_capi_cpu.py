@@ -12,9 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    hdr = open(os.path.join(ROOT, "include", "sda_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return set(re.findall(r"\b(sda_[a-z0-9_]+)\s*\(", hdr))
+    """every function the two headers under include/ declare: the boundary (sda_hip.h) and the test-only knobs (sda_hip_debug.h)"""
+    out = set()
+    for name in ("sda_hip.h", "sda_hip_debug.h"):
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        out |= set(re.findall(r"\b(sda_[a-z0-9_]+)\s*\(", hdr))
+    return out
 
 
 def test_library_exports_every_declared_symbol(built):
@@ -26,7 +30,25 @@ def test_library_exports_every_declared_symbol(built):
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
     exported = set(re.findall(r" T (sda_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.sda_abi_version() == 3 and b"gfx950" in lib.sda_version()
+    assert lib.sda_abi_version() == 4 and b"gfx950" in lib.sda_version()
+
+
+def test_release_library_reads_no_environment_variable(built):
+    """kernel selection of a crypto library is not steered by the process environment: the shipped build has no getenv
+    import at all (the A/B variant, -DSDA_AB_KNOBS, is built by tools/build_ab_variant.sh only), knobs move only through
+    the test-only sda_debug_set_knob, unknown names are refused, and the Python package and the library agree on the version."""
+    import sda_amd
+    from sda_amd import capi
+    lib = capi.load()
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", capi.LIB_PATH], text=True)
+    assert not re.search(r"\bU (secure_)?getenv\b", und), "the release library imports getenv"
+    assert lib.sda_debug_env_knobs_compiled_in() == 0
+    assert lib.sda_debug_set_knob(b"SDA_FORCE_MFMA", 1) == capi.OK
+    lib.sda_debug_reset_knobs()
+    assert lib.sda_debug_set_knob(b"SDA_NO_SUCH_KNOB", 1) == capi.ERR_INVALID_ARGUMENT
+    assert sda_amd.__version__.encode() in lib.sda_version()
+    build_py = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "SDA_AB_KNOBS" not in build_py.split("def smoke")[0].replace("# SDA_AB_KNOBS", "")
 
 
 def test_library_is_gfx950_only_and_links_no_oracle(built):

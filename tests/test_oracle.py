@@ -223,6 +223,37 @@ def test_drbg_spec_c_equals_python_and_golden():
     assert coracle.drbg_fill(key, 3, 300, 2, m).tolist() == po.drbg_fill(key, 3, 300, 2, m)
 
 
+def test_csprng_share_map_c_equals_python_and_golden():
+    """the library's systematic CSPRNG share map (include/sda_hip.h): the C restatement and the big-int one against the
+    committed cases, draws = shares 0..t-1, and the tie to tss's own map - share(secrets, implied randomness) is the same
+    sharing, through the matrix form AND (tss-valid small prime) tss's FFT form."""
+    g = load_golden("drbg.json")
+    key = bytes.fromhex(g["key_hex"])
+    assert len(g["share_map_cases"]) >= 5
+    for c in g["share_map_cases"]:
+        k, t, n, m = c["secret_count"], c["privacy_threshold"], c["share_count"], c["modulus"]
+        w2, w3 = c["omega_secrets"], c["omega_shares"]
+        B = -(-len(c["secrets"]) // k)
+        assert po.drbg_fill(key, c["stream"], B, t, m) == c["draws"]
+        got, implied = coracle.packed_generate_systematic(m, k, t, n, w2, w3, c["secrets"], c["draws"], want_implied=True)
+        assert got.tolist() == c["systematic_shares"] and implied.tolist() == c["implied_tss_randomness"]
+        assert got[:t].T.reshape(-1).tolist() == c["draws"]
+        assert coracle.packed_generate(m, k, t, n, w2, w3, c["secrets"], implied).tolist() == c["systematic_shares"]
+        assert coracle.packed_generate_csprng(m, k, t, n, w2, w3, c["secrets"], c["draws"], 1).tolist() == c["systematic_shares"]
+        pss = po.PackedSecretSharing(t, n, k, m, w2, w3)
+        for b in range(B):
+            batch = c["secrets"][b * k:(b + 1) * k]
+            batch = batch + [0] * (k - len(batch))
+            col = [row[b] for row in c["systematic_shares"]]
+            assert pss.share_systematic(batch, c["draws"][b * t:(b + 1) * t]) == col
+            if m * m < 2 ** 62 and pss.is_fft_shape():                   # tss's own transform form, canonicalised
+                fft = pss.share_fft(batch, c["implied_tss_randomness"][b * t:(b + 1) * t], "rust_signed")
+                assert [x % m for x in fft] == col
+            # any t + k of the shares give the secrets back (first-t direct rows included)
+            idx = list(range(t + k))
+            assert pss.reconstruct_lagrange(idx, [col[i] for i in idx]) == batch
+
+
 def test_synthetic_input_and_baseline_pass():
     a = coracle.fill_synthetic(2, 5, 10, 0x5DA5DA5DA5DA5DA5, P62)
     assert a.tolist() == [[po.synthetic_secret(0x5DA5DA5DA5DA5DA5, 10 + p, i, P62) for i in range(5)] for p in range(2)]

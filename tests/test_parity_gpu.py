@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, set_knob
 
 
 def _free_port():
@@ -248,7 +248,7 @@ def test_packed_generic_path_equals_fast_path(gpu, monkeypatch):
     fast = crypto.ShareGenerator(sch)
     fast.set_drbg_key(KEY)
     a = fast.generate(secrets)
-    monkeypatch.setenv("SDA_FORCE_GENERIC", "1")
+    set_knob("SDA_FORCE_GENERIC", "1")
     slow = crypto.ShareGenerator(sch)
     slow.set_drbg_key(KEY)
     b = slow.generate(secrets)
@@ -281,7 +281,7 @@ def test_transform_share_generation_vs_oracle(gpu, monkeypatch, p, k, t, n, w2, 
     from sda_amd.device import DeviceBuffer
     from oracle import coracle
     if force:
-        monkeypatch.setenv("SDA_FORCE_FFT", "1")
+        set_knob("SDA_FORCE_FFT", "1")
     w2 = w2 or _root(p, k + t + 1)
     w3 = w3 or _root(p, n + 1)
     assert pow(w2, k + t + 1, p) == 1 and pow(w2, (k + t + 1) // 2, p) != 1
@@ -305,7 +305,7 @@ def test_transform_share_generation_vs_oracle(gpu, monkeypatch, p, k, t, n, w2, 
     gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=70)
     out = d_out.to_numpy().reshape(P, n, Bs)
     for q in range(P):
-        w = coracle.packed_generate(p, k, t, n, w2, w3, sec2[q], coracle.drbg_fill(KEY, 70 + q, B, t, p))
+        w = coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec2[q], coracle.drbg_fill(KEY, 70 + q, B, t, p), gen.csprng_share_map())
         assert np.array_equal(out[q, :, :B], w), f"participant {q}"
     # and the round trip: reconstruct from t + k clerks == the secrets
     idx = sorted(rng.choice(n, size=t + k, replace=False).tolist())
@@ -328,7 +328,7 @@ def test_transform_kernel_over_the_shape_space(gpu, monkeypatch, a, b, split):
     kt = m2 - 1
     k = max(1, min(kt, int(round(kt * split))))
     t, n = kt - k, m3 - 1
-    monkeypatch.setenv("SDA_FORCE_FFT", "1")
+    set_knob("SDA_FORCE_FFT", "1")
     w2, w3 = _root(P62, m2), _root(P62, m3)
     rng = np.random.default_rng(a * 100 + b)
     sch = crypto.PackedShamir(k, n, t, P62, w2, w3)
@@ -364,7 +364,8 @@ def test_transform_group_boundaries(gpu, dim):
     gen.generate_batch_dev(d_sec.ptr, P, dim, stride, d_out.ptr, n * Bs, Bs, first_participant=first)
     out = d_out.to_numpy().reshape(P, n, Bs)
     for q in range(P):
-        want = coracle.packed_generate(P62, k, t, n, w2, w3, sec[q, :dim], coracle.drbg_fill(KEY, first + q, B, t, P62))
+        want = coracle.packed_generate_csprng(P62, k, t, n, w2, w3, sec[q, :dim], coracle.drbg_fill(KEY, first + q, B, t, P62),
+                                              gen.csprng_share_map())
         assert np.array_equal(out[q, :, :B], want), f"participant {q}"
     assert not out[:, :, B:].any()
 
@@ -434,6 +435,40 @@ def test_drbg_matches_spec(gpu, case):
     want = np.array(c["values"], dtype=np.int64).reshape(B, T).T
     assert np.array_equal(got[:T], want)
     assert np.array_equal(got[T], np.mod(-want.astype(object).sum(axis=0), m).astype(np.int64))
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_csprng_share_map_golden(gpu, case):
+    """a generator without injected randomness against the committed share-map cases (tests/golden/drbg.json): the draws
+    are shares 0..t-1, the other rows the oracle's interpolation; tss's map with the implied randomness gives the same
+    shares; both maps through host and device entry points."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    g = load_golden("drbg.json")
+    c = g["share_map_cases"][case]
+    k, t, n, m = c["secret_count"], c["privacy_threshold"], c["share_count"], c["modulus"]
+    gen = crypto.ShareGenerator(crypto.PackedShamir(k, n, t, m, c["omega_secrets"], c["omega_shares"]))
+    gen.set_drbg_key(bytes.fromhex(g["key_hex"]))
+    assert gen.csprng_share_map() == gen.SHARE_MAP_SYSTEMATIC
+    secrets = np.array(c["secrets"], dtype=np.int64)
+    want = np.array(c["systematic_shares"], dtype=np.int64)
+    B = want.shape[1]
+    d_sec = DeviceBuffer.from_numpy(secrets)
+    Bs = B + (B & 1)
+    d_out = DeviceBuffer(n * Bs).zero()
+    gen.generate_batch_dev(d_sec.ptr, 1, len(secrets), len(secrets), d_out.ptr, n * Bs, Bs, first_participant=c["stream"])
+    assert np.array_equal(d_out.to_numpy().reshape(n, Bs)[:, :B], want)
+    assert np.array_equal(gen.generate(secrets, np.array(c["implied_tss_randomness"], dtype=np.int64)), want)
+    gen.set_csprng_share_map(gen.SHARE_MAP_TSS_NODES)
+    d_out.zero()
+    gen.generate_batch_dev(d_sec.ptr, 1, len(secrets), len(secrets), d_out.ptr, n * Bs, Bs, first_participant=c["stream"])
+    assert np.array_equal(d_out.to_numpy().reshape(n, Bs)[:, :B],
+                          coracle_generate(m, k, t, n, c["omega_secrets"], c["omega_shares"], secrets, c["draws"]))
+
+
+def coracle_generate(p, k, t, n, w2, w3, secrets, rand):
+    from oracle import coracle
+    return coracle.packed_generate(p, k, t, n, w2, w3, secrets, rand)
 
 
 def test_drbg_rejection_path(gpu):
@@ -520,9 +555,19 @@ def test_packed_generate_drbg_vs_oracle(gpu):
         dim = 3001
         secrets = coracle.fill_synthetic(1, dim, 0, 1, P62)[0]
         B = gen.batch_count(dim)
-        got = gen.generate(secrets)
         rnd = coracle.drbg_fill(KEY, 0, B, t, P62)
-        assert np.array_equal(got, coracle.packed_generate(P62, k, t, n, W[o2], W[o3], secrets, rnd)), (k, t)
+        # the default map of every matrix-form kernel: the draws ARE shares 0..t-1 (include/sda_hip.h "CSPRNG share map") ...
+        assert gen.csprng_share_map() == gen.SHARE_MAP_SYSTEMATIC
+        got = gen.generate(secrets)
+        assert np.array_equal(got[:t], rnd.reshape(B, t).T), (k, t)
+        sysm, implied = coracle.packed_generate_systematic(P62, k, t, n, W[o2], W[o3], secrets, rnd, want_implied=True)
+        assert np.array_equal(got, sysm), (k, t)
+        # ... which is a tss sharing of the same secrets: tss's own map reproduces it from the implied randomness
+        assert np.array_equal(gen.generate(secrets, implied), got), (k, t)
+        # and tss's map on request (the round-3 behaviour; what the transform kernel always does)
+        gen.set_csprng_share_map(gen.SHARE_MAP_TSS_NODES)
+        rnd1 = coracle.drbg_fill(KEY, 1, B, t, P62)                     # the second host call that draws: stream id 1
+        assert np.array_equal(gen.generate(secrets), coracle.packed_generate(P62, k, t, n, W[o2], W[o3], secrets, rnd1)), (k, t)
 
 
 # ---- combiner -----------------------------------------------------------------------------------------
@@ -892,7 +937,7 @@ def test_full_dimension_roundtrip(gpu, shape):
     if shape == "additive_n3":
         want = coracle.additive_generate(P62, n, host_secrets[p], rnd)
     else:
-        want = coracle.packed_generate(P62, k, t, n, sch.omega_secrets, sch.omega_shares, host_secrets[p], rnd)
+        want = coracle.packed_generate_csprng(P62, k, t, n, sch.omega_secrets, sch.omega_shares, host_secrets[p], rnd, gen.csprng_share_map())
     all_shares = shares.to_numpy().reshape(n, P, Bs)
     assert np.array_equal(all_shares[:, p, :B], want)
     assert np.array_equal(S, np.stack([coracle.combine(P62, all_shares[c, :, :B]) for c in range(n)]))
@@ -922,7 +967,8 @@ def test_config5_dimension_16m_vs_oracle(gpu):
     d_sh = DeviceBuffer(n * P * Bs).zero()
     gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_sh.ptr, Bs, P * Bs, first_participant=1000)   # job-major [n][P][Bs]
     got = d_sh.to_numpy().reshape(n, P, Bs)
-    want = [coracle.packed_generate(P62, k, t, n, W[8], W[9], secrets[p], coracle.drbg_fill(KEY, 1000 + p, B, t, P62))
+    assert gen.csprng_share_map() == gen.SHARE_MAP_SYSTEMATIC
+    want = [coracle.packed_generate_systematic(P62, k, t, n, W[8], W[9], secrets[p], coracle.drbg_fill(KEY, 1000 + p, B, t, P62))
             for p in range(P)]
     for p in range(P):
         assert np.array_equal(got[:, p, :B], want[p]), f"participant {p}"
@@ -1002,7 +1048,7 @@ def test_comm_c_abi_single_rank_rccl(gpu, monkeypatch):
     try:
         for force in (False, True):
             if force:
-                monkeypatch.setenv("SDA_FORCE_COLLECTIVES", "1")
+                set_knob("SDA_FORCE_COLLECTIVES", "1")
             for n in (1, 7, 1000, 22369 * 8 + 3):
                 v = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
                 d, o = DeviceBuffer.from_numpy(v), DeviceBuffer(n)
@@ -1096,7 +1142,7 @@ def test_mont64_kernel_equals_limb31_kernel(gpu, monkeypatch):
         sch = crypto.PackedShamir(k, n, t, P62, W[o2], W[o3])
         secrets = rng.integers(-(1 << 63), (1 << 63) - 1, size=4099, dtype=np.int64)
         a = crypto.ShareGenerator(sch); a.set_drbg_key(KEY)
-        monkeypatch.setenv("SDA_FORCE_MONT64", "1")
+        set_knob("SDA_FORCE_MONT64", "1")
         b = crypto.ShareGenerator(sch); b.set_drbg_key(KEY)
         monkeypatch.delenv("SDA_FORCE_MONT64")
         assert np.array_equal(a.generate(secrets), b.generate(secrets))
@@ -1170,7 +1216,7 @@ def test_packed_random_primes_and_roots(gpu, bits):
         sums2 = [comb.combine([shares2[i][c] for i in range(P)]) for c in range(n)]
         assert crypto.SecretReconstructor(sch, dim).reconstruct([(c, sums2[c]) for c in subset]).tolist() == want
         rnd_draws = coracle.drbg_fill(KEY, 0, B, t, p) if t else np.zeros(0, dtype=np.int64)
-        assert np.array_equal(shares2[0], coracle.packed_generate(p, k, t, n, w2, w3, secrets[0], rnd_draws))
+        assert np.array_equal(shares2[0], coracle.packed_generate_csprng(p, k, t, n, w2, w3, secrets[0], rnd_draws, gen.csprng_share_map()))
 
 
 def test_odd_strides_and_unaligned_bases_dev(gpu):
@@ -1308,7 +1354,7 @@ def test_side_stream_pipeline_without_host_synchronisation(gpu):
     want = want.to_numpy()
     for env in ({}, {"SDA_NO_SIDE_STREAM": "1"}):
         for kk, vv in env.items():
-            os.environ[kk] = vv
+            set_knob(kk, vv)
         try:
             gen2 = crypto.ShareGenerator(sch); gen2.set_drbg_key(KEY)
             comb2 = crypto.ShareCombiner(sch)
@@ -1323,7 +1369,7 @@ def test_side_stream_pipeline_without_host_synchronisation(gpu):
             assert np.array_equal(got.to_numpy(), want), env
         finally:
             for kk in env:
-                del os.environ[kk]
+                set_knob(kk, 0)
 
 
 def test_device_entry_points_refuse_bad_arguments(gpu):
@@ -1555,12 +1601,12 @@ def test_limb_gemm_share_generation_vs_oracle(gpu, monkeypatch, k, t, n, dim):
     compiled shape) against the oracle's matrix form: injected randomness with any-i64 secrets (ragged last batch, partial
     64-batch steps, several workgroups per participant), then the device CSPRNG streams of three participants, and the
     round trip through reconstruct."""
-    monkeypatch.setenv("SDA_FORCE_MFMA", "1")
+    set_knob("SDA_FORCE_MFMA", "1")
     _share_gen_vs_oracle(k, t, n, dim)
 
 
 def test_limb31_kernel_serves_8_7_26_when_the_limb_gemm_is_switched_off(gpu, monkeypatch):
-    monkeypatch.setenv("SDA_NO_MFMA", "1")
+    set_knob("SDA_NO_MFMA", "1")
     _share_gen_vs_oracle(8, 7, 26, 8 * 64 * 5 + 3)
 
 
@@ -1600,7 +1646,8 @@ def _share_gen_vs_oracle(k, t, n, dim, w3=None, odd_stride=False):
     gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=(1 << 40) + 5)
     out = d_out.to_numpy().reshape(P, n, Bs)
     for q in range(P):
-        w = coracle.packed_generate(P62, k, t, n, w2, w3, sec2[q], coracle.drbg_fill(KEY, (1 << 40) + 5 + q, B, t, P62))
+        w = coracle.packed_generate_csprng(P62, k, t, n, w2, w3, sec2[q], coracle.drbg_fill(KEY, (1 << 40) + 5 + q, B, t, P62),
+                                           gen.csprng_share_map())
         assert np.array_equal(out[q, :, :B], w), f"participant {q}"
     idx = sorted(rng.choice(n, size=t + k, replace=False).tolist())
     rec = crypto.SecretReconstructor(sch, dim).reconstruct([(i, out[1, i, :B]) for i in idx])

@@ -3,6 +3,8 @@ restatement of integer-encoding 1.0 `VarInt for i64` (sodium.rs:36-41, :83-89). 
 import numpy as np
 import pytest
 
+from conftest import set_knob
+
 pytestmark = pytest.mark.gpu
 P62 = 4611686006577364993
 
@@ -31,7 +33,7 @@ def test_published_vectors(gpu):
 @pytest.fixture(params=["scan", "stream"])
 def decode_path(request, monkeypatch):
     """the two decode forms: three-pass block scan (few rows) and single-pass row streaming (many rows)"""
-    monkeypatch.setenv("SDA_VARINT_PATH", request.param)
+    set_knob("SDA_VARINT_PATH", request.param)
     return request.param
 
 
@@ -207,7 +209,7 @@ def test_row_streaming_decode(gpu, monkeypatch, rows, L, kind, shift):
     stride = L + 3
     got = {}
     for path in ("scan", "stream"):
-        monkeypatch.setenv("SDA_VARINT_PATH", path)
+        set_knob("SDA_VARINT_PATH", path)
         d_dec = DeviceBuffer(rows * stride).zero()
         st = DeviceBuffer(1).zero()
         codec.decode_dev(d_bytes.ptr + shift, len(raw), d_off.ptr, rows, L, d_dec.ptr, stride, st.ptr)
@@ -218,7 +220,7 @@ def test_row_streaming_decode(gpu, monkeypatch, rows, L, kind, shift):
         got[path] = m
     # damaged rows: same verdicts from both forms
     def status(path, raw_b, offs_b, want_len):
-        monkeypatch.setenv("SDA_VARINT_PATH", path)
+        set_knob("SDA_VARINT_PATH", path)
         db = DeviceBuffer.from_numpy(np.frombuffer(raw_b + b"\0" * (-len(raw_b) % 8 or 8), dtype=np.int64))
         do = DeviceBuffer.from_numpy(np.asarray(offs_b, dtype=np.int64))
         st = DeviceBuffer(1).zero()
@@ -273,7 +275,7 @@ def test_wire_format_clerk_sums(gpu, monkeypatch, jobs, rpj, L, kind):
     q = P62
     want = np.stack([coracle.combine(q, np.concatenate([v[j * rpj:(j + 1) * rpj]] * 2)) for j in range(jobs)])
     for path in ("scan", "stream"):
-        monkeypatch.setenv("SDA_VARINT_PATH", path)
+        set_knob("SDA_VARINT_PATH", path)
         comb = crypto.ShareCombiner(crypto.Additive(3, q))
         st = DeviceBuffer(1).zero()
         out = DeviceBuffer(jobs * L)
@@ -288,7 +290,7 @@ def test_wire_format_clerk_sums(gpu, monkeypatch, jobs, rpj, L, kind):
         bad = bytearray(raw); bad[int(offs[rows // 2 + 1]) - 1] |= 0x80
         db = DeviceBuffer.from_numpy(np.frombuffer(bytes(bad) + b"\0" * (-len(raw) % 8 or 8), dtype=np.int64))
         for path in ("scan", "stream"):
-            monkeypatch.setenv("SDA_VARINT_PATH", path)
+            set_knob("SDA_VARINT_PATH", path)
             comb = crypto.ShareCombiner(crypto.Additive(3, q))
             st = DeviceBuffer(1).zero()
             comb.begin_dev(jobs, L)
@@ -397,7 +399,7 @@ def test_whole_pipeline_over_the_wire_format(gpu):
     # a participant's wire bytes are the oracle's encoding of the oracle's shares for the same draws
     sec = secrets.to_numpy().reshape(P, dim)
     rnd = coracle.drbg_fill(KEY, 3, B, t, P62)
-    want = coracle.packed_generate(P62, k, t, n, W8, W9, sec[3], rnd)
+    want = coracle.packed_generate_csprng(P62, k, t, n, W8, W9, sec[3], rnd, gen.csprng_share_map())
     raw = wire.to_numpy().view(np.uint8)
     ln = lens.to_numpy().astype(np.int64).reshape(n, P)
     for c in (0, 5):
@@ -462,7 +464,7 @@ def test_decoders_on_damaged_wire_data(gpu, monkeypatch):
         d_off = DeviceBuffer.from_numpy(offs)
         stride = L + 4
         for path in ("scan", "stream"):
-            monkeypatch.setenv("SDA_VARINT_PATH", path)
+            set_knob("SDA_VARINT_PATH", path)
             guard = np.full((rows + 2, stride), -7, dtype=np.int64)                      # a guard row above and below
             d_out = DeviceBuffer.from_numpy(guard)
             st = DeviceBuffer(1).zero()
