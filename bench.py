@@ -62,12 +62,30 @@ WORKLOADS = {
                      desc="BASELINE config 2: additive 3-way, dim 1048576, 62-bit modulus, 10k participants"),
     "packed_pss728": dict(kind="packed", n=728, k=100, t=155, o2=256, o3=729, participants=10_000, tile_max=500,
                           desc="tss's shipped shape PSS_155_728_100 (k=100, t=155, n=728; transform kernel), dim 1048576, 62-bit prime"),
+    # the reference's own valid domain (tss multiplies i64 residues without widening: p < 2^31.5): the tss-valid shapes over a
+    # 31-bit prime (largest prime = 1 mod 432 below 2^31) and tss's shipped PSS_155_728_100 over ITS prime 746497 with ITS roots
+    "narrow_ref": dict(kind="packed", n=8, k=3, t=4, participants=100_000, prime=2147482801, w2=495332030, w3=1761729792,
+                       desc="reference-valid tss shape t=4 k=3 n=8 over a 31-bit prime (narrow kernels), dim 1048576"),
+    "narrow26_ref": dict(kind="packed", n=26, k=8, t=7, participants=100_000, prime=2147482801, w2=1541819067, w3=638656353,
+                         desc="reference-valid tss shape t=7 k=8 n=26 over a 31-bit prime (narrow kernels), dim 1048576"),
+    "narrow_pss728": dict(kind="packed", n=728, k=100, t=155, participants=10_000, tile_max=500, prime=746497, w2=95660, w3=610121,
+                          desc="tss's shipped PSS_155_728_100 (k=100, t=155, n=728) over tss's own prime 746497 and roots: the "
+                               "uint32_t transform kernel, dim 1048576"),
     # config 5 on ONE GPU: its 100k participants are spread over 8 GPUs (12.5k each); the dimension is what differs, and
     # the reveal over 16 Mi secrets is part of it.  --dim defaults to 16777216 for this workload.
     "packed_dim16m": dict(kind="packed", n=8, k=3, t=1, o2=8, o3=9, participants=12_500, dim=1 << 24, tile_max=125,
                           desc="BASELINE config 5 per-GPU share: packed Shamir t=1 k=3 n=8, dim 16777216, 62-bit prime, Lagrange reveal"),
 }
 TILE_MAX = 2500      # participants resident per launch (secrets 21 GB + two share buffers of 56 GB at config 3)
+
+
+def prime_of(w):
+    return w.get("prime", P62)
+
+
+def roots_of(w):
+    """(omega_secrets, omega_shares) of a packed workload"""
+    return (w["w2"], w["w3"]) if "w2" in w else (OMEGA[w["o2"]], OMEGA[w["o3"]])
 
 
 def plan_steps(target_participants, steps, tile_max):
@@ -88,7 +106,8 @@ def describe(w, dim, participants_total, world):
         shape = f"packed Shamir t={w['t']} k={w['k']} n={w['n']}"
     else:
         shape = f"additive {w['n']}-way"
-    return f"{shape}, dim {dim}, 62-bit prime modulus, {participants_total} participants ({participants_total // world} per GPU)"
+    bits = prime_of(w).bit_length()
+    return f"{shape}, dim {dim}, {bits}-bit prime modulus, {participants_total} participants ({participants_total // world} per GPU)"
 
 
 def algorithmic_bytes_per_element(n, k):
@@ -141,7 +160,7 @@ def cpu_baseline(w, dim, budget_s=10.0, samples=3):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import coracle
     packed = 1 if w["kind"] == "packed" else 0
-    a = (packed, P62, w["n"], w["k"], w["t"], OMEGA[w["o2"]], OMEGA[w["o3"]])
+    a = (packed, prime_of(w), w["n"], w["k"], w["t"], *roots_of(w))
     host = _host_cpu()
     t0 = time.perf_counter()
     coracle.baseline_pass(*a, 1, dim, 0, SEED, KEY)
@@ -235,7 +254,7 @@ class Env:
         # A/B runs (tools/*.sh) and the one-rank RCCL test select non-default kernels by environment variable; the release
         # library reads none, so the bench - a measurement tool - hands them to its test-only entry point (sda_hip_debug.h)
         for name in ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
-                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES"):
+                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW"):
             if os.environ.get(name):
                 v = os.environ[name]
                 capi.check(self.lib.sda_debug_set_knob(name.encode(), int(v) if v.lstrip("-").isdigit() else 1))
@@ -306,14 +325,14 @@ class Env:
                      "devices": [f"{b} (ordinal {o})" for _, b, o in everyone],
                      "comm_device": int(self.lib.sda_comm_device(self.comm)) if self.comm else None}
 
-    def modular_allreduce(self, t):
-        """sum over ranks mod P62 of the int64 device tensor `t`, on every rank (new tensor)"""
+    def modular_allreduce(self, t, q=P62):
+        """sum over ranks mod q of the int64 device tensor `t`, on every rank (new tensor)"""
         torch = self.torch
         if self.use_dist and not self.comm:
             from sda_amd.distributed import modular_allreduce
-            return modular_allreduce(t, P62)
+            return modular_allreduce(t, q)
         out = torch.empty_like(t)
-        self.capi.check(self.lib.sda_modular_allreduce_dev(self.comm, P62, t.data_ptr(), t.numel(), out.data_ptr(),
+        self.capi.check(self.lib.sda_modular_allreduce_dev(self.comm, q, t.data_ptr(), t.numel(), out.data_ptr(),
                                                            torch.cuda.current_stream(self.dev).cuda_stream or None))
         return out
 
@@ -344,8 +363,8 @@ def _setup(env, name, dim, P, row_align, rounds):
     from sda_amd import crypto
     w = WORKLOADS[name]
     n, k, t = w["n"], w["k"], w["t"]
-    scheme = (crypto.PackedShamir(k, n, t, P62, OMEGA[w["o2"]], OMEGA[w["o3"]]) if w["kind"] == "packed"
-              else crypto.Additive(n, P62))
+    scheme = (crypto.PackedShamir(k, n, t, prime_of(w), *roots_of(w)) if w["kind"] == "packed"
+              else crypto.Additive(n, prime_of(w)))
     B = (dim + k - 1) // k
     Bs = (B + row_align - 1) // row_align * row_align      # 128-byte aligned rows (row_align = 16 elements)
     gen = crypto.ShareGenerator(scheme)
@@ -366,26 +385,26 @@ def _share_map_name(gen, w):
             "tss nodes: draws are the values at omega_secrets^(k+1..k+t), n dot products per batch")
 
 
-def _expected_sums(env, secrets, P, dim, firsts):
+def _expected_sums(env, secrets, P, dim, firsts, q=P62):
     """column sums mod p of the secrets the run shared, summed over the ranks: `firsts` = the first participant index of
     every tile THIS rank processed.  One entry repeated K times is the replayed resident tile (no refill needed); distinct
     entries regenerate each tile with the bench's own fill kernel (splitmix64 of (participant, component))."""
     torch, capi, lib, dev = env.torch, env.capi, env.lib, env.dev
     from sda_amd import crypto
-    cs = crypto.ShareCombiner(crypto.Additive(2, P62))
+    cs = crypto.ShareCombiner(crypto.Additive(2, q))
     cs.begin_dev(1, dim)
     resident = None
     for first in firsts:
         if first != resident:
-            capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, first, SEED, P62, None))
+            capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, first, SEED, q, None))
             resident = first
         cs.update_dev(secrets.data_ptr(), 0, P, dim)
     exp = torch.empty(dim, dtype=torch.int64, device=dev)
     cs.finish_dev(exp.data_ptr())
-    return env.modular_allreduce(exp)
+    return env.modular_allreduce(exp, q)
 
 
-def _verify(env, scheme, secrets, total, P, dim, B, firsts):
+def _verify(env, scheme, secrets, total, P, dim, B, firsts, q=P62):
     """size-independent check of the full result: reconstruct(clerk sums over all ranks) == the column sums of every
     secret vector that was shared, mod p.  Also times the reveal (Lagrange reconstruction over `dim` secrets,
     receive.rs:140-152) with HIP events."""
@@ -409,7 +428,7 @@ def _verify(env, scheme, secrets, total, P, dim, B, firsts):
     capi.check(lib.sda_event_elapsed_ms(e0, e1, C.byref(ms)))
     lib.sda_event_destroy(e0); lib.sda_event_destroy(e1)
     reveal_ms = ms.value / reps
-    exp_total = _expected_sums(env, secrets, P, dim, firsts)
+    exp_total = _expected_sums(env, secrets, P, dim, firsts, q)
     torch.cuda.synchronize(dev)
     verified = bool(torch.equal(out, exp_total))
     nrows = len(idx)
@@ -439,7 +458,7 @@ def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, s
         "config": {"workload": describe(w, dim, participants_total, world), "baseline_config": w["desc"], "name": name,
                    "dim": dim, "participants_total": participants_total, "participants_per_step_per_gpu": n_sub * P,
                    "sub_tiles_per_step": n_sub, "tile_participants": P,
-                   "share_count": n, "secret_count": k, "privacy_threshold": t, "modulus": P62,
+                   "share_count": n, "secret_count": k, "privacy_threshold": t, "modulus": prime_of(w),
                    "randomness": f"on-device ChaCha{rounds} (sda-drbg-v1, deterministic bench key)",
                    "csprng_share_map": share_map,
                    "row_stride_elements": Bs, "schedule": schedule,
@@ -525,6 +544,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     torch, capi, lib, dev = env.torch, env.capi, env.lib, env.dev
     rank, world = env.rank, env.world
     w, n, k, t, scheme, B, Bs, gen, comb = _setup(env, name, dim, P, row_align, rounds)
+    q = prime_of(w)
     distinct = inputs == "distinct"
     secrets = [torch.empty((P, dim), dtype=torch.int64, device=dev) for _ in range(2 if distinct else 1)]
     shares = [torch.empty((n, P, Bs), dtype=torch.int64, device=dev) for _ in range(2)]
@@ -539,7 +559,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     def fill(i, stream=None):
         buf = secrets[i % len(secrets)]
         src = first_of(i) if distinct else rank * P
-        capi.check(lib.sda_fill_synthetic_dev(buf.data_ptr(), P, dim, dim, src, SEED, P62, stream))
+        capi.check(lib.sda_fill_synthetic_dev(buf.data_ptr(), P, dim, dim, src, SEED, q, stream))
 
     def launch(i, total, ev=None):
         """launch i of total+1: generate tile i (if i < total), sum tile i-1 (if i > 0)"""
@@ -584,7 +604,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
     sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
-    env.modular_allreduce(sums)                              # connect RCCL outside the timed region, real message size
+    env.modular_allreduce(sums, q)                           # connect RCCL outside the timed region, real message size
     env.barrier()
     t0 = time.perf_counter()
     for i in range(tiles + 1):
@@ -592,7 +612,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     comb.finish_dev(sums.data_ptr())
     torch.cuda.synchronize(dev)
     tx = time.perf_counter()
-    total = env.modular_allreduce(sums)                      # X1: the only exchange step
+    total = env.modular_allreduce(sums, q)                   # X1: the only exchange step
     torch.cuda.synchronize(dev)
     exchange_ms = (time.perf_counter() - tx) * 1e3
     env.barrier()
@@ -608,11 +628,13 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     for e in evs:
         lib.sda_event_destroy(e)
     firsts = [first_of(i) for i in range(tiles)] if distinct else [rank * P] * tiles
-    verified, reveal = _verify(env, scheme, secrets[0], total, P, dim, B, firsts) if verify else (None, None)
+    verified, reveal = _verify(env, scheme, secrets[0], total, P, dim, B, firsts, q) if verify else (None, None)
     gen_b, comb_b = algorithmic_bytes_per_element(n, k)
     per_launch_bytes = P * dim * (gen_b + comb_b)
     gbs = tiles * per_launch_bytes / (sum(launch_ms) * 1e-3) / 1e9
+    narrow = prime_of(w) < (1 << 31) and rounds == 20
     kern = ("fused_additive_kernel" if w["kind"] != "packed" else
+            "fused_packed_n31_kernel" if narrow and w["k"] + w["t"] <= 16 else
             "fused_packed_mfma_kernel" if (w["k"], w["t"]) in MFMA_DEFAULT_SHAPES else
             "fused_packed_l31_kernel" if w["k"] + w["t"] <= 16 else "packed_gen_fft_kernel + combine_update_kernel (no dual-role form)")
     has_dual = w["kind"] != "packed" or w["k"] + w["t"] <= 16
@@ -653,6 +675,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     torch, capi, lib, dev = env.torch, env.capi, env.lib, env.dev
     rank, world = env.rank, env.world
     w, n, k, t, scheme, B, Bs, gen, comb = _setup(env, name, dim, P, row_align, rounds)
+    q = prime_of(w)
     if overlap:
         comb.set_residency(2)            # 8 waves per CU saturate HBM; the rest stay with share generation
     nbuf = 2 if overlap else 1
@@ -663,7 +686,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     else:
         s_gen = s_comb = torch.cuda.current_stream(dev)
     h_gen, h_comb = s_gen.cuda_stream or None, s_comb.cuda_stream or None
-    capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, rank * P, SEED, P62, None))
+    capi.check(lib.sda_fill_synthetic_dev(secrets.data_ptr(), P, dim, dim, rank * P, SEED, q, None))
     torch.cuda.synchronize(dev)
     comb.begin_dev(n, B, h_comb or 0)
     gen_done = [torch.cuda.Event() for _ in range(nbuf)]
@@ -706,7 +729,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
     sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
-    env.modular_allreduce(sums)
+    env.modular_allreduce(sums, q)
     env.barrier()
     t0 = time.perf_counter()
     for i in range(tiles):
@@ -714,7 +737,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     comb.finish_dev(sums.data_ptr(), h_comb or 0)
     torch.cuda.synchronize(dev)
     tx = time.perf_counter()
-    total = env.modular_allreduce(sums)
+    total = env.modular_allreduce(sums, q)
     torch.cuda.synchronize(dev)
     exchange_ms = (time.perf_counter() - tx) * 1e3
     env.barrier()
@@ -728,13 +751,14 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     comb_ms /= tiles
     for e in evs:
         lib.sda_event_destroy(e)
-    verified, reveal = _verify(env, scheme, secrets, total, P, dim, B, [rank * P] * tiles) if verify else (None, None)
+    verified, reveal = _verify(env, scheme, secrets, total, P, dim, B, [rank * P] * tiles, q) if verify else (None, None)
     gen_b, comb_b = algorithmic_bytes_per_element(n, k)
     per_launch = P * dim
     gen_gbs = per_launch * gen_b / (gen_ms * 1e-3) / 1e9
     comb_gbs = per_launch * comb_b / (comb_ms * 1e-3) / 1e9
     dominant_gen = gen_ms >= comb_ms
     gen_kernel = ("additive_gen_kernel" if w["kind"] != "packed" else
+                  "packed_gen_n31_kernel" if prime_of(w) < (1 << 31) and rounds == 20 and w["k"] + w["t"] <= 16 else
                   "packed_gen_mfma_kernel" if (w["k"], w["t"]) in MFMA_DEFAULT_SHAPES else
                   "packed_gen_l31_kernel" if w["k"] + w["t"] <= 32 else "packed_gen_fft_kernel")
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,

@@ -15,6 +15,7 @@
  *   SDA_SIDE_STREAM_WGS n, SDA_SIDE_STREAM_PRIORITY 1 (= high)   side-stream grid and priority
  *   SDA_FFT_G n, SDA_FFT_THREADS n   batches per workgroup / threads of the transform kernel
  *   SDA_VARINT_PATH 1 (stream) / 2 (scan)   pin one varint decode form
+ *   SDA_NO_NARROW 1            primes below 2^31 through the 62-bit kernels too (default: the one-limb narrow kernels)
  *   SDA_FORCE_COLLECTIVES 1    a one-rank communicator still goes through RCCL send/recv to itself
  * Built with -DSDA_AB_KNOBS (tools/build_ab_variant.sh; never by __graft_entry__.build()) an unset knob falls back to the
  * environment variable of the same name. */

@@ -31,10 +31,22 @@
 
 namespace sda {
 
-// x (any 64-bit value) times the constant w < p, given ws = floor(w 2^64 / p) and np = 2^64 - p: congruent to x w, in
+// Two instantiations of one kernel: WIDE (uint64_t values, p < 2^62) and NARROW (uint32_t values, p < 2^30 - the reference's
+// own domain: tss's shipped primes are 20- to 23-bit).  A field value is V, a table entry (w, companion) is W.
+template <typename V> struct FftW;
+template <> struct FftW<uint64_t> { typedef ulonglong2 type; };
+template <> struct FftW<uint32_t> { typedef uint2 type; };
+template <typename V>
+struct FftConst {
+    V p, p2, np;             // modulus, 2p, 2^w - p (w = width of V)
+    V om, oms;               // omega_shares^(m3/3) (a primitive cube root of unity) and its companion
+};
+
+// WIDE.  x (any 64-bit value) times the constant w < p, given ws = floor(w 2^64 / p) and np = 2^64 - p: congruent to x w, in
 // [0, 2p).  q = hi64(x ws); the low 64 bits of x w - q p = x w + q np are ONE pair of accumulating 32 x 32 -> 64 products
 // plus four low products into the high word (16 VALU instructions as compiled, 20 in the plain x * w - q * p form)
-__device__ __forceinline__ uint64_t f_mulS(uint64_t x, uint64_t w, uint64_t ws, uint64_t np) {
+__device__ __forceinline__ uint64_t f_mulS(uint64_t x, uint64_t w, uint64_t ws, const FftConst<uint64_t>& c) {
+    const uint64_t np = c.np;
     const uint64_t q = __umul64hi(x, ws);
     const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
     const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32), n0 = (uint32_t)np, n1 = (uint32_t)(np >> 32);
@@ -51,20 +63,26 @@ __device__ __forceinline__ uint64_t f_csub(uint64_t x, uint64_t m) {
         : "=&v"(lo), "=&v"(hi) : "v"(xl), "v"(xh), "v"(ml), "v"(mh) : "vcc");
     return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t f_red2(uint64_t x, uint64_t p2) { return f_csub(x, p2); }
-
-struct FftConst {
-    uint64_t p, p2, np;      // modulus, 2p, 2^64 - p
-    uint64_t om, oms;        // omega_shares^(m3/3) (a primitive cube root of unity) and its companion
-};
+// NARROW (p < 2^30, so 4p < 2^32: the same lazy ranges in 32 bits).  Shoup product with ws = floor(w 2^32 / p): q = hi32(x ws),
+// x w - q p in the low 32 bits lies in [0, 2p) for ANY 32-bit x - three multiplications and a subtraction (WIDE: 16
+// instructions); the conditional subtraction is a subtraction and an unsigned minimum (x - m wraps exactly when x < m).
+__device__ __forceinline__ uint32_t f_mulS(uint32_t x, uint32_t w, uint32_t ws, const FftConst<uint32_t>& c) {
+    const uint32_t q = __umulhi(x, ws);
+    return x * w - q * c.p;
+}
+__device__ __forceinline__ uint32_t f_csub(uint32_t x, uint32_t m) {
+    const uint32_t d = x - m;
+    return d < x ? d : x;
+}
+template <typename V> __device__ __forceinline__ V f_red2(V x, V p2) { return f_csub(x, p2); }
 
 // radix-3 butterfly on A, B, C in [0, 2p) (B, C already multiplied by their twiddles): y_d = A + w^d B + w^2d C, in [0, 4p)
-__device__ __forceinline__ void f_r3(uint64_t A, uint64_t Bv, uint64_t Cv, const FftConst& c, uint64_t& y0, uint64_t& y1,
-                                     uint64_t& y2) {
-    const uint64_t w = f_mulS(Bv + c.p2 - Cv, c.om, c.oms, c.np);    // w (B - C); w^2 = -1 - w
-    y0 = f_red2(A + Bv, c.p2) + Cv;
-    y1 = f_red2(A + c.p2 - Cv, c.p2) + w;                            // A - C + w (B - C)
-    y2 = f_red2(A + c.p2 - Bv, c.p2) + (c.p2 - w);                   // A - B - w (B - C)
+template <typename V>
+__device__ __forceinline__ void f_r3(V A, V Bv, V Cv, const FftConst<V>& c, V& y0, V& y1, V& y2) {
+    const V w = f_mulS((V)(Bv + c.p2 - Cv), c.om, c.oms, c);          // w (B - C); w^2 = -1 - w
+    y0 = f_red2((V)(A + Bv), c.p2) + Cv;
+    y1 = f_red2((V)(A + c.p2 - Cv), c.p2) + w;                        // A - C + w (B - C)
+    y2 = f_red2((V)(A + c.p2 - Bv), c.p2) + (c.p2 - w);               // A - B - w (B - C)
 }
 
 __device__ __forceinline__ uint32_t f_bitrev(uint32_t i, uint32_t bits) { return bits ? __brev(i) >> (32 - bits) : 0u; }
@@ -100,28 +118,31 @@ __device__ __noinline__ uint64_t f_drbg_retry(uint32_t k0, uint32_t k1, uint32_t
 }
 
 // TWL: the twiddle tables (with their companions) are copied to LDS; otherwise they are read from global memory
-template <int ROUNDS, bool TWL>
+template <int ROUNDS, bool TWL, typename V>
 __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, FftPlan F, uint64_t groups, uint64_t batches) {
-    extern __shared__ __align__(16) uint64_t lds[];
+    typedef typename FftW<V>::type W;
+    extern __shared__ __align__(16) uint64_t lds_raw[];
+    V* lds = reinterpret_cast<V*>(lds_raw);
     const uint32_t T = blockDim.x, tid = threadIdx.x;
     const uint64_t p = blockIdx.x / groups, g = blockIdx.x - p * groups;
     const uint32_t G = F.G, m2 = F.m2, m3 = F.m3, k = F.k, t = F.t;
     // LDS: [twiddles of the radix-3 part | twiddles of the radix-2 part |] X [G][m2] | Y [G][m3]
-    const ulonglong2* tw3 = TWL ? reinterpret_cast<const ulonglong2*>(lds) : reinterpret_cast<const ulonglong2*>(F.tw3);
-    const ulonglong2* tw2 = TWL ? reinterpret_cast<const ulonglong2*>(lds) + m3 : reinterpret_cast<const ulonglong2*>(F.tw2);
-    uint64_t* X = lds + (TWL ? 2 * ((size_t)m3 + (m2 >> 1)) : 0);   // secret-node values / coefficients
-    uint64_t* Y = X + (size_t)G * m2;                               // share-point values
-    FftConst c;
-    c.p = mod.m; c.p2 = 2 * mod.m; c.np = 0 - mod.m; c.om = F.omega; c.oms = F.omega_s;
+    const W* tw3 = TWL ? reinterpret_cast<const W*>(lds) : reinterpret_cast<const W*>(F.tw3);
+    const W* tw2 = TWL ? reinterpret_cast<const W*>(lds) + m3 : reinterpret_cast<const W*>(F.tw2);
+    V* X = lds + (TWL ? 2 * ((size_t)m3 + (m2 >> 1)) : 0);          // secret-node values / coefficients
+    V* Y = X + (size_t)G * m2;                                      // share-point values
+    FftConst<V> c;
+    c.p = (V)mod.m; c.p2 = (V)(2 * mod.m); c.np = (V)((V)0 - (V)mod.m); c.om = (V)F.omega; c.oms = (V)F.omega_s;
+    const V scale = (V)F.scale, scale_s = (V)F.scale_s;
     const int64_t* sp = L.secrets + p * L.secrets_stride;
     const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
     const uint64_t stream = L.first_participant + p;
     const uint64_t b_first = g * G;
 
     if (TWL) {
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(lds);
-        const ulonglong2* s3 = reinterpret_cast<const ulonglong2*>(F.tw3);
-        const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(F.tw2);
+        W* dst = reinterpret_cast<W*>(lds);
+        const W* s3 = reinterpret_cast<const W*>(F.tw3);
+        const W* s2 = reinterpret_cast<const W*>(F.tw2);
         for (uint32_t u = tid; u < m3; u += T) dst[u] = s3[u];
         for (uint32_t u = tid; u < (m2 >> 1); u += T) dst[m3 + u] = s2[u];
     }
@@ -135,13 +156,13 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
             const uint64_t e = b * k + (i - 1);
             if (b < batches && e < L.len) v = canon_i64(sp[e], mod.m, mod.mu);
         }
-        X[(size_t)j * m2 + i] = v;
+        X[(size_t)j * m2 + i] = (V)v;
     }
     if (rp) {
         for (uint32_t u = tid; u < G * t; u += T) {
             const uint32_t j = f_div(u, t, F.magic_t), i = u - j * t;
             const uint64_t b = b_first + j;
-            X[(size_t)j * m2 + 1 + k + i] = b < batches ? canon_i64(rp[b * t + i], mod.m, mod.mu) : 0;
+            X[(size_t)j * m2 + 1 + k + i] = (V)(b < batches ? canon_i64(rp[b * t + i], mod.m, mod.mu) : 0);
         }
     } else if (G >= 8) {                      // one CSPRNG block serves draw i of 8 consecutive batches; G / 8 such blocks of 8
         const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
@@ -157,7 +178,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 uint64_t val;
                 if (!lemire_sample(xw, mod.m, mod.lemire_thr, val))
                     val = f_drbg_retry<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, (b_first + 8u * nb + jj) * (uint64_t)t + i, mod.m, mod.lemire_thr);
-                X[(size_t)(8u * nb + jj) * m2 + 1 + k + i] = val;
+                X[(size_t)(8u * nb + jj) * m2 + 1 + k + i] = (V)val;
             }
         }
     } else {                                  // G = 1, 2, 4 batches of ONE block group of 8: each block serves G of its 8 word pairs
@@ -178,7 +199,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 uint64_t val;
                 if (!lemire_sample(((uint64_t)hi << 32) | lo, mod.m, mod.lemire_thr, val))
                     val = f_drbg_retry<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, (b_first + jj) * (uint64_t)t + i, mod.m, mod.lemire_thr);
-                X[(size_t)jj * m2 + 1 + k + i] = val;
+                X[(size_t)jj * m2 + 1 + k + i] = (V)val;
             }
         }
     }
@@ -191,11 +212,11 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
         const uint32_t h = mblk >> 1;
         for (uint32_t u = tid; u < G * h; u += T) {
             const uint32_t j = u >> (lg - 1), jj = u & (h - 1);
-            uint64_t* x = X + (size_t)j * m2 + jj;
-            const uint64_t av = x[0], bv = x[h];
-            const ulonglong2 w = tw2[jj];
+            V* x = X + (size_t)j * m2 + jj;
+            const V av = x[0], bv = x[h];
+            const W w = tw2[jj];
             x[0] = f_red2(av + bv, c.p2);
-            x[h] = f_mulS(av + c.p2 - bv, w.x, w.y, c.np);                  // the table's entry 0 is 1 with its companion
+            x[h] = f_mulS(av + c.p2 - bv, w.x, w.y, c);                  // the table's entry 0 is 1 with its companion
         }
         __syncthreads();
         mblk >>= 1; --lg;
@@ -206,19 +227,19 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
         for (uint32_t u = tid; u < G * items; u += T) {
             const uint32_t j = u >> (F.a - 2), i = u & (items - 1);
             const uint32_t blk = i >> (lg - 2), jj = i & (qd - 1);
-            uint64_t* x = X + (size_t)j * m2 + (size_t)blk * mblk + jj;
-            const uint64_t x0 = x[0], x1 = x[qd], x2 = x[2 * qd], x3 = x[3 * qd];
+            V* x = X + (size_t)j * m2 + (size_t)blk * mblk + jj;
+            const V x0 = x[0], x1 = x[qd], x2 = x[2 * qd], x3 = x[3 * qd];
             // level with blocks of mblk: (x0, x2) and (x1, x3), twiddles w^jj and w^(jj + qd)
-            const uint64_t a0 = f_red2(x0 + x2, c.p2), a1 = f_red2(x1 + x3, c.p2);
-            const ulonglong2 wb = tw2[(jj + qd) * step];
-            const uint64_t a3 = f_mulS(x1 + c.p2 - x3, wb.x, wb.y, c.np);
-            uint64_t a2, b1, b3;
+            const V a0 = f_red2(x0 + x2, c.p2), a1 = f_red2(x1 + x3, c.p2);
+            const W wb = tw2[(jj + qd) * step];
+            const V a3 = f_mulS(x1 + c.p2 - x3, wb.x, wb.y, c);
+            V a2, b1, b3;
             if (qd > 1) {
-                const ulonglong2 wa = tw2[jj * step], wc = tw2[2 * jj * step];
-                a2 = f_mulS(x0 + c.p2 - x2, wa.x, wa.y, c.np);
+                const W wa = tw2[jj * step], wc = tw2[2 * jj * step];
+                a2 = f_mulS(x0 + c.p2 - x2, wa.x, wa.y, c);
                 // level with blocks of mblk / 2: (a0, a1) and (a2, a3), twiddle (w^2)^jj
-                b1 = f_mulS(a0 + c.p2 - a1, wc.x, wc.y, c.np);
-                b3 = f_mulS(a2 + c.p2 - a3, wc.x, wc.y, c.np);
+                b1 = f_mulS(a0 + c.p2 - a1, wc.x, wc.y, c);
+                b3 = f_mulS(a2 + c.p2 - a3, wc.x, wc.y, c);
             } else {                                                        // the last pass: jj = 0, those twiddles are 1
                 a2 = f_red2(x0 + c.p2 - x2, c.p2);
                 b1 = f_red2(a0 + c.p2 - a1, c.p2);
@@ -241,17 +262,17 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
     for (uint32_t u = tid; u < G * ninth; u += T) {
         const uint32_t j = f_div(u, ninth, magic_ninth), q = u - j * ninth;
         const uint32_t r = f_trirev(q, F.b - 2);
-        const uint64_t* xj = X + (size_t)j * m2;
-        uint64_t v[3][3];                                                  // [e1][d]: level-1 outputs
+        const V* xj = X + (size_t)j * m2;
+        V v[3][3];                                                  // [e1][d]: level-1 outputs
 #pragma unroll
         for (int e1 = 0; e1 < 3; ++e1) {
-            uint64_t in[3];
+            V in[3];
 #pragma unroll
             for (int e0 = 0; e0 < 3; ++e0) {
                 in[e0] = 0;
                 if (nz >> (3 * e0 + e1) & 1u) {                            // uniform: some block has this coefficient
                     const uint32_t ci = r + (uint32_t)e1 * S2 + (uint32_t)e0 * S1;
-                    if (ci < m2) in[e0] = f_mulS(xj[f_bitrev(ci, F.a)], F.scale, F.scale_s, c.np);
+                    if (ci < m2) in[e0] = f_mulS(xj[f_bitrev(ci, F.a)], scale, scale_s, c);
                 }
             }
             if ((nz >> (3 + e1) & 1u) || (nz >> (6 + e1) & 1u)) {          // uniform
@@ -262,14 +283,14 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 v[e1][0] = v[e1][1] = v[e1][2] = in[0];                    // two of three inputs are zero-extension zeros
             }
         }
-        uint64_t* y = Y + (size_t)j * m3 + 9u * q;
+        V* y = Y + (size_t)j * m3 + 9u * q;
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
-            uint64_t Bv = v[1][jj], Cv = v[2][jj];
+            V Bv = v[1][jj], Cv = v[2][jj];
             if (jj) {
-                const ulonglong2 w1 = tw3[jj * ninth], w2 = tw3[2 * jj * ninth];
-                Bv = f_mulS(Bv, w1.x, w1.y, c.np);
-                Cv = f_mulS(Cv, w2.x, w2.y, c.np);
+                const W w1 = tw3[jj * ninth], w2 = tw3[2 * jj * ninth];
+                Bv = f_mulS(Bv, w1.x, w1.y, c);
+                Cv = f_mulS(Cv, w2.x, w2.y, c);
             }
             f_r3(v[0][jj], Bv, Cv, c, y[jj], y[jj + 3], y[jj + 6]);
         }
@@ -284,10 +305,10 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
         for (uint32_t u = tid; u < G * S1; u += T) {
             const uint32_t j = f_div(u, S1, magic_third), q = u - j * S1;
             const uint32_t blk = f_div(q, t3, magic), jj = q - blk * t3;
-            uint64_t* y = Y + (size_t)j * m3 + (size_t)blk * (3 * t3) + jj;
-            const ulonglong2 w1 = tw3[jj * step], w2 = tw3[2 * jj * step];
-            const uint64_t A = f_red2(y[0], c.p2);
-            const uint64_t Bv = f_mulS(y[t3], w1.x, w1.y, c.np), Cv = f_mulS(y[2 * t3], w2.x, w2.y, c.np);
+            V* y = Y + (size_t)j * m3 + (size_t)blk * (3 * t3) + jj;
+            const W w1 = tw3[jj * step], w2 = tw3[2 * jj * step];
+            const V A = f_red2(y[0], c.p2);
+            const V Bv = f_mulS(y[t3], w1.x, w1.y, c), Cv = f_mulS(y[2 * t3], w2.x, w2.y, c);
             f_r3(A, Bv, Cv, c, y[0], y[t3], y[2 * t3]);
         }
         __syncthreads();
@@ -308,26 +329,26 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
             if (last && G > 1) { j = u & (G - 1); q = u >> F.lgG; }
             else { j = f_div(u, ninth, magic_ninth); q = u - j * ninth; }
             const uint32_t blk = f_div(q, t3, magic), jj = q - blk * t3;
-            uint64_t* y = Y + (size_t)j * m3 + (size_t)blk * (9 * t3) + jj;
-            uint64_t a[9], v[9];
+            V* y = Y + (size_t)j * m3 + (size_t)blk * (9 * t3) + jj;
+            V a[9], v[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) a[e] = y[(uint32_t)e * t3];
             {   // level with blocks of 3 t3: the three butterflies share their twiddles
-                const ulonglong2 w1 = tw3[jj * step_a], w2 = tw3[2 * jj * step_a];
+                const W w1 = tw3[jj * step_a], w2 = tw3[2 * jj * step_a];
 #pragma unroll
                 for (int e1 = 0; e1 < 3; ++e1) {
-                    const uint64_t A = f_red2(a[3 * e1], c.p2);
-                    const uint64_t Bv = f_mulS(a[3 * e1 + 1], w1.x, w1.y, c.np), Cv = f_mulS(a[3 * e1 + 2], w2.x, w2.y, c.np);
+                    const V A = f_red2(a[3 * e1], c.p2);
+                    const V Bv = f_mulS(a[3 * e1 + 1], w1.x, w1.y, c), Cv = f_mulS(a[3 * e1 + 2], w2.x, w2.y, c);
                     f_r3(A, Bv, Cv, c, v[3 * e1], v[3 * e1 + 1], v[3 * e1 + 2]);
                 }
             }
-            uint64_t o[9];
+            V o[9];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {   // level with blocks of 9 t3: element jj + d t3 of each third
                 const uint32_t jb = jj + (uint32_t)d * t3;
-                const ulonglong2 w1 = tw3[jb * step_b], w2 = tw3[2 * jb * step_b];
-                const uint64_t A = f_red2(v[d], c.p2);
-                const uint64_t Bv = f_mulS(v[3 + d], w1.x, w1.y, c.np), Cv = f_mulS(v[6 + d], w2.x, w2.y, c.np);
+                const W w1 = tw3[jb * step_b], w2 = tw3[2 * jb * step_b];
+                const V A = f_red2(v[d], c.p2);
+                const V Bv = f_mulS(v[3 + d], w1.x, w1.y, c), Cv = f_mulS(v[6 + d], w2.x, w2.y, c);
                 f_r3(A, Bv, Cv, c, o[d], o[d + 3], o[d + 6]);
             }
             if (!last) {
@@ -341,7 +362,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                     for (int e = 0; e < 9; ++e) {
                         const uint32_t pos = jj + (uint32_t)e * t3;
                         if (pos) {
-                            const int64_t val = (int64_t)f_csub(f_red2(o[e], c.p2), c.p);
+                            const int64_t val = (int64_t)(uint64_t)f_csub(f_red2(o[e], c.p2), c.p);
                             int64_t* dst = op + (size_t)(pos - 1) * L.out_stride_clerk + b;
                             // 64-byte segments (8 batches per row and workgroup): non-temporal.  Fewer batches per workgroup
                             // leave 8- to 32-byte pieces of a line to DIFFERENT workgroups: those must meet in the L2
@@ -362,30 +383,30 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
         const uint32_t sj = u >> F.lgG, jj = u & (G - 1);   // batch fastest: G consecutive values per clerk row
         const uint64_t b = b_first + jj;
         if (b >= batches) continue;
-        const int64_t val = (int64_t)f_csub(f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2), c.p);
+        const int64_t val = (int64_t)(uint64_t)f_csub(f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2), c.p);
         int64_t* dst = op + (size_t)sj * L.out_stride_clerk + b;
         if (G >= 8) __builtin_nontemporal_store(val, dst); else *dst = val;
     }
 }
 
-size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds) {
-    return ((size_t)G * ((size_t)m2 + m3) + (tw_lds ? 2 * ((size_t)m3 + m2 / 2) : 0)) * 8;
+size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds, bool narrow) {
+    return ((size_t)G * ((size_t)m2 + m3) + (tw_lds ? 2 * ((size_t)m3 + m2 / 2) : 0)) * (narrow ? 4 : 8);
 }
 
-hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
-                                      hipStream_t s) {
+template <typename V>
+static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds, hipStream_t s) {
     const uint64_t batches = (L.len + F.k - 1) / F.k;
     const uint64_t groups = (batches + F.G - 1) / F.G;
     if (groups * L.participants == 0) return hipSuccess;
-    const size_t lds = fft_lds_bytes(F.m2, F.m3, F.G, F.tw_lds != 0);
+    const size_t lds = fft_lds_bytes(F.m2, F.m3, F.G, F.tw_lds != 0, sizeof(V) == 4);
     // 512 threads = 4 waves per SIMD with the two workgroups a CU's LDS holds (PSS_155_728_100, round 2: 58 ms per 500 x 1 Mi
     // tile against 66 with 256 threads, 79 with 1024, 120 with 128)
     const long want_threads = knob(KNOB_FFT_THREADS);                           // A/B only
     unsigned threads = (F.G == 1 && F.m3 > 2187) ? 1024u : 512u;
     if (want_threads >= 64 && want_threads <= 1024 && want_threads % 64 == 0) threads = (unsigned)want_threads;
     if (rounds != 20 && rounds != 12 && rounds != 8) return hipErrorInvalidValue;
-    auto kern = F.tw_lds ? (rounds == 20 ? packed_gen_fft_kernel<20, true> : rounds == 12 ? packed_gen_fft_kernel<12, true> : packed_gen_fft_kernel<8, true>)
-                         : (rounds == 20 ? packed_gen_fft_kernel<20, false> : rounds == 12 ? packed_gen_fft_kernel<12, false> : packed_gen_fft_kernel<8, false>);
+    auto kern = F.tw_lds ? (rounds == 20 ? packed_gen_fft_kernel<20, true, V> : rounds == 12 ? packed_gen_fft_kernel<12, true, V> : packed_gen_fft_kernel<8, true, V>)
+                         : (rounds == 20 ? packed_gen_fft_kernel<20, false, V> : rounds == 12 ? packed_gen_fft_kernel<12, false, V> : packed_gen_fft_kernel<8, false, V>);
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     const uint64_t max_blocks = 0x7FFFFFFFull;
@@ -404,6 +425,11 @@ hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, 
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
+}
+
+hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
+                                      hipStream_t s) {
+    return F.narrow ? fft_launch_v<uint32_t>(L, mod, key, F, rounds, s) : fft_launch_v<uint64_t>(L, mod, key, F, rounds, s);
 }
 
 }  // namespace sda

@@ -117,6 +117,7 @@ struct FftPlan {
     uint32_t m3, b;            // n + 1 = 3^b
     uint32_t G, lgG;           // batches per workgroup (a power of two): 16 or 8 (one CSPRNG block per draw serves 8) or 1
     uint32_t tw_lds;           // 1: the workgroup copies both twiddle tables to LDS
+    uint32_t narrow;           // 1: p < 2^30 - uint32_t values, tables of (uint32 w, uint32 floor(w 2^32 / p)) pairs, 32-bit companions below
     uint32_t nz_mask;          // bit 3 e0 + e1: e1 (m3 / 9) + e0 (m3 / 3) < m2, i.e. some 9-block of the zero-extended
                                // vector holds a coefficient at that position (fft_kernels.hip, the folded first two levels)
     const uint64_t* tw2;       // m2 / 2 pairs: omega_secrets^-j              (device)
@@ -125,7 +126,7 @@ struct FftPlan {
     uint64_t scale, scale_s;   // 1 / m2 and its companion
     uint32_t magic_k1, magic_t; // floor(2^32 / d) + 1 for d = k + 1 and d = t (exact quotients of the loader's small indices)
 };
-size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds);
+size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds, bool narrow);
 hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
                                       hipStream_t s);
 

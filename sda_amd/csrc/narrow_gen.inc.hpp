@@ -12,7 +12,7 @@
 //     (S + q p) / 2^32 = hi(S) + mulhi(q, p) + (lo(S) != 0) - the low words cancel, so the carry is known without
 //     forming the 65-bit sum; |result| < GROUP p^2 / 2^34 + p / 2 < p, made canonical with one masked add.
 // Bounds and exactness: tests/test_narrow_model.py (big-int model, extreme operands).  Draws are the same sda-drbg-v1
-// stream (64-bit Lemire sampling), so the oracle's restatement serves both widths; only ROUNDS = 20 is instantiated
+// stream (64-bit Lemire sampling), so one CPU restatement of the stream serves both widths; only ROUNDS = 20 is instantiated
 // (the other round counts exist for A/B runs of the wide kernels).
 //
 // k and t are kernel arguments (KTMAX = 4 / 8 / 12 / 16 bounds k + t); the matrix travels in the kernarg segment as

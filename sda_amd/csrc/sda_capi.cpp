@@ -100,7 +100,8 @@ extern "C" int sda_abi_version(void) { return SDA_HIP_ABI_VERSION; }
 namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
-    "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES"};
+    "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES",
+    "SDA_NO_NARROW"};
 std::atomic<long> g_knobs[sda::KNOB_COUNT];
 }  // namespace
 long sda::knob(sda::Knob k) {
@@ -512,6 +513,11 @@ struct sda_share_generator {
     bool sys = false;                    // ... and the handle has not been switched back (sda_share_generator_set_csprng_share_map)
     MatArg* matarg = nullptr;            // fast path (kernarg copy)
     MatArg* matarg_sys = nullptr;        // the same for Msys
+    // narrow modulus (p < 2^31, the reference's own valid domain for packed Shamir): one 32-bit limb per residue
+    bool n31 = false;
+    N31Params n31p{};
+    MatArg* matarg_n31 = nullptr;        // int32 constants, tss map
+    MatArg* matarg_n31_sys = nullptr;    // int32 constants, systematic map
     bool fast = false;
     bool l31 = false;                    // balanced-31-bit-limb kernel, matrix in the kernarg segment
     bool l31g = false;                   // the same with run-time (k, t) and the matrix in global memory (d_M)
@@ -638,6 +644,31 @@ static int l31_place_matrix(sda_share_generator* g, const std::vector<uint64_t>&
     return SDA_OK;
 }
 
+// Constants of the narrow kernels: centred representatives of M * 2^32 mod p as int32, rows back to back in a MatArg
+static int n31_place_matrix(const std::vector<uint64_t>& Mm, uint64_t p, MatArg*& arg) {
+    arg = new (std::nothrow) MatArg();
+    if (!arg) return fail(SDA_ERR_ALLOC, "out of memory");
+    memset(arg, 0, sizeof(MatArg));
+    int32_t* e = reinterpret_cast<int32_t*>(arg->e);
+    uint64_t inv32;                                                     // 2^-32 mod p: Mm holds M * 2^64
+    if (!h_invmod((1ull << 32) % p, p, inv32)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not odd");
+    for (size_t i = 0; i < Mm.size(); ++i) {
+        const uint64_t mr = h_mulmod(Mm[i], inv32, p);                  // M * 2^32 mod p
+        e[i] = mr > (p - 1) / 2 ? (int32_t)((int64_t)mr - (int64_t)p) : (int32_t)mr;
+    }
+    return SDA_OK;
+}
+static int build_n31(sda_share_generator* g) {
+    const uint64_t p = g->mod.m;
+    uint64_t inv;
+    if (!h_invmod(p, 1ull << 32, inv)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not invertible mod 2^32");
+    g->n31p.p = (uint32_t)p; g->n31p.pinv = (uint32_t)((1ull << 32) - inv); g->n31p.h = (uint32_t)((p + 1) / 2); g->n31p.pad = 0;
+    SDA_TRY(n31_place_matrix(g->Mmont, p, g->matarg_n31));
+    if (g->sys_default) SDA_TRY(n31_place_matrix(g->Msys, p, g->matarg_n31_sys));
+    g->n31 = true;
+    return SDA_OK;
+}
+
 static int build_l31(sda_share_generator* g) {
     SDA_TRY(l31_params(g->mod.m, g->lp));
     SDA_TRY(l31_place_matrix(g, g->Mmont, g->matarg, g->d_M));
@@ -660,7 +691,9 @@ static int l31_params(uint64_t p, L31Params& lp) {
 // tss's transform structure applies when k + t + 1 = 2^a = ord(omega_secrets) and n + 1 = 3^b = ord(omega_shares)
 // (SURVEY.md App. B); the kernel also needs the group's values in LDS (p < 2^62 holds for every modulus the library takes).
 // Two workgroups per CU (80 KB each) when a group of 8 batches fits, with the twiddle tables in LDS too if there is room.
+static bool fft_narrow(uint64_t p) { return p < (1ull << 30) && !knob(KNOB_NO_NARROW); }   // 4p < 2^32: the kernel's lazy ranges in 32 bits
 static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, uint32_t& G, uint32_t& tw_lds) {
+    const bool narrow = fft_narrow(g->mod.m);
     const uint64_t p = g->mod.m, m2 = (uint64_t)g->k + g->t + 1, m3 = (uint64_t)g->n + 1;
     if (p >= (1ull << 62)) return false;
     a = 0; while ((1ull << a) < m2) ++a;
@@ -678,15 +711,17 @@ static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, ui
     // the most batches per workgroup (8, 4, 2, 1: a power of two inside one CSPRNG block group of 8) that still leaves two
     // workgroups per CU, twiddles in LDS when they fit too; a single batch may take the whole CU (PSS_155_19682_100: 157 KB)
     G = 0;
-    for (uint32_t cand = 8; cand >= 1 && !G; cand >>= 1)
+    // narrow values are half the size: 16 batches per workgroup (whole 128-byte lines per clerk row) still leave two workgroups
+    // per CU - PSS_155_728_100 over 746497: 25.5 Gelem/s against 21.0 with 8 (interleaved on one box, profiles/r04/narrow_bench.txt)
+    for (uint32_t cand = narrow ? 16 : 8; cand >= 1 && !G; cand >>= 1)
         for (uint32_t tw = 2; tw-- > 0 && !G;)
-            if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, cand, tw != 0) <= half_cu) { G = cand; tw_lds = tw; }
-    if (!G && fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, false) <= whole_cu) { G = 1; tw_lds = 0; }
+            if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, cand, tw != 0, narrow) <= half_cu) { G = cand; tw_lds = tw; }
+    if (!G && fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, false, narrow) <= whole_cu) { G = 1; tw_lds = 0; }
     if (const long fg = knob(KNOB_FFT_G)) {                               // A/B only: fewer batches per workgroup
         const uint32_t want = (uint32_t)fg;
-        if (want == 1 || want == 2 || want == 4 || want == 8) {
-            if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, true) <= half_cu) { G = want; tw_lds = 1; }
-            else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, false) <= whole_cu) { G = want; tw_lds = 0; }
+        if (want == 1 || want == 2 || want == 4 || want == 8 || want == 16) {
+            if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, true, narrow) <= half_cu) { G = want; tw_lds = 1; }
+            else if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, false, narrow) <= whole_cu) { G = want; tw_lds = 0; }
         }
     }
     return G != 0;
@@ -726,24 +761,38 @@ static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G,
     const uint64_t w2 = h_canon(g->scheme.omega_secrets, p), w3 = h_canon(g->scheme.omega_shares, p);
     uint64_t w2i, m2i;
     if (!h_invmod(w2, p, w2i) || !h_invmod(m2 % p, p, m2i)) return fail(SDA_ERR_INVALID_ARGUMENT, "omega_secrets is not invertible");
-    std::vector<uint64_t> tab(2 * (m3 + m2 / 2));               // [radix-3 twiddles | radix-2 twiddles], (w, companion) pairs
-    uint64_t x = 1;
-    for (uint64_t j = 0; j < m3; ++j) { shoup_pair(x, p, tab[2 * j], tab[2 * j + 1]); x = h_mulmod(x, w3, p); }
-    x = 1;
-    for (uint64_t j = 0; j < m2 / 2; ++j) { shoup_pair(x, p, tab[2 * (m3 + j)], tab[2 * (m3 + j) + 1]); x = h_mulmod(x, w2i, p); }
-    SDA_TRY(g->d_fft.reserve(tab.size() * 8));
-    HIP_TRY(hipMemcpy(g->d_fft.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    const bool narrow = fft_narrow(p);
     FftPlan& F = g->fplan;
+    F.narrow = narrow ? 1u : 0u;
+    if (narrow) {                                               // the same tables as (uint32 w, uint32 floor(w 2^32 / p)) pairs
+        std::vector<uint32_t> tab(2 * (m3 + m2 / 2));
+        uint64_t x = 1;
+        for (uint64_t j = 0; j < m3; ++j) { tab[2 * j] = (uint32_t)x; tab[2 * j + 1] = (uint32_t)((x << 32) / p); x = h_mulmod(x, w3, p); }
+        x = 1;
+        for (uint64_t j = 0; j < m2 / 2; ++j) { tab[2 * (m3 + j)] = (uint32_t)x; tab[2 * (m3 + j) + 1] = (uint32_t)((x << 32) / p); x = h_mulmod(x, w2i, p); }
+        SDA_TRY(g->d_fft.reserve(tab.size() * 4));
+        HIP_TRY(hipMemcpy(g->d_fft.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint64_t> tab(2 * (m3 + m2 / 2));           // [radix-3 twiddles | radix-2 twiddles], (w, companion) pairs
+        uint64_t x = 1;
+        for (uint64_t j = 0; j < m3; ++j) { shoup_pair(x, p, tab[2 * j], tab[2 * j + 1]); x = h_mulmod(x, w3, p); }
+        x = 1;
+        for (uint64_t j = 0; j < m2 / 2; ++j) { shoup_pair(x, p, tab[2 * (m3 + j)], tab[2 * (m3 + j) + 1]); x = h_mulmod(x, w2i, p); }
+        SDA_TRY(g->d_fft.reserve(tab.size() * 8));
+        HIP_TRY(hipMemcpy(g->d_fft.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    }
     F.k = g->k; F.t = g->t; F.n = g->n; F.m2 = (uint32_t)m2; F.a = a; F.m3 = (uint32_t)m3; F.b = b; F.G = G;
-    F.lgG = G == 16 ? 4 : G == 8 ? 3 : G == 4 ? 2 : G == 2 ? 1 : 0;
+    F.lgG = G == 16 ? 4 : G == 8 ? 3 : G == 4 ? 2 : G == 2 ? 1 : 0;      // 16: narrow kernel only (A/B knob SDA_FFT_G)
     F.tw_lds = tw_lds;
     F.nz_mask = 0;
     for (uint32_t e0 = 0; e0 < 3; ++e0)
         for (uint32_t e1 = 0; e1 < 3; ++e1)
             if (e1 * (m3 / 9) + e0 * (m3 / 3) < m2) F.nz_mask |= 1u << (3 * e0 + e1);
-    F.tw3 = g->d_fft.as<uint64_t>(); F.tw2 = g->d_fft.as<uint64_t>() + 2 * m3;
+    F.tw3 = g->d_fft.as<uint64_t>();
+    F.tw2 = narrow ? reinterpret_cast<const uint64_t*>(g->d_fft.as<uint32_t>() + 2 * m3) : g->d_fft.as<uint64_t>() + 2 * m3;
     shoup_pair(h_powmod(w3, m3 / 3, p), p, F.omega, F.omega_s);
     shoup_pair(m2i, p, F.scale, F.scale_s);
+    if (narrow) { F.omega_s = (F.omega << 32) / p; F.scale_s = (F.scale << 32) / p; }
     F.magic_k1 = (uint32_t)(0x100000000ull / ((uint64_t)g->k + 1)) + 1u;                 // k + 1 >= 2
     F.magic_t = g->t > 1 ? (uint32_t)(0x100000000ull / g->t) + 1u : 0u;
     return SDA_OK;
@@ -823,6 +872,11 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
             }
         }
         g->sys = g->sys_default;
+        // a narrow prime (p < 2^31 - everything the reference itself can run) takes the one-limb kernels whenever the shape
+        // fits their run-time (k, t) form; the wide path chosen above stays built (other ChaCha round counts, A/B)
+        const bool forced = knob(KNOB_FORCE_GENERIC) || knob(KNOB_FORCE_MONT64) || knob(KNOB_FORCE_MFMA) || knob(KNOB_FORCE_FFT);
+        if (st == SDA_OK && !g->fft && !forced && !knob(KNOB_NO_NARROW) && packed_n31_path_available(g->k, g->t, g->n, g->mod.m))
+            st = build_n31(g);
     }
     if (st != SDA_OK) { sda_share_generator_free(g); return st; }
     *out = g;
@@ -840,6 +894,8 @@ extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
     g->drbg.wipe();
     delete g->matarg;
     delete g->matarg_sys;
+    delete g->matarg_n31;
+    delete g->matarg_n31_sys;
     delete g;
 }
 
@@ -936,6 +992,10 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
     }
     if (g->additive) {
         HIP_TRY(launch_additive_generate(L, g->n, g->mod, key, g->drbg.rounds, s));
+        return SDA_OK;
+    }
+    if (g->n31 && (d_rand || g->drbg.rounds == 20)) {
+        HIP_TRY(launch_packed_generate_n31(L, g->n, g->k, g->t, g->mod, g->n31p, sys ? *g->matarg_n31_sys : *g->matarg_n31, key, s));
         return SDA_OK;
     }
     if (g->l31) {
@@ -1135,6 +1195,10 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     if (g->additive) {
         he = launch_fused_additive(L, g->n, g->mod, key, g->drbg.rounds, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(),
                                    d_prev, prev_participants, c->jobs, c->dimension, s, &fused);
+    } else if (g->n31 && g->drbg.rounds == 20) {
+        he = launch_fused_packed_n31(L, g->n, g->k, g->t, g->mod, g->n31p, sys ? *g->matarg_n31_sys : *g->matarg_n31, key,
+                                     c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs, c->dimension,
+                                     s, &fused);
     } else if (g->l31) {
         he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds,
                                      c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r03/final/<workload>/{pmc_hbm.json, pmc_sq.json, bench_under_rocprof.json}  ->  profiles/bounds.json:
+"""profiles/rNN/final/<workload>/{pmc_hbm.json, pmc_sq.json, bench_under_rocprof.json}  ->  profiles/bounds.json:
 which ceiling is active for each bench workload's dominant kernel (SURVEY.md 8d "report which bound is active"), read
-by bench.py for `roofline.bound`.     python tools/make_bounds.py profiles/r03/final
+by bench.py for `roofline.bound`.     python tools/make_bounds.py profiles/r04/final
 
 Rule.  "hbm": the HBM bytes the PMC counters saw per launch / the launch's duration (HIP events of the same command) is
 within 10 % of what tools/microbench_hbm reaches with the SAME access pattern and no arithmetic at all (the floor).
@@ -68,7 +68,7 @@ for w in sorted(os.listdir(root)):
             e["bound"] = "hbm" if gbps >= 0.9 * FLOOR[role] else "valu"
         else:
             e["bound"] = "valu" if valu["valu_busy"] > 0.6 else "hbm"
-        e["evidence"] = f"profiles/r03/final/{w}/{{pmc_sq.json,pmc_hbm.json,bench_under_rocprof.json}} (tile {P}, dim {dim}); rule in profiles/bounds.json _note"
+        e["evidence"] = f"{root.rstrip('/')}/{w}/{{pmc_sq.json,pmc_hbm.json,bench_under_rocprof.json}} (tile {P}, dim {dim}); rule in profiles/bounds.json _note"
         entry[role] = e
     for e in entry.values():
         e.pop("_grid", None)

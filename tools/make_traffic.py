@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """profiles/rNN/final/<workload>/{pmc_hbm.json, bench_under_rocprof.json} -> profiles/traffic.json (HBM bytes per launch of the
 dominant kernel, FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide coalesced reads on
-gfx950, WRITE_SIZE as reported) and a summary table on stdout.   python tools/make_traffic.py profiles/r03/final"""
+gfx950, WRITE_SIZE as reported) and a summary table on stdout.   python tools/make_traffic.py profiles/r04/final"""
 import json, os, sys
 
 root = sys.argv[1]
-traffic = {"_note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes, kernel-trace only; tools/profile_r02.sh). "
+traffic = {"_note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes, kernel-trace only; tools/profile_r04.sh). "
                     "FETCH_SIZE (KiB) is doubled as the microarchitecture guide prescribes for wide coalesced 16 B/lane reads on "
                     "gfx950; WRITE_SIZE (KiB) is used as reported (calibrated in round 1 on fill_synthetic_kernel: 16.777 GB written, "
                     "16.777 GB reported). Dual-role kernels: the both-roles launches (the largest grid)."}
