@@ -373,6 +373,17 @@ class ChaChaRng:
         self.buffer: List[int] = []
         self.index = 16
 
+    def set_counter(self, counter_low: int, counter_high: int):
+        """rand 0.3 ``ChaChaRng::set_counter(counter_low: u64, counter_high: u64)`` [recalled]: words 12, 13 = low / high half of
+        counter_low, words 14, 15 = low / high half of counter_high; buffered output is discarded.  The reference never
+        calls it (from_seed starts at 0, chacha.rs:36) - the harness uses it to reach the 2^32 / 2^64 carries of the 128-bit
+        block counter without drawing 256 GB."""
+        self.state[12] = counter_low & MASK32
+        self.state[13] = (counter_low >> 32) & MASK32
+        self.state[14] = counter_high & MASK32
+        self.state[15] = (counter_high >> 32) & MASK32
+        self.index = 16
+
     def _update(self):
         self.buffer = chacha_block(self.state, 20)
         self.index = 0

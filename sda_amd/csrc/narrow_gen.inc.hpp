@@ -118,8 +118,13 @@ __device__ __forceinline__ void packed_gen_n31_body(const GenLayout& L, uint32_t
     }
 }
 
+// Register caps as for the limb-31 kernels (SDA_LB): hipcc's free allocation takes 117 VGPRs (KTMAX = 8) to 151 (16) - it
+// hoists all 2 x KTMAX secret loads to the top - i.e. 4 and 3 waves per SIMD, and the round-4 counters showed these kernels
+// waiting, not computing (narrow26_ref: VALU busy 0.53 at 4.6 wave-instructions per element, 0.71 of the HBM floor): the
+// serial ChaCha20 chains of the t draws need more waves to hide behind.  5 waves (96 VGPRs) up to 8 terms, 4 (128) beyond.
+#define SDA_N31_LB(KTMAX_) __launch_bounds__(kThreads, ((KTMAX_) <= 8 ? 5 : 4))
 template <int KTMAX, int GROUP, int ROUNDS>
-__global__ __launch_bounds__(kThreads) void packed_gen_n31_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t, ModParams mod,
+__global__ SDA_N31_LB(KTMAX) void packed_gen_n31_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t, ModParams mod,
                                                                   N31Params np, MatArg M, DrbgKey key, uint64_t chunks,
                                                                   uint64_t batches, bool vec) {
     packed_gen_n31_body<KTMAX, GROUP, ROUNDS>(L, n, k, t, mod, np, reinterpret_cast<const int32_t*>(&M.e[0]), key, chunks, batches, vec,
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(kThreads) void packed_gen_n31_kernel(GenLayout L, u
 
 // the dual-role launch (share-gen of tile i + clerk-sum of tile i-1 in one grid) for the narrow kernel
 template <int KTMAX, int GROUP, int ROUNDS>
-__global__ __launch_bounds__(kThreads) void fused_packed_n31_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t, ModParams mod,
+__global__ SDA_N31_LB(KTMAX) void fused_packed_n31_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t, ModParams mod,
                                                                     N31Params np, MatArg M, DrbgKey key, uint64_t chunks,
                                                                     uint64_t batches, FuseArgs F) {
     uint64_t idx;

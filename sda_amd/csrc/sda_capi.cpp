@@ -101,7 +101,7 @@ namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
     "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES",
-    "SDA_NO_NARROW"};
+    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU"};
 std::atomic<long> g_knobs[sda::KNOB_COUNT];
 }  // namespace
 long sda::knob(sda::Knob k) {
@@ -1827,7 +1827,9 @@ extern "C" int sda_secret_unmasker_unmask_dev(sda_secret_unmasker_t* u, const in
 
 extern "C" int sda_positive(const int64_t* values, size_t len, int64_t modulus, int64_t* out) {
     if (len && (!values || !out)) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL buffer");
-    for (size_t i = 0; i < len; ++i) out[i] = values[i] < 0 ? values[i] + modulus : values[i];   // receive.rs:15
+    // receive.rs:15 - `if v < 0 { v + modulus } else { v }`, no validation there either; formed in unsigned arithmetic so that a
+    // hostile (value, modulus) pair wraps like release Rust instead of being undefined behaviour here
+    for (size_t i = 0; i < len; ++i) out[i] = values[i] < 0 ? (int64_t)((uint64_t)values[i] + (uint64_t)modulus) : values[i];
     return SDA_OK;
 }
 

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "capi_internal.hpp"
 #include "kernels.hpp"
 #include "sbox_primitives.hpp"
 
@@ -375,7 +376,7 @@ static hipError_t bulk(const uint8_t* d_in, size_t in_slot, size_t in_off, uint8
         const unsigned nr = (unsigned)(rows - r0 < 65535 ? rows - r0 : 65535);
         for (int pass : {first, second}) {
             if (pass == kPassStream && max_msg)
-                sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), 0, s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
+                sbox_stream_kernel<<<dim3((unsigned)sblocks, nr), dim3(kSbThreads), residency_pad_bytes(knob(KNOB_SBOX_WG_PER_CU), 20480), s>>>(d_in, in_slot, in_off, d_out, out_slot, out_off,
                                                                                             d_lens, len_sub, max_msg, d_states, r0);
             if (pass == kPassPoly)
                 sbox_poly_kernel<<<dim3((unsigned)pblocks, nr), dim3(kSbThreads), 0, s>>>(d_ct, ct_slot, ct_off, d_lens, len_sub, max_msg, d_states,

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "capi_internal.hpp"
 #include "kernels.hpp"
 #include "modarith.hpp"
 
@@ -818,7 +819,7 @@ hipError_t launch_varint_stream_decode(const uint8_t* d_bytes, size_t n_bytes, c
 hipError_t launch_varint_stream_encode(const VarintRows& R, uint8_t* d_out, size_t slot_bytes, uint64_t* d_row_bytes,
                                        hipStream_t s) {
     if (R.rows == 0) return hipSuccess;
-    varint_stream_encode_kernel<<<dim3((unsigned)vceil(R.rows, kStreamWaves)), dim3(kStreamWaves * 64), 0, s>>>(
+    varint_stream_encode_kernel<<<dim3((unsigned)vceil(R.rows, kStreamWaves)), dim3(kStreamWaves * 64), residency_pad_bytes(knob(KNOB_WIRE_WG_PER_CU), 8192), s>>>(
         R, d_out, slot_bytes, d_row_bytes);
     return hipGetLastError();
 }
@@ -832,7 +833,7 @@ hipError_t launch_varint_stream_combine(const uint8_t* d_bytes, size_t n_bytes, 
     const uint64_t groups = vceil(rows_per_job, wide ? 16 : 8);
     if (groups * jobs > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
     if (wide)
-        varint_stream_combine_kernel<16><<<dim3((unsigned)(groups * jobs)), dim3(16 * 64), 0, s>>>(
+        varint_stream_combine_kernel<16><<<dim3((unsigned)(groups * jobs)), dim3(16 * 64), residency_pad_bytes(knob(KNOB_WIRE_WG_PER_CU), 49152), s>>>(
             d_bytes, n_bytes, d_offsets, rows_per_job, groups, len, d_acc_lo, d_acc_hi, d_status);
     else
         varint_stream_combine_kernel<8><<<dim3((unsigned)(groups * jobs)), dim3(8 * 64), 0, s>>>(

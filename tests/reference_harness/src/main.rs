@@ -4,6 +4,8 @@
 //!  (i)  `ChaChaRng::from_seed(&seed).gen_range(0_i64, q)` prefixes and the first `next_u64()` - exactly the calls of
 //!       client/src/crypto/masking/chacha.rs:36-39 / :67-69 - for several seeds (2, 4 and 8 words) and moduli, one of them with
 //!       a 25 % rejection rate so that the zone rule is pinned too;
+//!  (i') raw `next_u32()` words after `set_counter` just below 2^32, 2^64 and 2^96 blocks: the carries of the 128-bit block
+//!       counter (words 12..15), which `from_seed` streams only reach after 2^35 masks;
 //!  (ii) for tss's parameter sets: `share(&secrets)` (fresh OsRng randomness inside tss, as in packed_shamir.rs:42) and
 //!       `reconstruct(&subset, &oracle_shares)` (packed_shamir.rs:76) applied to shares THE ORACLE generated - so that
 //!       oracle-reconstruct(tss shares) and tss-reconstruct(oracle shares) both have to give back the secrets: cross-
@@ -18,7 +20,7 @@ extern crate threshold_secret_sharing as tss;
 use rand::{ChaChaRng, Rng, SeedableRng};
 
 mod oracle_inputs;
-use oracle_inputs::{CHACHA_CASES, PSS_CASES};
+use oracle_inputs::{CHACHA_CASES, PSS_CASES, RAW_CASES};
 
 fn ints<T: std::fmt::Debug>(v: &[T]) -> String {
     format!("{:?}", v) // "[1, -2, 3]" is valid JSON for integers
@@ -39,6 +41,21 @@ fn main() {
         chacha.push(format!(
             "{{\"name\": \"{}\", \"seed\": {}, \"modulus\": {}, \"masks\": {}, \"first_next_u64\": {}, \"first_next_u32s\": {}}}",
             case.name, ints(case.seed), case.modulus, ints(&masks), first_u64, ints(&first_u32s)
+        ));
+    }
+
+    // raw keystream words around the carries of the 128-bit block counter (rand 0.3 ChaChaRng::set_counter): the reference
+    // itself always starts at 0 (chacha.rs:36) - this pins the counter layout its long streams would run into
+    let mut raw: Vec<String> = Vec::new();
+    for case in RAW_CASES.iter() {
+        let mut r = ChaChaRng::from_seed(case.seed);
+        if case.counter_low != 0 || case.counter_high != 0 {
+            r.set_counter(case.counter_low, case.counter_high);
+        }
+        let words: Vec<u32> = (0..case.words).map(|_| r.next_u32()).collect();
+        raw.push(format!(
+            "{{\"name\": \"{}\", \"seed\": {}, \"counter_low\": {}, \"counter_high\": {}, \"next_u32s\": {}}}",
+            case.name, ints(case.seed), case.counter_low, case.counter_high, ints(&words)
         ));
     }
 
@@ -75,6 +92,7 @@ fn main() {
     println!(" \"provenance\": \"reference-generated: threshold-secret-sharing 0.2 and rand 0.3, the crates client/Cargo.toml:15,18 names, run by tests/reference_harness (commit its Cargo.lock beside this file)\",");
     println!(" \"generator\": \"tests/reference_harness/src/main.rs\",");
     println!(" \"chacha\": [\n  {}\n ],", chacha.join(",\n  "));
+    println!(" \"raw\": [\n  {}\n ],", raw.join(",\n  "));
     println!(" \"pss\": [\n  {}\n ]", pss_out.join(",\n  "));
     println!("}}");
 }

@@ -51,6 +51,16 @@ def test_release_library_reads_no_environment_variable(built):
     assert "SDA_AB_KNOBS" not in build_py.split("def smoke")[0].replace("# SDA_AB_KNOBS", "")
 
 
+def test_host_side_under_address_and_undefined_behaviour_sanitizers(built):
+    """make -C tests/cpp check-sanitize: the four host translation units of the library rebuilt with
+    -fsanitize=address,undefined, linked with the in-tree kernel objects, and driven through every host-only entry point
+    (scheme sizes, constructors on hostile descriptors, positive(), the SDAJOBv1 parser on 20,000 mutated blobs and every
+    truncation, NULL / short-buffer misuse).  Round 4's first run found a signed overflow in sda_positive."""
+    out = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "check-sanitize"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "host side clean under ASan + UBSan" in out.stdout
+
+
 def test_library_is_gfx950_only_and_links_no_oracle(built):
     from sda_amd import capi
     out = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", capi.LIB_PATH], text=True)

@@ -389,6 +389,14 @@ def check_reference_generated(doc, gen):
         assert c["first_next_u64"] == po.ChaChaRng(seed).next_u64(), name
         r = po.ChaChaRng(seed)
         assert c["first_next_u32s"] == [r.next_u32() for _ in range(4)], name
+    by_name = {c["name"]: c for c in doc["raw"]}
+    for name, seed, lo, hi, words in gen.RAW_CASES:
+        c = by_name[name]
+        assert c["seed"] == seed and c["counter_low"] == lo and c["counter_high"] == hi
+        r = po.ChaChaRng(seed)
+        if lo or hi:
+            r.set_counter(lo, hi)
+        assert c["next_u32s"] == [r.next_u32() for _ in range(words)], name
     by_name = {c["name"]: c for c in doc["pss"]}
     for args in gen.PSS_CASES:
         want = gen.pss_case(*args)
@@ -413,7 +421,12 @@ def _simulated_reference_output(gen):
     """the document the harness WOULD print if the crates behave as the oracle restates them (used to keep the consumer
     above exercised while no machine with cargo has produced the real file)"""
     import random as _r
-    doc = {"provenance": "reference-generated (SIMULATED by the oracle for the consumer's self-test)", "chacha": [], "pss": []}
+    doc = {"provenance": "reference-generated (SIMULATED by the oracle for the consumer's self-test)", "chacha": [], "raw": [], "pss": []}
+    for name, seed, lo, hi, words in gen.RAW_CASES:
+        r = po.ChaChaRng(seed)
+        if lo or hi:
+            r.set_counter(lo, hi)
+        doc["raw"].append({"name": name, "seed": seed, "counter_low": lo, "counter_high": hi, "next_u32s": [r.next_u32() for _ in range(words)]})
     for name, seed, q, count in gen.CHACHA_CASES:
         rng = po.ChaChaRng(seed)
         r = po.ChaChaRng(seed)
@@ -442,6 +455,10 @@ def test_reference_harness_inputs_are_current():
     check_reference_generated(doc, gen)
     bad = json.loads(json.dumps(doc))
     bad["chacha"][5]["masks"][7] ^= 1
+    with pytest.raises(AssertionError):
+        check_reference_generated(bad, gen)
+    bad = json.loads(json.dumps(doc))
+    bad["raw"][1]["next_u32s"][16:32] = doc["raw"][0]["next_u32s"][16:32]             # the block after the carry computed WITHOUT the carry
     with pytest.raises(AssertionError):
         check_reference_generated(bad, gen)
     bad = json.loads(json.dumps(doc))

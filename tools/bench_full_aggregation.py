@@ -20,6 +20,9 @@ from sda_amd.device import DeviceBuffer, DeviceBytes, synchronize  # noqa: E402
 P62 = 4611686006577364993
 W8, W9 = 631229665360524489, 3451275676410824977
 lib = capi.load()
+for _knob in ("SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU"):       # residency caps for the two-stream schedule (include/sda_hip_debug.h)
+    if os.environ.get(_knob):
+        capi.check(lib.sda_debug_set_knob(_knob.encode(), int(os.environ[_knob])))
 k, t, n, dim = 3, 1, 8, 1 << 20
 P, tiles = int(os.environ.get("TILE", "1000")), int(os.environ.get("TILES", "4"))
 sch = crypto.PackedShamir(k, n, t, P62, W8, W9)
