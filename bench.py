@@ -254,7 +254,7 @@ class Env:
         # A/B runs (tools/*.sh) and the one-rank RCCL test select non-default kernels by environment variable; the release
         # library reads none, so the bench - a measurement tool - hands them to its test-only entry point (sda_hip_debug.h)
         for name in ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
-                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW"):
+                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY"):
             if os.environ.get(name):
                 v = os.environ[name]
                 capi.check(self.lib.sda_debug_set_knob(name.encode(), int(v) if v.lstrip("-").isdigit() else 1))
@@ -917,6 +917,11 @@ def main():
                                         "config4_full": {k: c4[k] for k in keep if k in c4},
                                         "config5_full": {k: big[k] for k in keep if k in big},
                                         "packed_pss728": {k: pss[k] for k in keep if k in pss}}
+        # the reference's OWN valid domain (tss multiplies i64 residues without widening): the tss-valid shapes over a 31-bit
+        # prime and tss's shipped PSS_155_728_100 over its own prime 746497, through the narrow (one 32-bit limb) kernels
+        for nm, part, tile in (("narrow_ref", 6000, 1500), ("narrow26_ref", 6000, 1500), ("narrow_pss728", 2000, 500)):
+            r = run(nm, 4, 1, participants=part, tile=tile)
+            line["additional_workloads"][nm] = {k: r[k] for k in keep if k in r}
     if env.world > 1 and not args.no_additional and args.workload == "packed":
         # The two BASELINE configurations that are DEFINED on several GPUs, sharded over the ranks that
         # are here: config 4 = 1,000,000 participants of packed Shamir t=2 k=8 n=26; config 5 = 100,000 participants at

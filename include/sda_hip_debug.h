@@ -16,6 +16,8 @@
  *   SDA_FFT_G n, SDA_FFT_THREADS n   batches per workgroup / threads of the transform kernel
  *   SDA_VARINT_PATH 1 (stream) / 2 (scan)   pin one varint decode form
  *   SDA_NO_NARROW 1            primes below 2^31 through the 62-bit kernels too (default: the one-limb narrow kernels)
+ *   SDA_NO_LAZY 1              narrow transform kernel with the conditional subtractions of the 64-bit form (default: lazy where it fits)
+ *   SDA_WIRE_WG_PER_CU n, SDA_SBOX_WG_PER_CU n   residency caps (unused dynamic LDS) of the varint stream kernels / the XSalsa20 kernel
  *   SDA_FORCE_COLLECTIVES 1    a one-rank communicator still goes through RCCL send/recv to itself
  * Built with -DSDA_AB_KNOBS (tools/build_ab_variant.sh; never by __graft_entry__.build()) an unset knob falls back to the
  * environment variable of the same name. */

@@ -76,13 +76,30 @@ __device__ __forceinline__ uint32_t f_csub(uint32_t x, uint32_t m) {
 }
 template <typename V> __device__ __forceinline__ V f_red2(V x, V p2) { return f_csub(x, p2); }
 
-// radix-3 butterfly on A, B, C in [0, 2p) (B, C already multiplied by their twiddles): y_d = A + w^d B + w^2d C, in [0, 4p)
-template <typename V>
+// radix-3 butterfly on A, B, C (B, C in [0, 2p): already multiplied by their twiddles): y_d = A + w^d B + w^2d C.  A in [0, 2p)
+// gives outputs in [0, 4p).  LAZY (narrow values and (4 b + 4) p < 2^32, b = the number of radix-3 levels: tss's 20- to 23-bit
+// primes): no conditional subtraction at all - every level lets the A chain grow by 4p (B and C always come out of a Shoup
+// product, which takes ANY 32-bit operand and returns [0, 2p)), and the last pass reduces once (tests/test_narrow_model.py)
+template <bool LAZY, typename V>
 __device__ __forceinline__ void f_r3(V A, V Bv, V Cv, const FftConst<V>& c, V& y0, V& y1, V& y2) {
     const V w = f_mulS((V)(Bv + c.p2 - Cv), c.om, c.oms, c);          // w (B - C); w^2 = -1 - w
-    y0 = f_red2((V)(A + Bv), c.p2) + Cv;
-    y1 = f_red2((V)(A + c.p2 - Cv), c.p2) + w;                        // A - C + w (B - C)
-    y2 = f_red2((V)(A + c.p2 - Bv), c.p2) + (c.p2 - w);               // A - B - w (B - C)
+    if constexpr (LAZY) {
+        y0 = A + Bv + Cv;
+        y1 = A + (c.p2 - Cv) + w;
+        y2 = A + (c.p2 - Bv) + (c.p2 - w);
+    } else {
+        y0 = f_red2((V)(A + Bv), c.p2) + Cv;
+        y1 = f_red2((V)(A + c.p2 - Cv), c.p2) + w;                    // A - C + w (B - C)
+        y2 = f_red2((V)(A + c.p2 - Bv), c.p2) + (c.p2 - w);           // A - B - w (B - C)
+    }
+}
+// the A input of a level: [0, 4p) -> [0, 2p), or left to grow (LAZY)
+template <bool LAZY, typename V> __device__ __forceinline__ V f_redA(V x, const FftConst<V>& c) {
+    if constexpr (LAZY) return x; else return f_red2(x, c.p2);
+}
+// any value of the lazy chain -> [0, 2p): a Shoup product by 1 (ones = floor(2^32 / p))
+template <bool LAZY, typename V> __device__ __forceinline__ V f_full2(V x, V ones, const FftConst<V>& c) {
+    if constexpr (LAZY) return f_mulS(x, (V)1, ones, c); else return f_red2(x, c.p2);
 }
 
 __device__ __forceinline__ uint32_t f_bitrev(uint32_t i, uint32_t bits) { return bits ? __brev(i) >> (32 - bits) : 0u; }
@@ -97,6 +114,19 @@ __device__ __forceinline__ uint32_t f_trirev(uint32_t i, uint32_t digits) {
 }
 // exact floor(x / d) for x < 2^16, magic = floor(2^32 / d) + 1 (d > 1), identity for d = 1
 __device__ __forceinline__ uint32_t f_div(uint32_t x, uint32_t d, uint32_t magic) { return d > 1 ? __umulhi(x, magic) : x; }
+
+// Lemire sampling (sda-drbg-v1: accept iff lo64(x m) >= 2^64 mod m, value hi64(x m)) for a modulus below 2^32: the 96-bit
+// product is two 32 x 32 -> 64 multiply-adds instead of a 64 x 64 one
+__device__ __forceinline__ bool f_lemire32(uint64_t x, uint32_t m, uint64_t thr, uint64_t& out) {
+    const uint64_t t0 = (uint64_t)(uint32_t)x * m;
+    const uint64_t t1 = (uint64_t)(uint32_t)(x >> 32) * m + (t0 >> 32);
+    out = t1 >> 32;
+    return ((t1 << 32) | (uint32_t)t0) >= thr;
+}
+template <typename V> __device__ __forceinline__ bool f_lemire(uint64_t x, const ModParams& mod, uint64_t& out) {
+    if constexpr (sizeof(V) == 4) return f_lemire32(x, (uint32_t)mod.m, mod.lemire_thr, out);
+    else return lemire_sample(x, mod.m, mod.lemire_thr, out);
+}
 
 // one uniform value per (stream, batch, draw) - sda-drbg-v1, identical to drbg_pair() of sda_kernels.hip.  The key travels
 // BY VALUE: a by-reference key in this rare path makes every lane park the key in scratch memory at kernel entry
@@ -118,7 +148,7 @@ __device__ __noinline__ uint64_t f_drbg_retry(uint32_t k0, uint32_t k1, uint32_t
 }
 
 // TWL: the twiddle tables (with their companions) are copied to LDS; otherwise they are read from global memory
-template <int ROUNDS, bool TWL, typename V>
+template <int ROUNDS, bool TWL, typename V, bool LAZY>
 __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, FftPlan F, uint64_t groups, uint64_t batches) {
     typedef typename FftW<V>::type W;
     extern __shared__ __align__(16) uint64_t lds_raw[];
@@ -133,7 +163,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
     V* Y = X + (size_t)G * m2;                                      // share-point values
     FftConst<V> c;
     c.p = (V)mod.m; c.p2 = (V)(2 * mod.m); c.np = (V)((V)0 - (V)mod.m); c.om = (V)F.omega; c.oms = (V)F.omega_s;
-    const V scale = (V)F.scale, scale_s = (V)F.scale_s;
+    const V scale = (V)F.scale, scale_s = (V)F.scale_s, ones = (V)F.one_s;
     const int64_t* sp = L.secrets + p * L.secrets_stride;
     const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
     const uint64_t stream = L.first_participant + p;
@@ -176,7 +206,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 const int cc = jj >> 1, e = jj & 1;
                 const uint64_t xw = ((uint64_t)o[8 * e + cc] << 32) | o[8 * e + 4 + cc];
                 uint64_t val;
-                if (!lemire_sample(xw, mod.m, mod.lemire_thr, val))
+                if (!f_lemire<V>(xw, mod, val))
                     val = f_drbg_retry<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, (b_first + 8u * nb + jj) * (uint64_t)t + i, mod.m, mod.lemire_thr);
                 X[(size_t)(8u * nb + jj) * m2 + 1 + k + i] = (V)val;
             }
@@ -197,7 +227,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                     if ((uint32_t)w == want_lo) lo = o[w];
                 }
                 uint64_t val;
-                if (!lemire_sample(((uint64_t)hi << 32) | lo, mod.m, mod.lemire_thr, val))
+                if (!f_lemire<V>(((uint64_t)hi << 32) | lo, mod, val))
                     val = f_drbg_retry<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, (b_first + jj) * (uint64_t)t + i, mod.m, mod.lemire_thr);
                 X[(size_t)jj * m2 + 1 + k + i] = (V)val;
             }
@@ -276,9 +306,9 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 }
             }
             if ((nz >> (3 + e1) & 1u) || (nz >> (6 + e1) & 1u)) {          // uniform
-                f_r3(in[0], in[1], in[2], c, v[e1][0], v[e1][1], v[e1][2]);
+                f_r3<LAZY>(in[0], in[1], in[2], c, v[e1][0], v[e1][1], v[e1][2]);
 #pragma unroll
-                for (int d = 0; d < 3; ++d) v[e1][d] = f_red2(v[e1][d], c.p2);
+                for (int d = 0; d < 3; ++d) v[e1][d] = f_redA<LAZY>(v[e1][d], c);
             } else {
                 v[e1][0] = v[e1][1] = v[e1][2] = in[0];                    // two of three inputs are zero-extension zeros
             }
@@ -291,8 +321,11 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 const W w1 = tw3[jj * ninth], w2 = tw3[2 * jj * ninth];
                 Bv = f_mulS(Bv, w1.x, w1.y, c);
                 Cv = f_mulS(Cv, w2.x, w2.y, c);
+            } else if (LAZY) {                                                // twiddle 1: no product brings them back to [0, 2p)
+                Bv = f_full2<LAZY>(Bv, ones, c);
+                Cv = f_full2<LAZY>(Cv, ones, c);
             }
-            f_r3(v[0][jj], Bv, Cv, c, y[jj], y[jj + 3], y[jj + 6]);
+            f_r3<LAZY>(v[0][jj], Bv, Cv, c, y[jj], y[jj + 3], y[jj + 6]);
         }
     }
     __syncthreads();
@@ -307,9 +340,9 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
             const uint32_t blk = f_div(q, t3, magic), jj = q - blk * t3;
             V* y = Y + (size_t)j * m3 + (size_t)blk * (3 * t3) + jj;
             const W w1 = tw3[jj * step], w2 = tw3[2 * jj * step];
-            const V A = f_red2(y[0], c.p2);
+            const V A = f_redA<LAZY>(y[0], c);
             const V Bv = f_mulS(y[t3], w1.x, w1.y, c), Cv = f_mulS(y[2 * t3], w2.x, w2.y, c);
-            f_r3(A, Bv, Cv, c, y[0], y[t3], y[2 * t3]);
+            f_r3<LAZY>(A, Bv, Cv, c, y[0], y[t3], y[2 * t3]);
         }
         __syncthreads();
         t3 *= 3; --left;
@@ -337,9 +370,9 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                 const W w1 = tw3[jj * step_a], w2 = tw3[2 * jj * step_a];
 #pragma unroll
                 for (int e1 = 0; e1 < 3; ++e1) {
-                    const V A = f_red2(a[3 * e1], c.p2);
+                    const V A = f_redA<LAZY>(a[3 * e1], c);
                     const V Bv = f_mulS(a[3 * e1 + 1], w1.x, w1.y, c), Cv = f_mulS(a[3 * e1 + 2], w2.x, w2.y, c);
-                    f_r3(A, Bv, Cv, c, v[3 * e1], v[3 * e1 + 1], v[3 * e1 + 2]);
+                    f_r3<LAZY>(A, Bv, Cv, c, v[3 * e1], v[3 * e1 + 1], v[3 * e1 + 2]);
                 }
             }
             V o[9];
@@ -347,9 +380,9 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
             for (int d = 0; d < 3; ++d) {   // level with blocks of 9 t3: element jj + d t3 of each third
                 const uint32_t jb = jj + (uint32_t)d * t3;
                 const W w1 = tw3[jb * step_b], w2 = tw3[2 * jb * step_b];
-                const V A = f_red2(v[d], c.p2);
+                const V A = f_redA<LAZY>(v[d], c);
                 const V Bv = f_mulS(v[3 + d], w1.x, w1.y, c), Cv = f_mulS(v[6 + d], w2.x, w2.y, c);
-                f_r3(A, Bv, Cv, c, o[d], o[d + 3], o[d + 6]);
+                f_r3<LAZY>(A, Bv, Cv, c, o[d], o[d + 3], o[d + 6]);
             }
             if (!last) {
 #pragma unroll
@@ -362,7 +395,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
                     for (int e = 0; e < 9; ++e) {
                         const uint32_t pos = jj + (uint32_t)e * t3;
                         if (pos) {
-                            const int64_t val = (int64_t)(uint64_t)f_csub(f_red2(o[e], c.p2), c.p);
+                            const int64_t val = (int64_t)(uint64_t)f_csub(f_full2<LAZY>(o[e], ones, c), c.p);
                             int64_t* dst = op + (size_t)(pos - 1) * L.out_stride_clerk + b;
                             // 64-byte segments (8 batches per row and workgroup): non-temporal.  Fewer batches per workgroup
                             // leave 8- to 32-byte pieces of a line to DIFFERENT workgroups: those must meet in the L2
@@ -383,7 +416,7 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
         const uint32_t sj = u >> F.lgG, jj = u & (G - 1);   // batch fastest: G consecutive values per clerk row
         const uint64_t b = b_first + jj;
         if (b >= batches) continue;
-        const int64_t val = (int64_t)(uint64_t)f_csub(f_red2(Y[(size_t)jj * m3 + sj + 1], c.p2), c.p);
+        const int64_t val = (int64_t)(uint64_t)f_csub(f_full2<LAZY>(Y[(size_t)jj * m3 + sj + 1], ones, c), c.p);
         int64_t* dst = op + (size_t)sj * L.out_stride_clerk + b;
         if (G >= 8) __builtin_nontemporal_store(val, dst); else *dst = val;
     }
@@ -393,7 +426,7 @@ size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds, bool nar
     return ((size_t)G * ((size_t)m2 + m3) + (tw_lds ? 2 * ((size_t)m3 + m2 / 2) : 0)) * (narrow ? 4 : 8);
 }
 
-template <typename V>
+template <typename V, bool LAZY>
 static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds, hipStream_t s) {
     const uint64_t batches = (L.len + F.k - 1) / F.k;
     const uint64_t groups = (batches + F.G - 1) / F.G;
@@ -405,8 +438,8 @@ static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const D
     unsigned threads = (F.G == 1 && F.m3 > 2187) ? 1024u : 512u;
     if (want_threads >= 64 && want_threads <= 1024 && want_threads % 64 == 0) threads = (unsigned)want_threads;
     if (rounds != 20 && rounds != 12 && rounds != 8) return hipErrorInvalidValue;
-    auto kern = F.tw_lds ? (rounds == 20 ? packed_gen_fft_kernel<20, true, V> : rounds == 12 ? packed_gen_fft_kernel<12, true, V> : packed_gen_fft_kernel<8, true, V>)
-                         : (rounds == 20 ? packed_gen_fft_kernel<20, false, V> : rounds == 12 ? packed_gen_fft_kernel<12, false, V> : packed_gen_fft_kernel<8, false, V>);
+    auto kern = F.tw_lds ? (rounds == 20 ? packed_gen_fft_kernel<20, true, V, LAZY> : rounds == 12 ? packed_gen_fft_kernel<12, true, V, LAZY> : packed_gen_fft_kernel<8, true, V, LAZY>)
+                         : (rounds == 20 ? packed_gen_fft_kernel<20, false, V, LAZY> : rounds == 12 ? packed_gen_fft_kernel<12, false, V, LAZY> : packed_gen_fft_kernel<8, false, V, LAZY>);
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     const uint64_t max_blocks = 0x7FFFFFFFull;
@@ -429,7 +462,8 @@ static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const D
 
 hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
                                       hipStream_t s) {
-    return F.narrow ? fft_launch_v<uint32_t>(L, mod, key, F, rounds, s) : fft_launch_v<uint64_t>(L, mod, key, F, rounds, s);
+    if (!F.narrow) return fft_launch_v<uint64_t, false>(L, mod, key, F, rounds, s);
+    return F.lazy ? fft_launch_v<uint32_t, true>(L, mod, key, F, rounds, s) : fft_launch_v<uint32_t, false>(L, mod, key, F, rounds, s);
 }
 
 }  // namespace sda

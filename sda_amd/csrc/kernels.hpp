@@ -117,6 +117,8 @@ struct FftPlan {
     uint32_t m3, b;            // n + 1 = 3^b
     uint32_t G, lgG;           // batches per workgroup (a power of two): 16 or 8 (one CSPRNG block per draw serves 8) or 1
     uint32_t tw_lds;           // 1: the workgroup copies both twiddle tables to LDS
+    uint32_t lazy;             // 1 (narrow only): (4 b + 4) p < 2^32 - the radix-3 levels run without conditional subtractions
+    uint64_t one_s;            // floor(2^32 / p): the companion of the constant 1 (narrow: full reduction of a lazy value)
     uint32_t narrow;           // 1: p < 2^30 - uint32_t values, tables of (uint32 w, uint32 floor(w 2^32 / p)) pairs, 32-bit companions below
     uint32_t nz_mask;          // bit 3 e0 + e1: e1 (m3 / 9) + e0 (m3 / 3) < m2, i.e. some 9-block of the zero-extended
                                // vector holds a coefficient at that position (fft_kernels.hip, the folded first two levels)

@@ -101,7 +101,7 @@ namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
     "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES",
-    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU"};
+    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY"};
 std::atomic<long> g_knobs[sda::KNOB_COUNT];
 }  // namespace
 long sda::knob(sda::Knob k) {
@@ -793,6 +793,8 @@ static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G,
     shoup_pair(h_powmod(w3, m3 / 3, p), p, F.omega, F.omega_s);
     shoup_pair(m2i, p, F.scale, F.scale_s);
     if (narrow) { F.omega_s = (F.omega << 32) / p; F.scale_s = (F.scale << 32) / p; }
+    F.one_s = narrow ? (1ull << 32) / p : 0;
+    F.lazy = narrow && (4ull * b + 4) * p < (1ull << 32) && !knob(KNOB_NO_LAZY) ? 1u : 0u;
     F.magic_k1 = (uint32_t)(0x100000000ull / ((uint64_t)g->k + 1)) + 1u;                 // k + 1 >= 2
     F.magic_t = g->t > 1 ? (uint32_t)(0x100000000ull / g->t) + 1u : 0u;
     return SDA_OK;

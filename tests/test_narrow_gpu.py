@@ -120,10 +120,11 @@ def test_narrow_transform_kernel_vs_oracle_and_wide(gpu, p, k, t, n, w2, w3, dim
     secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
     sec2 = rng.integers(0, p, size=(2, dim), dtype=np.int64)
     results = []
-    for narrow in (True, False):
+    for narrow in (True, "no_lazy", False):                                 # lazy radix-3 levels (default where (4b+4)p < 2^32), reduced, wide
         if k + t <= 32:
             set_knob("SDA_FORCE_FFT", 1)
         set_knob("SDA_NO_NARROW", 0 if narrow else 1)
+        set_knob("SDA_NO_LAZY", 1 if narrow == "no_lazy" else 0)
         sch = crypto.PackedShamir(k, n, t, p, w2, w3)
         gen = crypto.ShareGenerator(sch)
         assert gen.csprng_share_map() == gen.SHARE_MAP_TSS_NODES           # the transform kernel's draws are tss's nodes
@@ -141,4 +142,4 @@ def test_narrow_transform_kernel_vs_oracle_and_wide(gpu, p, k, t, n, w2, w3, dim
             w = coracle.packed_generate(p, k, t, n, w2, w3, sec2[q], coracle.drbg_fill(KEY, 70 + q, B, t, p))
             assert np.array_equal(o[q, :, :B], w), (narrow, q)
         results.append(o.copy())
-    assert np.array_equal(results[0], results[1])
+    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])

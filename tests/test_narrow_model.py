@@ -124,3 +124,50 @@ def test_narrow_shoup_product_and_butterfly_ranges(p):
         for y in (y0, y1, y2):
             assert 0 <= y < 4 * p <= M
         assert y0 % p == (A + B + C) % p and y1 % p == (A - C + om * (B - C)) % p and y2 % p == (A - B - om * (B - C)) % p
+
+
+@pytest.mark.parametrize("p,b", [(433, 2), (746497, 6), (5038849, 9), ((1 << 26) - 5, 6), (104857601, 9)])
+def test_lazy_radix3_levels_never_wrap(p, b):
+    """LAZY mode of the narrow transform kernel (fft_kernels.hip, (4 b + 4) p < 2^32): no conditional subtraction in any of
+    the b radix-3 levels; the A chain grows by at most 4p per level from 2p, B and C always come out of a Shoup product
+    (any 32-bit operand -> [0, 2p)), the last pass reduces once with the companion of 1.  Worst-case and random chains."""
+    M = 1 << 32
+    assert (4 * b + 4) * p < M
+    rnd = random.Random(p + b)
+    ones = M // p
+
+    def shoup(x, w):
+        assert 0 <= x < M
+        ws = (w << 32) // p
+        r = (x * w - ((x * ws) >> 32) * p) % M
+        assert r == x * w - ((x * ws) >> 32) * p and 0 <= r < 2 * p
+        return r
+
+    p2 = 2 * p
+    for trial in range(400):
+        worst = trial < 8
+        A = p2 - 1 if worst else rnd.randrange(p2)
+        true = A % p
+        bound = p2
+        om = rnd.randrange(1, p)
+        for level in range(b):
+            # B and C are arbitrary earlier values of the chain (< the current bound) times twiddles
+            xb, xc = (bound - 1 if worst else rnd.randrange(bound)), (bound - 1 if worst else rnd.randrange(bound))
+            wb, wc = rnd.randrange(p), rnd.randrange(p)
+            B, C = shoup(xb, wb), shoup(xc, wc)
+            if worst:
+                B, C = (p2 - 1, 0) if level & 1 else (0, p2 - 1)
+                xb, wb, xc, wc = B, 1, C, 1
+            w = shoup(B + p2 - C, om)
+            y = [A + B + C, A + (p2 - C) + w, A + (p2 - B) + (p2 - w)]
+            bound += 4 * p
+            assert all(0 <= v < bound <= M for v in y)
+            want = [(true + xb * wb + xc * wc) % p, (true - xc * wc + om * (xb * wb - xc * wc)) % p,
+                    (true - xb * wb - om * (xb * wb - xc * wc)) % p]
+            assert [v % p for v in y] == want
+            pick = rnd.randrange(3) if not worst else max(range(3), key=lambda i: y[i])
+            A, true = y[pick], want[pick]
+        full = (A - ((A * ones) >> 32) * p) % M                       # f_full2: the Shoup product by 1
+        assert 0 <= full < p2 and full % p == true
+        d = (full - p) % M
+        assert (d if d < full else full) == true
