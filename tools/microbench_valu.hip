@@ -70,6 +70,11 @@ __global__ __launch_bounds__(256) void bench(uint32_t* out, uint32_t seed) {
             if (OP == 46) asm volatile("v_subb_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b[i]) : "vcc");
             if (OP == 47) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w[i]) : "s"(mask64));
             if (OP == 48) asm volatile("v_cmp_ge_u64 vcc, %0, %1\n\tv_cndmask_b32 %2, %2, %3, vcc" : : "v"(w[i]), "v"(w[(i+1)%CHAINS]), "v"(a[i]), "v"(b[i]) : "vcc");
+            if (OP == 49) asm volatile("v_alignbyte_b32 %0, %0, %0, 2" : "+v"(a[i]));
+            if (OP == 50) asm volatile("v_perm_b32 %0, %0, %0, %1" : "+v"(a[i]) : "s"(seed));
+            if (OP == 51) asm volatile("v_add_u32 %0, %0, %1\n\tv_xor_b32 %2, %2, %0\n\tv_perm_b32 %2, %2, %2, %3" : "+v"(a[i]), "+v"(b[i]) : "v"(seed), "s"(seed));
+            if (OP == 52) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 53) asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
             if (OP == 38) asm volatile("v_add_u32 %0, %0, %1\n\tv_xor_b32 %2, %2, %0\n\tv_alignbit_b32 %2, %2, %2, 16" : "+v"(a[i]), "+v"(b[i]) : "v"(seed));
         }
     }
@@ -146,6 +151,11 @@ int main() {
     run<35>("v_perm_b32", d_out, blocks, clk);
     run<37>("v_pk_add_u16", d_out, blocks, clk);
     run<38>("ARX triple (3 inst)", d_out, blocks, clk);
+    run<51>("ARX triple with v_perm (3)", d_out, blocks, clk);
+    run<49>("v_alignbyte_b32", d_out, blocks, clk);
+    run<50>("v_perm_b32 sgpr selector", d_out, blocks, clk);
+    run<52>("v_min_u32", d_out, blocks, clk);
+    run<53>("v_mul_hi_i32", d_out, blocks, clk);
     run<39>("cmp vcc + cndmask vcc (2)", d_out, blocks, clk);
     run<40>("sub_co vcc + cndmask vcc (2)", d_out, blocks, clk);
     run<41>("sub_co sgpr + cndmask e64 (2)", d_out, blocks, clk);
