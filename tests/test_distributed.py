@@ -147,3 +147,27 @@ def test_bench_leg_planning_covers_the_baseline_jobs_exactly():
     assert p_sub <= 7 and 10 * n_sub * p_sub >= 1001
     # exchange sizes stated in DESIGN.md 6: [n][B] partial sums of 8 bytes
     assert 8 * 26 * -(-(1 << 20) // 8) == 27_262_976 and 8 * 8 * -(-(1 << 24) // 3) == 357_913_984
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_first_failure():
+    """`python bench.py --gpus 2` with no launcher (the command form the driver uses): the script becomes the launcher of its
+    two ranks.  Without a GPU every rank fails at device selection - the launcher must come back promptly with a non-zero
+    exit code and NO JSON line (never hang in a rendezvous, never print a partial result).  The GPU suite covers the
+    successful run (test_bench_launches_its_own_ranks)."""
+    import subprocess
+    import sys
+    import time
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("covered by the GPU test on a box with a device")
+    except ImportError:
+        pass
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 240
