@@ -122,7 +122,13 @@ __device__ __forceinline__ void packed_gen_n31_body(const GenLayout& L, uint32_t
 // hoists all 2 x KTMAX secret loads to the top - i.e. 4 and 3 waves per SIMD, and the round-4 counters showed these kernels
 // waiting, not computing (narrow26_ref: VALU busy 0.53 at 4.6 wave-instructions per element, 0.71 of the HBM floor): the
 // serial ChaCha20 chains of the t draws need more waves to hide behind.  5 waves (96 VGPRs) up to 8 terms, 4 (128) beyond.
-#define SDA_N31_LB(KTMAX_) __launch_bounds__(kThreads, ((KTMAX_) <= 8 ? 5 : 4))
+#ifndef SDA_N31_W_SMALL
+#define SDA_N31_W_SMALL 5
+#endif
+#ifndef SDA_N31_W_BIG
+#define SDA_N31_W_BIG 4
+#endif
+#define SDA_N31_LB(KTMAX_) __launch_bounds__(kThreads, ((KTMAX_) <= 8 ? SDA_N31_W_SMALL : SDA_N31_W_BIG))
 template <int KTMAX, int GROUP, int ROUNDS>
 __global__ SDA_N31_LB(KTMAX) void packed_gen_n31_kernel(GenLayout L, uint32_t n, uint32_t k, uint32_t t, ModParams mod,
                                                                   N31Params np, MatArg M, DrbgKey key, uint64_t chunks,
