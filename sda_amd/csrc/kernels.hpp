@@ -181,6 +181,13 @@ hipError_t launch_packed_reconstruct(const int64_t* d_shares, size_t row_stride,
                                      const uint64_t* d_Rmont /*[k][n_rows]*/, int64_t* d_out,
                                      hipStream_t s);
 
+// the same over a narrow prime (p < 2^31): one-limb arithmetic, R31 = centred Montgomery-form (R = 2^32) int32 constants [k][n_rows]
+bool packed_reconstruct_n31_available(uint32_t n_rows, uint32_t k, uint64_t p, const int64_t* d_shares, size_t row_stride,
+                                      const int64_t* d_out);
+hipError_t launch_packed_reconstruct_n31(const int64_t* d_shares, size_t row_stride, uint32_t n_rows, uint32_t k, size_t batches,
+                                         size_t dimension, const ModParams& mod, const N31Params& np, const int32_t* d_R31,
+                                         int64_t* d_out, hipStream_t s);
+
 // ---- element-wise masking (full.rs / chacha.rs mask+unmask arithmetic) ----------------------------
 // out = (a + b) mod m   or   (a - b) mod m, any i64 inputs
 hipError_t launch_addsub_mod(const int64_t* d_a, const int64_t* d_b, size_t len, bool subtract,

@@ -147,3 +147,63 @@ __global__ SDA_N31_LB(KTMAX) void fused_packed_n31_kernel(GenLayout L, uint32_t 
         packed_gen_n31_body<KTMAX, GROUP, ROUNDS>(L, n, k, t, mod, np, reinterpret_cast<const int32_t*>(&M.e[0]), key, chunks, batches,
                                                   true, idx);
 }
+
+// ---- reveal over a narrow prime: secrets[k] = R[k x n'] * sums[n'] per batch, the structure of packed_reconstruct_vec_kernel
+// (share pairs in registers, LDS-staged coalesced stores) on one-limb arithmetic.  R31: centred Montgomery-form (R = 2^32)
+// constants, int32 [k][n_rows] in device memory (wave-uniform: scalar loads).
+template <int NMAX, int GROUP>
+__global__ __launch_bounds__(kThreads) void packed_reconstruct_n31_kernel(const int64_t* __restrict__ shares, size_t row_stride,
+                                                                          uint32_t n_rows, uint32_t k, size_t batches, size_t dimension,
+                                                                          ModParams mod, N31Params np, const int32_t* __restrict__ R31,
+                                                                          int64_t* __restrict__ out) {
+    extern __shared__ int64_t stage[];                    // [2 * kThreads][k] = the block's secrets in output order
+    const size_t b0 = 2 * ((size_t)blockIdx.x * kThreads + threadIdx.x);
+    int32_t v0[NMAX], v1[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+        uint64_t a = 0, b = 0;
+        if ((uint32_t)c < n_rows && b0 < batches) {
+            if (b0 + 1 < batches) {
+                const ll2 v = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(shares + (size_t)c * row_stride + b0));
+                a = canon_i64(v.x, mod.m, mod.mu); b = canon_i64(v.y, mod.m, mod.mu);
+            } else {
+                a = canon_i64(shares[(size_t)c * row_stride + b0], mod.m, mod.mu);
+            }
+        }
+        v0[c] = n31_centre(a, np); v1[c] = n31_centre(b, np);
+    }
+    for (uint32_t e = 0; e < k; ++e) {
+        uint32_t r0 = 0, r1 = 0;
+#pragma unroll
+        for (int g0 = 0; g0 < NMAX; g0 += GROUP) {
+            if ((uint32_t)g0 < n_rows) {                  // wave-uniform
+                int64_t S0 = 0, S1 = 0;
+#pragma unroll
+                for (int c = g0; c < g0 + GROUP && c < NMAX; ++c) {
+                    if ((uint32_t)c < n_rows) {
+                        const int32_t m = R31[(size_t)e * n_rows + c];
+                        S0 += (int64_t)m * v0[c]; S1 += (int64_t)m * v1[c];
+                    }
+                }
+                const uint32_t t0 = n31_redc(S0, np), t1 = n31_redc(S1, np);
+                uint32_t s = r0 + t0, d = s - np.p;
+                r0 = d < s ? d : s;
+                s = r1 + t1; d = s - np.p;
+                r1 = d < s ? d : s;
+            }
+        }
+        stage[(size_t)(2 * threadIdx.x) * k + e] = (int64_t)r0;
+        stage[(size_t)(2 * threadIdx.x + 1) * k + e] = (int64_t)r1;
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * 2 * kThreads * k;
+    const size_t total = (size_t)2 * kThreads * k;
+    for (size_t i = 2 * (size_t)threadIdx.x; i < total; i += 2 * kThreads) {
+        if (base + i + 1 < dimension) {                   // truncate padding (batched.rs:94)
+            ll2 v; v.x = stage[i]; v.y = stage[i + 1];
+            *reinterpret_cast<ll2*>(out + base + i) = v;
+        } else if (base + i < dimension) {
+            out[base + i] = stage[i];
+        }
+    }
+}

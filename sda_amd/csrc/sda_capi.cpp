@@ -1318,9 +1318,11 @@ struct sda_secret_reconstructor {
     MontParams mont{0, 0};
     Ctx ctx;
     AccState acc;
-    DevBuf tile, d_out, d_R, d_shares;
+    DevBuf tile, d_out, d_R, d_R31, d_shares;
     std::vector<size_t> cached_indices;
     bool have_R = false;
+    bool narrow = false;                 // p < 2^31: the one-limb reveal kernel (d_R31) when the shape and layout allow
+    N31Params n31p{};
 };
 
 extern "C" int sda_secret_reconstructor_new(const sda_sharing_scheme_t* scheme, size_t dimension,
@@ -1358,7 +1360,7 @@ extern "C" int sda_secret_reconstructor_new(const sda_sharing_scheme_t* scheme, 
 extern "C" void sda_secret_reconstructor_free(sda_secret_reconstructor_t* r) {
     if (!r) return;
     if (r->ctx.device >= 0) (void)hipSetDevice(r->ctx.device);
-    r->acc.release(); r->tile.release(); r->d_out.release(); r->d_R.release(); r->d_shares.release();
+    r->acc.release(); r->tile.release(); r->d_out.release(); r->d_R.release(); r->d_R31.release(); r->d_shares.release();
     r->ctx.destroy();
     delete r;
 }
@@ -1390,7 +1392,21 @@ static int prepare_R(sda_secret_reconstructor* r, const size_t* indices, size_t 
     if (!h_lagrange_matrix_mont(nodes, evals, 0, p, R)) return fail(SDA_ERR_INVALID_ARGUMENT, "reconstruction matrix is singular");
     SDA_TRY(r->d_R.reserve(R.size() * 8));
     HIP_TRY(hipMemcpyAsync(r->d_R.p, R.data(), R.size() * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));               // R is a stack vector
+    std::vector<int32_t> R31;
+    r->narrow = p < (1ull << 31) && !knob(KNOB_NO_NARROW);
+    if (r->narrow) {                                // the same matrix as centred int32 constants with R = 2^32
+        uint64_t inv, inv32;
+        if (!h_invmod(p, 1ull << 32, inv) || !h_invmod((1ull << 32) % p, p, inv32)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not odd");
+        r->n31p.p = (uint32_t)p; r->n31p.pinv = (uint32_t)((1ull << 32) - inv); r->n31p.h = (uint32_t)((p + 1) / 2); r->n31p.pad = 0;
+        R31.resize(R.size());
+        for (size_t i = 0; i < R.size(); ++i) {
+            const uint64_t mr = h_mulmod(R[i], inv32, p);                    // R holds M * 2^64: M * 2^32 mod p
+            R31[i] = mr > (p - 1) / 2 ? (int32_t)((int64_t)mr - (int64_t)p) : (int32_t)mr;
+        }
+        SDA_TRY(r->d_R31.reserve(R31.size() * 4 + 16));
+        HIP_TRY(hipMemcpyAsync(r->d_R31.p, R31.data(), R31.size() * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));               // R, R31 are stack vectors
     r->cached_indices.assign(indices, indices + n_rows);
     r->have_R = true;
     return SDA_OK;
@@ -1421,8 +1437,12 @@ extern "C" int sda_secret_reconstructor_reconstruct_dev(sda_secret_reconstructor
     if (!d_shares || !d_out || out_cap < r->dimension) return fail(SDA_ERR_INVALID_ARGUMENT, "bad device buffers");
     if (n_rows > 0xFFFFFFFFull) return fail(SDA_ERR_UNSUPPORTED, "too many rows");
     SDA_TRY(prepare_R(r, indices, n_rows, s));
-    HIP_TRY(launch_packed_reconstruct(d_shares, row_stride, (uint32_t)n_rows, r->k, batches, r->dimension, r->mod, r->mont,
-                                      r->d_R.as<uint64_t>(), d_out, s));
+    if (r->narrow && packed_reconstruct_n31_available((uint32_t)n_rows, r->k, r->mod.m, d_shares, row_stride, d_out))
+        HIP_TRY(launch_packed_reconstruct_n31(d_shares, row_stride, (uint32_t)n_rows, r->k, batches, r->dimension, r->mod, r->n31p,
+                                              r->d_R31.as<int32_t>(), d_out, s));
+    else
+        HIP_TRY(launch_packed_reconstruct(d_shares, row_stride, (uint32_t)n_rows, r->k, batches, r->dimension, r->mod, r->mont,
+                                          r->d_R.as<uint64_t>(), d_out, s));
     *out_len = r->dimension;
     return SDA_OK;
 }

@@ -1978,6 +1978,30 @@ hipError_t launch_combine_finish(const uint64_t* d_acc_lo, const int64_t* d_acc_
     return hipGetLastError();
 }
 
+// narrow primes (p < 2^31), small shapes and vectorisable layouts only; false: the caller takes launch_packed_reconstruct
+bool packed_reconstruct_n31_available(uint32_t n_rows, uint32_t k, uint64_t p, const int64_t* d_shares, size_t row_stride,
+                                      const int64_t* d_out) {
+    return p < (1ull << 31) && n_rows <= 16 && k <= 16 && aligned16(d_shares) && aligned16(d_out) && row_stride % 2 == 0;
+}
+hipError_t launch_packed_reconstruct_n31(const int64_t* d_shares, size_t row_stride, uint32_t n_rows, uint32_t k, size_t batches,
+                                         size_t dimension, const ModParams& mod, const N31Params& np, const int32_t* d_R31,
+                                         int64_t* d_out, hipStream_t s) {
+    if (batches == 0) return hipSuccess;
+    const uint64_t vblocks = ceil_div(ceil_div(batches, 2), kThreads);
+    if (hipError_t e = grid_check(vblocks)) return e;
+    const size_t lds = (size_t)2 * kThreads * k * 8;
+    const dim3 grid((unsigned)vblocks), block(kThreads);
+    const bool g16 = np.p < (1u << 29);
+#define RN(NMAX_)                                                                                                                  \
+    do {                                                                                                                           \
+        if (g16) packed_reconstruct_n31_kernel<NMAX_, 16><<<grid, block, lds, s>>>(d_shares, row_stride, n_rows, k, batches, dimension, mod, np, d_R31, d_out); \
+        else packed_reconstruct_n31_kernel<NMAX_, 4><<<grid, block, lds, s>>>(d_shares, row_stride, n_rows, k, batches, dimension, mod, np, d_R31, d_out);      \
+    } while (0)
+    if (n_rows <= 4) RN(4); else if (n_rows <= 8) RN(8); else RN(16);
+#undef RN
+    return hipGetLastError();
+}
+
 hipError_t launch_packed_reconstruct(const int64_t* d_shares, size_t row_stride, uint32_t n_rows, uint32_t k,
                                      size_t batches, size_t dimension, const ModParams& mod, const MontParams& mont,
                                      const uint64_t* d_Rmont, int64_t* d_out, hipStream_t s) {

@@ -143,3 +143,31 @@ def test_narrow_transform_kernel_vs_oracle_and_wide(gpu, p, k, t, n, w2, w3, dim
             assert np.array_equal(o[q, :, :B], w), (narrow, q)
         results.append(o.copy())
     assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
+
+
+@pytest.mark.parametrize("p,k,t,n,rows", [(433, 3, 4, 8, 7), (433, 3, 4, 8, 8), (TSS_P1, 8, 7, 26, 15), (TSS_P2, 8, 7, 26, 16),
+                                          (P31, 8, 7, 26, 15), (P31, 8, 7, 26, 20), (P31, 3, 1, 8, 4), (P29, 3, 1, 8, 6)])
+def test_narrow_reveal_vs_oracle_and_wide(gpu, p, k, t, n, rows):
+    """packed_reconstruct_n31_kernel (the reveal over a narrow prime; up to 16 clerk rows, more fall back to the 64-bit
+    kernel) against the oracle's per-batch Newton interpolation (batched.rs:68-97, packed_shamir.rs:73-77) and against the
+    64-bit kernel, for an arbitrary clerk subset and any-i64 share values"""
+    from sda_amd import crypto
+    from oracle import coracle
+    w2, w3 = _root(p, _pow2_at_least(k + t + 1)), _root(p, n + 1)
+    rng = np.random.default_rng(rows * 17 + k)
+    dim = k * 1000 + 1
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    B = (dim + k - 1) // k
+    idx = sorted(rng.choice(n, size=rows, replace=False).tolist())
+    secrets = rng.integers(0, p, size=dim, dtype=np.int64)
+    rand = rng.integers(0, p, size=B * t, dtype=np.int64)
+    shares = coracle.packed_generate(p, k, t, n, w2, w3, secrets, rand)
+    signed = shares[idx].copy()
+    signed[::2] -= p                                             # the reference's representatives live in (-p, p)
+    want = coracle.packed_reconstruct(p, k, t, w2, w3, dim, idx, shares[idx])
+    assert np.array_equal(want, secrets)
+    got = crypto.SecretReconstructor(sch, dim).reconstruct([(i, signed[j]) for j, i in enumerate(idx)])
+    assert np.array_equal(got, want)
+    set_knob("SDA_NO_NARROW", 1)
+    wide = crypto.SecretReconstructor(sch, dim).reconstruct([(i, signed[j]) for j, i in enumerate(idx)])
+    assert np.array_equal(wide, want)
