@@ -18,6 +18,8 @@
  *   SDA_NO_NARROW 1            primes below 2^31 through the 62-bit kernels too (default: the one-limb narrow kernels)
  *   SDA_NO_LAZY 1              narrow transform kernel with the conditional subtractions of the 64-bit form (default: lazy where it fits)
  *   SDA_WIRE_WG_PER_CU n, SDA_SBOX_WG_PER_CU n   residency caps (unused dynamic LDS) of the varint stream kernels / the XSalsa20 kernel
+ *   SDA_NO_XCD_MAP 1           transform kernel with fewer than 8 batches per workgroup: plain group order (default: the
+ *                              workgroups that share a 128-byte line of a clerk row are placed on one XCD)
  *   SDA_FORCE_COLLECTIVES 1    a one-rank communicator still goes through RCCL send/recv to itself
  * Built with -DSDA_AB_KNOBS (tools/build_ab_variant.sh; never by __graft_entry__.build()) an unset knob falls back to the
  * environment variable of the same name. */

@@ -154,8 +154,22 @@ __global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, F
     extern __shared__ __align__(16) uint64_t lds_raw[];
     V* lds = reinterpret_cast<V*>(lds_raw);
     const uint32_t T = blockDim.x, tid = threadIdx.x;
-    const uint64_t p = blockIdx.x / groups, g = blockIdx.x - p * groups;
     const uint32_t G = F.G, m2 = F.m2, m3 = F.m3, k = F.k, t = F.t;
+    // Fewer than 8 batches per workgroup: a 128-byte line of a clerk row holds the 8-byte shares of 16 consecutive batches,
+    // i.e. pieces from 16 / G DIFFERENT workgroups, which can only be merged in an L2 - and workgroup b runs on XCD b mod 8,
+    // each XCD with an L2 of its own.  The launcher pads the groups of a participant to a multiple of 8 * (16 / G) and the
+    // group index is permuted so that the 16 / G workgroups of one line sit on ONE XCD, dispatched within 128 block indices
+    // of each other (tss's PSS_155_19682_100: 0.17 -> see DESIGN.md; the pieces used to leave eight different L2s as partial
+    // lines, 16 fabric writes per line).
+    const uint64_t gpad = F.groups_padded ? F.groups_padded : groups;
+    const uint64_t p = blockIdx.x / gpad;
+    uint64_t g = blockIdx.x - p * gpad;
+    if (F.groups_padded) {
+        const uint32_t C = 16u / G;
+        const uint64_t xcd = g & 7u, slot = g >> 3, chunk = slot / C, i = slot - chunk * C;
+        g = (chunk * 8u + xcd) * C + i;
+        if (g >= groups) return;
+    }
     // LDS: [twiddles of the radix-3 part | twiddles of the radix-2 part |] X [G][m2] | Y [G][m3]
     const W* tw3 = TWL ? reinterpret_cast<const W*>(lds) : reinterpret_cast<const W*>(F.tw3);
     const W* tw2 = TWL ? reinterpret_cast<const W*>(lds) + m3 : reinterpret_cast<const W*>(F.tw2);
@@ -442,8 +456,16 @@ static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const D
                          : (rounds == 20 ? packed_gen_fft_kernel<20, false, V, LAZY> : rounds == 12 ? packed_gen_fft_kernel<12, false, V, LAZY> : packed_gen_fft_kernel<8, false, V, LAZY>);
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
+    FftPlan Fl = F;
+    Fl.groups_padded = 0;
+    uint64_t gridg = groups;
+    if (F.G < 8 && !knob(KNOB_NO_XCD_MAP)) {
+        const uint64_t unit = 8ull * (16u / F.G);
+        gridg = (groups + unit - 1) / unit * unit;
+        Fl.groups_padded = gridg;
+    }
     const uint64_t max_blocks = 0x7FFFFFFFull;
-    uint64_t per = max_blocks / groups;
+    uint64_t per = max_blocks / gridg;
     if (per == 0) return hipErrorInvalidConfiguration;
     if (per > L.participants) per = L.participants;
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
@@ -454,7 +476,7 @@ static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const D
         S.out = L.out + p0 * L.out_stride_participant;
         S.participants = cnt;
         S.first_participant = L.first_participant + p0;
-        kern<<<dim3((unsigned)(groups * cnt)), dim3(threads), lds, s>>>(S, mod, key, F, groups, batches);
+        kern<<<dim3((unsigned)(gridg * cnt)), dim3(threads), lds, s>>>(S, mod, key, Fl, groups, batches);
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;

@@ -117,6 +117,7 @@ struct FftPlan {
     uint32_t m3, b;            // n + 1 = 3^b
     uint32_t G, lgG;           // batches per workgroup (a power of two): 16 or 8 (one CSPRNG block per draw serves 8) or 1
     uint32_t tw_lds;           // 1: the workgroup copies both twiddle tables to LDS
+    uint64_t groups_padded;    // set by the launcher for G < 8: groups per participant rounded up to 8 * (16 / G) (XCD-aware group map)
     uint32_t lazy;             // 1 (narrow only): (4 b + 4) p < 2^32 - the radix-3 levels run without conditional subtractions
     uint64_t one_s;            // floor(2^32 / p): the companion of the constant 1 (narrow: full reduction of a lazy value)
     uint32_t narrow;           // 1: p < 2^30 - uint32_t values, tables of (uint32 w, uint32 floor(w 2^32 / p)) pairs, 32-bit companions below

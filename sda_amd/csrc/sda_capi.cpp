@@ -101,7 +101,7 @@ namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
     "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES",
-    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY"};
+    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP"};
 std::atomic<long> g_knobs[sda::KNOB_COUNT];
 }  // namespace
 long sda::knob(sda::Knob k) {

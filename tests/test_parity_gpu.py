@@ -885,7 +885,8 @@ def test_scheme_validation(gpu):
 
 
 # ---- BASELINE-size property tests (size-independent invariants; data stays in HBM) ------------------------
-@pytest.mark.parametrize("shape", ["additive_n3", "packed_k3_t1_n8", "packed_k8_t2_n26"])
+@pytest.mark.parametrize("shape", ["additive_n3", "packed_k3_t1_n8", "packed_k8_t2_n26", "narrow_k3_t4_n8_p31", "narrow_k8_t7_n26_p31",
+                                   "narrow_k3_t4_n8_p433"])
 def test_full_dimension_roundtrip(gpu, shape):
     """dim = 1,048,576 (BASELINE configs 2-4), P participants on the device CSPRNG:
     reconstruct(combine(generate(x_p))) == sum_p x_p mod q, for a strict subset of clerks where the
@@ -894,7 +895,17 @@ def test_full_dimension_roundtrip(gpu, shape):
     from sda_amd.device import DeviceBuffer
     from oracle import coracle
     dim, P = 1 << 20, 24
-    if shape == "additive_n3":
+    q = P62
+    if shape.startswith("narrow"):
+        # the reference's own domain (tss multiplies i64 residues without widening): tss-valid shapes over the largest prime
+        # = 1 mod 432 below 2^31 and over full_loop.rs's p = 433, through the one-limb kernels (generate, sums, narrow reveal)
+        k, t, n = (3, 4, 8) if "k3" in shape else (8, 7, 26)
+        q = 433 if shape.endswith("p433") else 2147482801
+        w2 = 354 if q == 433 else _root(q, k + t + 1)
+        w3 = 150 if q == 433 else _root(q, n + 1)
+        sch = crypto.PackedShamir(k, n, t, q, w2, w3)
+        subset = sorted(np.random.default_rng(5).choice(n, size=k + t, replace=False).tolist())
+    elif shape == "additive_n3":
         sch, k, t, n = crypto.Additive(3, P62), 1, 2, 3
         subset = [0, 1, 2]
     elif shape == "packed_k3_t1_n8":
@@ -910,7 +921,7 @@ def test_full_dimension_roundtrip(gpu, shape):
     lib = gpu
     secrets = DeviceBuffer(P * dim)
     from sda_amd.capi import check
-    check(lib.sda_fill_synthetic_dev(secrets.ptr, P, dim, dim, 100, 0x5DA5DA5DA5DA5DA5, P62, None))
+    check(lib.sda_fill_synthetic_dev(secrets.ptr, P, dim, dim, 100, 0x5DA5DA5DA5DA5DA5, q, None))
     shares = DeviceBuffer(n * P * Bs)                                        # job-major [n][P][Bs]
     gen = crypto.ShareGenerator(sch)
     gen.set_drbg_key(KEY)
@@ -924,8 +935,8 @@ def test_full_dimension_roundtrip(gpu, shape):
     S = sums.to_numpy().reshape(n, B)
     got = rec.reconstruct([(c, S[c]) for c in subset])
     host_secrets = secrets.to_numpy().reshape(P, dim)
-    assert np.array_equal(host_secrets[:2], coracle.fill_synthetic(2, dim, 100, 0x5DA5DA5DA5DA5DA5, P62))
-    assert np.array_equal(got, coracle.combine(P62, host_secrets))           # == sum of secrets mod q
+    assert np.array_equal(host_secrets[:2], coracle.fill_synthetic(2, dim, 100, 0x5DA5DA5DA5DA5DA5, q))
+    assert np.array_equal(got, coracle.combine(q, host_secrets))             # == sum of secrets mod q
     # device-resident reconstruct from the first rows (contiguous [n'][B] in HBM)
     first = list(range(sch.reconstruction_threshold()))
     out = DeviceBuffer(dim)
@@ -933,14 +944,14 @@ def test_full_dimension_roundtrip(gpu, shape):
     assert np.array_equal(out.to_numpy(), got)
     # spot-check one participant's shares bit-exactly against the oracle
     p = 7
-    rnd = coracle.drbg_fill(KEY, 100 + p, B, t, P62)
+    rnd = coracle.drbg_fill(KEY, 100 + p, B, t, q)
     if shape == "additive_n3":
-        want = coracle.additive_generate(P62, n, host_secrets[p], rnd)
+        want = coracle.additive_generate(q, n, host_secrets[p], rnd)
     else:
-        want = coracle.packed_generate_csprng(P62, k, t, n, sch.omega_secrets, sch.omega_shares, host_secrets[p], rnd, gen.csprng_share_map())
+        want = coracle.packed_generate_csprng(q, k, t, n, sch.omega_secrets, sch.omega_shares, host_secrets[p], rnd, gen.csprng_share_map())
     all_shares = shares.to_numpy().reshape(n, P, Bs)
     assert np.array_equal(all_shares[:, p, :B], want)
-    assert np.array_equal(S, np.stack([coracle.combine(P62, all_shares[c, :, :B]) for c in range(n)]))
+    assert np.array_equal(S, np.stack([coracle.combine(q, all_shares[c, :, :B]) for c in range(n)]))
 
 
 # ---- host mirror in C++ (the reference's host language is compiled) and multi-GPU helper ---------------------

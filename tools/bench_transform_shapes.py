@@ -19,9 +19,19 @@ def root(p, order):
 
 
 lib = capi.load()
+for _k in ("SDA_NO_XCD_MAP", "SDA_NO_NARROW", "SDA_NO_LAZY"):
+    if os.environ.get(_k):
+        capi.check(lib.sda_debug_set_knob(_k.encode(), 1))
+ONLY = os.environ.get("ONLY_SMALL_G")
 dim = 1 << 20
-for (k, t, n, P) in [(100, 155, 728, 500), (100, 155, 19682, 40), (100, 155, 2186, 200), (40, 23, 242, 500), (70, 57, 242, 500)]:
-    p = P62B if n + 1 == 19683 else P62
+TSS_P1, TSS_P2 = 746497, 5038849          # tss's own primes: p - 1 = 2^10 * 3^6 and 2^8 * 3^9 (the uint32_t transform kernel)
+SHAPES = [(100, 155, 728, 500, None), (100, 155, 19682, 40, None), (100, 155, 2186, 200, None), (40, 23, 242, 500, None), (70, 57, 242, 500, None),
+          (100, 155, 728, 500, TSS_P1), (100, 155, 19682, 40, TSS_P2), (100, 155, 2186, 200, TSS_P2), (40, 23, 242, 500, TSS_P1),
+          (70, 57, 242, 500, TSS_P1)]
+for (k, t, n, P, small) in SHAPES:
+    if ONLY and n not in (19682, 2186):
+        continue
+    p = small or (P62B if n + 1 == 19683 else P62)
     sch = crypto.PackedShamir(k, n, t, p, root(p, k + t + 1), root(p, n + 1))
     gen = crypto.ShareGenerator(sch)
     sec = DeviceBuffer(P * dim)
@@ -38,5 +48,5 @@ for (k, t, n, P) in [(100, 155, 728, 500), (100, 155, 19682, 40), (100, 155, 218
         t0 = time.perf_counter(); run(); synchronize(); ts.append(time.perf_counter() - t0)
     dt = sorted(ts)[1]
     wr = n * P * B * 8
-    print(f"k={k} t={t} n={n} ({P} participants): {dt*1e3:.2f} ms  {P*dim/dt/1e9:.2f} Gelem/s  shares written {wr/1e9:.1f} GB = {wr/dt/1e12:.2f} TB/s", flush=True)
+    print(f"p={p} k={k} t={t} n={n} ({P} participants): {dt*1e3:.2f} ms  {P*dim/dt/1e9:.2f} Gelem/s  shares written {wr/1e9:.1f} GB = {wr/dt/1e12:.2f} TB/s", flush=True)
     del out, sec, gen
