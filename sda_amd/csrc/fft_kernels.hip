@@ -148,8 +148,11 @@ __device__ __noinline__ uint64_t f_drbg_retry(uint32_t k0, uint32_t k1, uint32_t
 }
 
 // TWL: the twiddle tables (with their companions) are copied to LDS; otherwise they are read from global memory
+// __launch_bounds__(1024): the launcher uses 512 threads (1024 for the one-batch shapes, any multiple of 64 through the A/B
+// knob), so the register budget is the 1024-thread one (128 VGPRs) for every instance - all of them compile to 94 - 106
+// without spills, and occupancy is set by the LDS (two workgroups per CU), not by registers.
 template <int ROUNDS, bool TWL, typename V, bool LAZY>
-__global__ void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, FftPlan F, uint64_t groups, uint64_t batches) {
+__global__ __launch_bounds__(1024) void packed_gen_fft_kernel(GenLayout L, ModParams mod, DrbgKey key, FftPlan F, uint64_t groups, uint64_t batches) {
     typedef typename FftW<V>::type W;
     extern __shared__ __align__(16) uint64_t lds_raw[];
     V* lds = reinterpret_cast<V*>(lds_raw);

@@ -171,3 +171,31 @@ def test_narrow_reveal_vs_oracle_and_wide(gpu, p, k, t, n, rows):
     set_knob("SDA_NO_NARROW", 1)
     wide = crypto.SecretReconstructor(sch, dim).reconstruct([(i, signed[j]) for j, i in enumerate(idx)])
     assert np.array_equal(wide, want)
+
+
+@pytest.mark.parametrize("p,k,t,n", [(P31, 8, 7, 26), (TSS_P1, 3, 4, 8), (433, 3, 4, 8)])
+def test_narrow_kernels_with_odd_strides_and_unaligned_rows(gpu, p, k, t, n):
+    """caller layouts that rule out 16-byte stores (odd clerk stride, odd participant stride, secrets on an 8-byte boundary):
+    the narrow kernels take their scalar paths, results identical to the oracle; nothing is written past a row"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    w2, w3 = _root(p, _pow2_at_least(k + t + 1)), _root(p, n + 1)
+    rng = np.random.default_rng(n + k)
+    dim, P, first = k * 333 + 2, 3, 9
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    B = gen.batch_count(dim)
+    stride = dim + 3
+    sec = rng.integers(-(1 << 62), 1 << 62, size=(P, stride), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec)
+    Bs = B | 1                                                    # odd row stride
+    d_out = DeviceBuffer(P * n * Bs + 1).zero()
+    gen.generate_batch_dev(d_sec.ptr, P, dim, stride, d_out.ptr + 8, n * Bs, Bs, first_participant=first)   # base on an 8-byte boundary
+    out = d_out.to_numpy()[1:].reshape(P, n, Bs)
+    for q in range(P):
+        want = coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[q, :dim], coracle.drbg_fill(KEY, first + q, B, t, p),
+                                              gen.csprng_share_map())
+        assert np.array_equal(out[q, :, :B], want), q
+    assert not out[:, :, B:].any()
