@@ -100,6 +100,10 @@ struct ShareGenerator {
     explicit ShareGenerator(const LinearSecretSharingScheme& s) { detail::check(sda_share_generator_new(&s.c, &h)); }
     // SDA_VALUES_RUST_SIGNED: the reference's own signed representatives (sda_hip.h "value representation")
     void set_value_mode(int mode) { detail::check(sda_share_generator_set_value_mode(h, mode)); }
+    // which parametrisation `generate` WITHOUT injected randomness uses (sda_hip.h "CSPRNG share map"): SDA_SHARE_MAP_SYSTEMATIC
+    // (the t draws of a batch are its shares 0..t-1; default of the matrix-form kernels) or SDA_SHARE_MAP_TSS_NODES
+    int csprng_share_map() const { return sda_share_generator_csprng_share_map(h); }
+    void set_csprng_share_map(int map) { detail::check(sda_share_generator_set_csprng_share_map(h, map)); }
     ~ShareGenerator() { sda_share_generator_free(h); }
     ShareGenerator(const ShareGenerator&) = delete;
     /// generate(&mut self, secrets) -> Vec<Vec<Share>>: outer index = clerk (batched.rs:46-48)

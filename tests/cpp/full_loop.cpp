@@ -117,6 +117,22 @@ int main() {
             EXPECT(false, "a payload of the wrong length must fail");
         } catch (const SdaClientError& e) { EXPECT(std::string(e.what()) == "Wrong dimension", "combiner.rs:21 on the wire form"); }
     }
+    // the two parametrisations of a sharing drawn by the library itself (sda_hip.h "CSPRNG share map"): both reveal the same sums
+    {
+        for (int map : {SDA_SHARE_MAP_SYSTEMATIC, SDA_SHARE_MAP_TSS_NODES}) {
+            ShareGenerator gen(pss);
+            EXPECT(gen.csprng_share_map() == SDA_SHARE_MAP_SYSTEMATIC, "matrix-form kernels default to the systematic map");
+            gen.set_csprng_share_map(map);
+            EXPECT(gen.csprng_share_map() == map, "share map setter");
+            ShareCombiner comb(pss);
+            std::vector<std::vector<std::vector<Share>>> per;            // [participant][clerk]
+            for (const auto& secrets : two) per.push_back(gen.generate(secrets));
+            std::vector<std::pair<size_t, std::vector<int64_t>>> sums;
+            for (size_t c : {7u, 1u, 2u, 3u, 4u, 5u, 0u}) sums.push_back({c, comb.combine({per[0][c], per[1][c]})});
+            auto out = SecretReconstructor(pss, 4).reconstruct(sums);
+            EXPECT((RecipientOutput{433, out}.positive().values) == want, "reveal is independent of the share map");
+        }
+    }
     // the reference's full path for a clerk: participants seal their varint-encoded share vectors to the clerk's key
     // (participate.rs:82-101, sodium.rs:33-46), the server hands the clerk ONE job (here an SDAJOBv1 blob instead of a
     // JSON array, stores.rs:86-101), the clerk decrypts and combines (clerk.rs:78-86, sodium.rs:72-92)

@@ -199,3 +199,33 @@ def test_narrow_kernels_with_odd_strides_and_unaligned_rows(gpu, p, k, t, n):
                                               gen.csprng_share_map())
         assert np.array_equal(out[q, :, :B], want), q
     assert not out[:, :, B:].any()
+
+
+@pytest.mark.parametrize("p", [P31, 4611686006577364993])
+def test_share_count_equal_to_the_reconstruction_threshold(gpu, p):
+    """n = t + k (every share is needed; the systematic map leaves n - t = k interpolated rows): 7 of the 8 non-trivial ninth
+    roots of unity as share points, over a narrow and over the 62-bit prime - generate (both share maps), reconstruct from
+    all seven clerks, and one clerk too few is refused with the reference's error (packed_shamir.rs:75)"""
+    from sda_amd import capi, crypto
+    from oracle import coracle
+    k, t, n = 3, 4, 7
+    g = next(g for g in range(2, 500) if all(pow(g, (p - 1) // f, p) != 1 for f in (2, 3)))
+    w2, w3 = pow(g, (p - 1) // 8, p), pow(g, (p - 1) // 9, p)
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    rng = np.random.default_rng(3)
+    dim = 3 * 500 + 1
+    B = gen.batch_count(dim)
+    secrets = rng.integers(0, p, size=dim, dtype=np.int64)
+    for share_map in (gen.SHARE_MAP_SYSTEMATIC, gen.SHARE_MAP_TSS_NODES):
+        gen.set_csprng_share_map(share_map)
+        stream = 0 if share_map == gen.SHARE_MAP_SYSTEMATIC else 1
+        got = gen.generate(secrets)
+        want = coracle.packed_generate_csprng(p, k, t, n, w2, w3, secrets, coracle.drbg_fill(KEY, stream, B, t, p), share_map)
+        assert np.array_equal(got, want), share_map
+        rec = crypto.SecretReconstructor(sch, dim)
+        assert np.array_equal(rec.reconstruct([(c, got[c]) for c in range(n)]), secrets)
+        with pytest.raises(capi.SdaError) as e:
+            rec.reconstruct([(c, got[c]) for c in range(n - 1)])
+        assert e.value.code == capi.ERR_NOT_ENOUGH_SHARES
