@@ -842,7 +842,7 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
         } else if (packed_mfma_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64) &&
                    !knob(KNOB_NO_MFMA) && (g->k + g->t >= 12 || knob(KNOB_FORCE_MFMA))) {
             // the limb GEMM on the matrix cores: measured ahead of the limb-31 kernel from k + t = 15 with n = 26 (+12 %),
-            // behind it for k + t = 10 and below (SDA_FORCE_MFMA=1 takes it for every compiled shape, SDA_NO_MFMA=1 never)
+            // behind it for k + t = 10 and below (knob SDA_FORCE_MFMA takes it for every compiled shape, SDA_NO_MFMA never)
             g->mfma = true; g->l31 = g->l31g = g->fast = false;
             g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
             st = build_mfma(g);
