@@ -33,32 +33,35 @@ __device__ __forceinline__ uint32_t n31_redc(int64_t S, const N31Params& P) {
     return (uint32_t)t;
 }
 
-// sum over i < kt of row[i] * v[i] mod p (Montgomery-form constants): groups of GROUP terms, each reduced on its own
+// The dot products of ONE matrix row with the lane's two batches: sum_i m[i] * x[i] and sum_i m[i] * y[i] mod p, canonical.
+// Straight-line code: the launchers pick KTMAX as k + t rounded up to a multiple of four and the value limbs beyond k + t
+// are zero, so every term is multiplied unconditionally (<= 3 wasted per dot product) - no wave-uniform branches, the two
+// accumulator chains alternate (two independent v_mad_i64_i32 in flight instead of one serial chain), and the row's
+// constants are SGPR operands of one scalar fetch per row.  (Round 4's first version guarded every group of four terms with a
+// branch and fetched its four constants right before use; this form is 1 - 2 % faster on (8,7,26) - 83.5 -> 84.4 Gelem/s -
+// which shows that the kernel waits for its ChaCha20 chains, not for its dot products.)
 template <int KTMAX, int GROUP>
-__device__ __forceinline__ uint32_t n31_dot(const int32_t* __restrict__ row, const int32_t (&v)[KTMAX], uint32_t kt,
-                                            const N31Params& P) {
-    uint32_t acc = 0;
+__device__ __forceinline__ void n31_dot2(const int32_t (&m)[KTMAX], const int32_t (&x)[KTMAX], const int32_t (&y)[KTMAX],
+                                         const N31Params& P, uint32_t& ra, uint32_t& rb) {
+    uint32_t acc_a = 0, acc_b = 0;
 #pragma unroll
     for (int g0 = 0; g0 < KTMAX; g0 += GROUP) {
-        if ((uint32_t)g0 < kt) {                                               // wave-uniform
-            int64_t S = 0;
+        int64_t Sa = 0, Sb = 0;
 #pragma unroll
-            for (int c0 = g0; c0 < g0 + GROUP && c0 < KTMAX; c0 += 4) {
-                if ((uint32_t)c0 < kt) {                                       // terms beyond kt have zero VALUES: whole chunks of four
-#pragma unroll
-                    for (int i = c0; i < c0 + 4 && i < KTMAX; ++i) S = (c0 == g0 && i == c0) ? mul_sv(row[i], v[i]) : mad_sv(row[i], v[i], S);
-                }
-            }
-            const uint32_t r = n31_redc(S, P);
-            if (g0 == 0) acc = r;
-            else {
-                const uint32_t s = acc + r;                                    // < 2p < 2^32
-                const uint32_t d = s - P.p;
-                acc = d < s ? d : s;                                           // min(s, s - p): s - p wraps exactly when s < p
-            }
+        for (int i = g0; i < g0 + GROUP && i < KTMAX; ++i) {
+            Sa = i == g0 ? mul_sv(m[i], x[i]) : mad_sv(m[i], x[i], Sa);
+            Sb = i == g0 ? mul_sv(m[i], y[i]) : mad_sv(m[i], y[i], Sb);
+        }
+        const uint32_t ta = n31_redc(Sa, P), tb = n31_redc(Sb, P);
+        if (g0 == 0) { acc_a = ta; acc_b = tb; }
+        else {
+            uint32_t s = acc_a + ta, d = s - P.p;                            // s < 2p < 2^32; s - p wraps exactly when s < p
+            acc_a = d < s ? d : s;
+            s = acc_b + tb; d = s - P.p;
+            acc_b = d < s ? d : s;
         }
     }
-    return acc;
+    ra = acc_a; rb = acc_b;
 }
 
 template <int KTMAX, int GROUP, int ROUNDS>
@@ -105,10 +108,16 @@ __device__ __forceinline__ void packed_gen_n31_body(const GenLayout& L, uint32_t
         x[i] = n31_centre(a, np);
         y[i] = n31_centre(b, np);
     }
+    // the whole row's constants in ONE scalar fetch at the top of the iteration (they are SGPR operands of the multiply-adds);
+    // double-buffering them one row ahead was tried: 32 more SGPRs live, spilled to VGPR lanes, no gain over the other
+    // waves of the SIMD hiding this one latency per row.  Indexed from Mrows every time: a pointer carried round the loop
+    // loses the kernarg address space and hipcc then copies the whole matrix to scratch.
     for (uint32_t j = direct; j < n; ++j) {
-        const int32_t* row = Mrows + (size_t)(j - direct) * kt;
-        const uint64_t a = n31_dot<KTMAX, GROUP>(row, x, kt, np);
-        const uint64_t b = n31_dot<KTMAX, GROUP>(row, y, kt, np);
+        int32_t m[KTMAX];
+#pragma unroll
+        for (int i = 0; i < KTMAX; ++i) m[i] = Mrows[(size_t)(j - direct) * kt + i];
+        uint32_t a, b;
+        n31_dot2<KTMAX, GROUP>(m, x, y, np, a, b);
         int64_t* o = op + (size_t)j * L.out_stride_clerk;
         if (vec && in1) store2(o, a, b);
         else {

@@ -1908,7 +1908,7 @@ hipError_t launch_fused_packed_mfma(const GenLayout& L, uint32_t n, uint32_t k, 
 
 // ---- narrow-modulus kernels (narrow_gen.inc.hpp) ---------------------------------------------------------------------
 bool packed_n31_path_available(uint32_t k, uint32_t t, uint32_t rows, uint64_t p) {
-    return p < (1ull << 31) && k >= 1 && k + t <= 16 && (uint64_t)rows * (k + t) + 3 <= 2 * SDA_MAT_ARG_MAX;
+    return p < (1ull << 31) && k >= 1 && k + t <= 16 && (uint64_t)rows * (k + t) + 3 <= 2 * SDA_MAT_ARG_MAX;   // a row is read up to 3 entries past its end
 }
 
 #define SDA_N31_DISPATCH(KERNEL, GRID, ...)                                                                              \
