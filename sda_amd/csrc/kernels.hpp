@@ -79,6 +79,7 @@ hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, ui
 
 // packed Shamir, compiled (k, t) shapes: balanced 31-bit limbs, carry-free v_mad_i64_i32 dot products
 bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n);
+unsigned packed_l31_r_bits(uint32_t k, uint32_t t);     // 62 or 93: the Montgomery radix 2^bits the kernels of this shape expect
 hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
                                       const ModParams& mod, const L31Params& lp, const MatArg& Ml31,
                                       const DrbgKey& key, int rounds, hipStream_t s);

@@ -611,12 +611,13 @@ static int validate_packed(const sda_sharing_scheme_t& s) {
 
 // Constants of the balanced-limb kernel: matrix entries in Montgomery form with R = 2^62, centred to
 // (-p/2, p/2] and split into balanced limbs m1 * 2^31 + m0, m0 in [-2^30, 2^30).
-static void l31_pack_matrix(const std::vector<uint64_t>& Mm, uint64_t p, std::vector<uint64_t>& packed) {
+static void l31_pack_matrix(const std::vector<uint64_t>& Mm, uint64_t p, unsigned r_bits, std::vector<uint64_t>& packed) {
     const uint64_t B = 1ull << 31;
     packed.assign(Mm.size() + 3, 0);                                    // three zero entries past the end (see l31_dot_rt)
-    const uint64_t r64_inv_to_r62 = h_powmod(4 % p, p - 2, p);          // Mm holds M * 2^64: divide by 4
+    // Mm holds M * 2^64: bring it to M * 2^r_bits (62: divide by 4; 93: multiply by 2^29)
+    const uint64_t adjust = r_bits == 62 ? h_powmod(4 % p, p - 2, p) : h_powmod(2, r_bits - 64, p);
     for (size_t i = 0; i < Mm.size(); ++i) {
-        const uint64_t mr = h_mulmod(Mm[i], r64_inv_to_r62, p);         // M * 2^62 mod p
+        const uint64_t mr = h_mulmod(Mm[i], adjust, p);                 // M * 2^r_bits mod p
         __int128 c = mr > (p - 1) / 2 ? (__int128)mr - (__int128)p : (__int128)mr;
         int64_t c64 = (int64_t)c;
         int64_t m0 = (int64_t)(((uint64_t)c64 & (B - 1)));
@@ -631,7 +632,8 @@ static int l31_params(uint64_t p, L31Params& lp);
 // one matrix in the form the limb-31 kernels take: the kernarg copy (compiled / run-time (k, t) kernels) or device memory
 static int l31_place_matrix(sda_share_generator* g, const std::vector<uint64_t>& Mm, MatArg*& arg, DevBuf& dev) {
     std::vector<uint64_t> packed;
-    l31_pack_matrix(Mm, g->mod.m, packed);
+    // the global-matrix kernels are run-time (k, t) forms (R = 2^62); a compiled shape may be a three-digit one (R = 2^93)
+    l31_pack_matrix(Mm, g->mod.m, g->l31g ? 62u : packed_l31_r_bits(g->k, g->t), packed);
     if (g->l31g) {                                                      // matrix in global memory
         SDA_TRY(dev.reserve(packed.size() * 8));
         HIP_TRY(hipMemcpy(dev.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));

@@ -363,6 +363,108 @@ __device__ __forceinline__ int64_t l31_group5(const uint64_t* __restrict__ row, 
     return mad_sv(P.p1, q1, C2) + (C1a >> 31) + (C1b >> 31) + ((E + (int64_t)(uint64_t)lows) >> 31);
 }
 
+// ---- the three-digit form (round 4): groups of up to SEVEN terms, ONE reduction per dot product ------------------------------
+// A two-digit reduction (R = 2^62) leaves (X + q p) / 2^62 with |X| up to terms x p^2 / 4: more than five terms do not fit a
+// signed 64-bit register, so a 7-term dot product paid two reductions, a 10-term one two reductions of five, plus the lazy
+// recombination of their results.  With R = 2^93 - a THIRD radix-2^31 digit - the reduced value is X / 2^93 + q p / 2^93, i.e.
+// within (-p/2 - eps, p/2 + eps) for ANY number of terms; what limits a group is then only the columns themselves: seven
+// products of 2^60 per signed 64-bit column with the two cross columns kept apart.  Between groups the columns are not
+// reduced but NORMALISED - carries pushed one column up, the low 31 bits kept, a fifth column C3 of weight 2^93 collecting
+// the top - 15 instructions instead of a 24-instruction reduction + select + lazy add.  One dot product of 7 terms: 28
+// multiply-adds + 36 (was 28 + 51); of 10 terms: 40 + 49 (was 40 + 57).  The constants of these shapes carry R = 2^93
+// (packed_l31_r_bits).  Every register bound, incl. the worst-case prime below 2^62: tests/test_limb31_r93_model.py.
+struct L31Cols {
+    int64_t C0, C1a, C1b, C2, C3;
+};
+
+// N more terms into the columns.  FRESH: the very first group (every column starts with a product); otherwise only C1b
+// starts fresh (the normalisation folded it into C1a).
+template <int N, bool FRESH>
+__device__ __forceinline__ void l31_cols_add(L31Cols& c, const uint64_t* __restrict__ row, const int32_t* v0, const int32_t* v1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int32_t m0 = (int32_t)(uint32_t)row[i];
+        const int32_t m1 = (int32_t)(uint32_t)(row[i] >> 32);
+        if (FRESH && i == 0) {
+            c.C0 = mul_sv(m0, v0[i]); c.C1a = mul_sv(m0, v1[i]); c.C2 = mul_sv(m1, v1[i]);
+        } else {
+            c.C0 = mad_sv(m0, v0[i], c.C0); c.C1a = mad_sv(m0, v1[i], c.C1a); c.C2 = mad_sv(m1, v1[i], c.C2);
+        }
+        c.C1b = i == 0 ? mul_sv(m1, v0[i]) : mad_sv(m1, v0[i], c.C1b);
+    }
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void l31_normalize(L31Cols& c) {
+    const int64_t t0 = c.C0 >> 31;
+    c.C0 = (int64_t)(uint64_t)((uint32_t)c.C0 & 0x7FFFFFFFu);
+    c.C1a += t0;
+    const int64_t hi = (c.C1a >> 31) + (c.C1b >> 31);
+    const uint32_t lows = ((uint32_t)c.C1a & 0x7FFFFFFFu) + ((uint32_t)c.C1b & 0x7FFFFFFFu);      // < 2^32
+    c.C1a = (int64_t)(uint64_t)lows;                                                            // C1b restarts with the next group
+    c.C2 += hi;
+    const int64_t t2 = c.C2 >> 31;
+    c.C2 = (int64_t)(uint64_t)((uint32_t)c.C2 & 0x7FFFFFFFu);
+    c.C3 = FIRST ? t2 : c.C3 + t2;
+}
+
+// columns -> sum * 2^-93 mod p, canonical.  SPLIT0: the last group held seven terms, C0 + q0 p0 can pass 2^63 and its quotient
+// by 2^31 is formed from the floor of C0 and the exact quotient of (low limb + q0 p0).  HAS_C3: more than one group.
+template <bool SPLIT0, bool HAS_C3>
+__device__ __forceinline__ uint64_t l31_redc3(const L31Cols& c, const L31Params& P) {
+    const int32_t q0 = sext31((uint32_t)c.C0 * P.pinvB);
+    int64_t d0;
+    if (SPLIT0) d0 = (c.C0 >> 31) + (mad_sv(P.p0, q0, (int64_t)(uint64_t)((uint32_t)c.C0 & 0x7FFFFFFFu)) >> 31);
+    else d0 = mad_sv(P.p0, q0, c.C0) >> 31;
+    const int64_t E1 = mad_sv(P.p1, q0, d0);
+    const uint32_t lows = ((uint32_t)c.C1a & 0x7FFFFFFFu) + ((uint32_t)c.C1b & 0x7FFFFFFFu);
+    const int32_t q1 = sext31(((uint32_t)c.C1a + (uint32_t)c.C1b + (uint32_t)E1) * P.pinvB);
+    const int64_t F = mad_sv(P.p0, q1, E1);                                  // C1a + C1b + F == 0 mod 2^31
+    const int64_t carry1 = (c.C1a >> 31) + (c.C1b >> 31) + ((F + (int64_t)(uint64_t)lows) >> 31);
+    const int64_t G = mad_sv(P.p1, q1, (int64_t)(uint64_t)((uint32_t)c.C2 & 0x7FFFFFFFu)) + carry1;
+    const int32_t q2 = sext31((uint32_t)G * P.pinvB);
+    const int64_t H = mad_sv(P.p0, q2, G);                                   // == 0 mod 2^31
+    int64_t top = (c.C2 >> 31) + (H >> 31);
+    if (HAS_C3) top += c.C3;
+    const int64_t res = mad_sv(P.p1, q2, top);                               // in (-p, p)
+    const uint64_t lifted = (uint64_t)res + P.p;                             // wraps exactly when res < 0
+    return lifted < (uint64_t)res ? lifted : (uint64_t)res;
+}
+
+template <int KT>
+__device__ __forceinline__ uint64_t l31_dot3(const uint64_t* __restrict__ row, const int32_t (&v0)[KT], const int32_t (&v1)[KT],
+                                             const L31Params& P) {
+    constexpr int FULL = KT / 7, REST = KT % 7;
+    static_assert(FULL >= 1 || REST >= 1, "empty dot product");
+    L31Cols c;
+    if constexpr (FULL == 0) {
+        l31_cols_add<REST, true>(c, row, v0, v1);
+        return l31_redc3<false, false>(c, P);
+    } else {
+        l31_cols_add<7, true>(c, row, v0, v1);
+#pragma unroll
+        for (int g = 1; g < FULL; ++g) {
+            if (g == 1) l31_normalize<true>(c); else l31_normalize<false>(c);
+            l31_cols_add<7, false>(c, row + 7 * g, v0 + 7 * g, v1 + 7 * g);
+        }
+        if constexpr (REST > 0) {
+            if (FULL == 1) l31_normalize<true>(c); else l31_normalize<false>(c);
+            l31_cols_add<REST, false>(c, row + 7 * FULL, v0 + 7 * FULL, v1 + 7 * FULL);
+            return l31_redc3<false, true>(c, P);
+        } else {
+            return FULL > 1 ? l31_redc3<true, true>(c, P) : l31_redc3<true, false>(c, P);
+        }
+    }
+}
+
+// which compiled (k, t) shapes use the three-digit form: those with a compiled instance in BOTH the plain and the dual-role
+// launchers (every other shape may be served by the run-time (k, t) kernels, whose constants carry R = 2^62) and a term
+// count it pays for
+template <int K, int T>
+struct L31UseR93 {
+    static constexpr bool value = (K == 3 && T == 4) || (K == 8 && T == 2) || (K == 8 && T == 7);
+};
+
 // x in [0, 2m) -> [0, m) given neg_m = 2^64 - m: y = x - m wraps (y > x) exactly when x < m.  One 64-bit add, one compare
 // and the select - four VALU instructions; the `x >= m ? x - m : x` form costs hipcc seven (it materialises m in VGPRs
 // for a masked subtraction).
@@ -459,8 +561,14 @@ __device__ __forceinline__ void packed_gen_l31_body(const GenLayout& L, uint32_t
     }
     for (uint32_t j = direct; j < n; ++j) {
         const uint64_t* row = &M.e[(size_t)(j - direct) * KT];
-        const uint64_t a = l31_dot<KT>(row, a0, a1, lp);
-        const uint64_t b = l31_dot<KT>(row, c0, c1, lp);
+        uint64_t a, b;
+        if constexpr (L31UseR93<K, T>::value) {
+            a = l31_dot3<KT>(row, a0, a1, lp);
+            b = l31_dot3<KT>(row, c0, c1, lp);
+        } else {
+            a = l31_dot<KT>(row, a0, a1, lp);
+            b = l31_dot<KT>(row, c0, c1, lp);
+        }
         store_pair<VEC>(op + (size_t)j * L.out_stride_clerk, a, b, in0, in1);
     }
 }
@@ -1537,6 +1645,15 @@ static bool packed_l31_compiled(uint32_t k, uint32_t t) {
 #undef X
     return false;
 }
+// Montgomery radix of the constants the limb-31 kernels expect for (k, t): 2^93 for the shapes compiled in the three-digit form
+// (L31UseR93), 2^62 for everything else (incl. the run-time (k, t) kernels)
+unsigned packed_l31_r_bits(uint32_t k, uint32_t t) {
+#define X(K_, T_) if (k == K_ && t == T_) return L31UseR93<K_, T_>::value ? 93u : 62u;
+    SDA_PACKED_L31_SHAPES(X)
+#undef X
+    return 62u;
+}
+
 bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n) {
     if ((uint64_t)n * (k + t) > SDA_MAT_ARG_MAX) return false;
     if (packed_l31_compiled(k, t)) return true;

@@ -1,0 +1,146 @@
+"""Big-int model of the THREE-digit form of the balanced-31-bit-limb dot product (round 4; l31_dot3 in
+sda_amd/csrc/sda_kernels.hip): groups of up to SEVEN terms in four signed 64-bit columns (the two cross columns kept apart),
+a carry normalisation between groups instead of a reduction, and ONE Montgomery reduction with R = 2^93 (three radix-2^31
+digits) at the end - the larger R absorbs the magnitude that makes a two-digit reduction of more than five terms overflow a
+64-bit register (its result lies in (-p/2 - eps, p/2 + eps) for any term count).  Every register is checked against its
+width, on random and adversarial operands, for the largest primes below 2^62 and for small ones."""
+import random
+
+import pytest
+
+B = 1 << 31
+MB = B - 1
+R93 = 1 << 93
+
+
+def sext31(x):
+    x &= MB
+    return x - B if x >= (1 << 30) else x
+
+
+def bal(x):
+    x0 = sext31(x)
+    x1 = (x - x0) >> 31
+    assert x1 * B + x0 == x and -(1 << 30) <= x1 <= (1 << 30)
+    return x0, x1
+
+
+def i64(x):
+    assert -(1 << 63) <= x < (1 << 63), x
+    return x
+
+
+def u32(x):
+    assert 0 <= x < (1 << 32), x
+    return x
+
+
+def centre(v, p):
+    return v - p if v >= (p + 1) // 2 else v
+
+
+def groups_of(kt):
+    """l31_dot3: groups of seven, the remainder last"""
+    return [7] * (kt // 7) + ([kt % 7] if kt % 7 else [])
+
+
+def dot3(p, row, vals):
+    """row: constants m (canonical, NOT yet in Montgomery form); vals: canonical values.  Returns sum m v mod p as the kernel computes it."""
+    pinvB = (-pow(p, -1, B)) % B
+    p0, p1 = p % B, p >> 31
+    cons = [bal(centre(m * R93 % p, p)) for m in row]
+    lim = [bal(centre(v, p)) for v in vals]
+    C0 = C1a = C1b = C2 = C3 = 0
+    g = 0
+    sizes = groups_of(len(row))
+    for gi, size in enumerate(sizes):
+        if gi > 0:                                            # ---- l31_normalize: carries forward, no reduction
+            t0 = C0 >> 31
+            C0 = C0 & MB
+            C1a = i64(C1a + t0)
+            hi = i64((C1a >> 31) + (C1b >> 31))
+            lows = u32((C1a & MB) + (C1b & MB))
+            C1a, C1b = lows, 0
+            C2 = i64(C2 + hi)
+            t2 = C2 >> 31
+            C2 = C2 & MB
+            C3 = i64(C3 + t2)
+        for (m0, m1), (v0, v1) in zip(cons[g:g + size], lim[g:g + size]):
+            C0 = i64(C0 + m0 * v0)
+            C1a = i64(C1a + m0 * v1)
+            C1b = i64(C1b + m1 * v0)
+            C2 = i64(C2 + m1 * v1)
+        g += size
+    X = C0 + (C1a + C1b) * B + C2 * B * B + C3 * B * B * B
+    # ---- l31_redc3
+    q0 = sext31((C0 & 0xFFFFFFFF) * pinvB)
+    if sizes[-1] == 7:
+        # a full last group: C0 + q0 p0 can pass 2^63 (7 products of 2^60 + 2^61) - the quotient by B is formed from the floor
+        # of C0 and the exact quotient of its low limb plus q0 p0
+        low = i64((C0 & MB) + q0 * p0)
+        assert low % B == 0
+        d0 = i64((C0 >> 31) + (low >> 31))
+        assert d0 * B == C0 + q0 * p0
+    else:
+        D0 = i64(C0 + q0 * p0)
+        assert D0 % B == 0
+        d0 = D0 >> 31
+    E1 = i64(d0 + q0 * p1)
+    lows = u32((C1a & MB) + (C1b & MB))
+    q1 = sext31(((C1a & 0xFFFFFFFF) + (C1b & 0xFFFFFFFF) + (E1 & 0xFFFFFFFF)) * pinvB)
+    F = i64(E1 + q1 * p0)
+    assert (C1a + C1b + F) % B == 0
+    carry1 = i64((C1a >> 31) + (C1b >> 31) + (i64(F + lows) >> 31))
+    assert carry1 == (C1a + C1b + F) // B
+    c2lo, c2hi = C2 & MB, C2 >> 31
+    G = i64(c2lo + q1 * p1 + carry1)
+    q2 = sext31((G & 0xFFFFFFFF) * pinvB)
+    H = i64(G + q2 * p0)
+    assert H % B == 0
+    res = i64(c2hi + (H >> 31) + q2 * p1 + C3)
+    assert res * R93 == X + (q0 + q1 * B + q2 * B * B) * p
+    assert -p < res < p, (res, p)
+    lifted = (res + p) % (1 << 64)                             # unsigned wrap: exactly when res < 0
+    out = lifted if lifted < (res % (1 << 64)) else res % (1 << 64)
+    assert 0 <= out < p
+    return out
+
+
+def largest_prime_below(n):
+    from sympy import prevprime
+    return prevprime(n)
+
+
+PRIMES = [4611686006577364993, None, 433, 746497, (1 << 61) + 1 - 0]      # None -> the largest prime below 2^62
+
+
+@pytest.mark.parametrize("p", PRIMES)
+@pytest.mark.parametrize("kt", [6, 7, 9, 10, 13, 14, 15, 16])
+def test_three_digit_dot_product_exact_and_in_range(p, kt):
+    if p is None:
+        p = largest_prime_below(1 << 62)
+    if p == (1 << 61) + 1:
+        from sympy import nextprime
+        p = nextprime(1 << 61)
+    rnd = random.Random(kt * 1000 + p % 997)
+    ext = [0, 1, p - 1, (p - 1) // 2, (p + 1) // 2, 1 << 30, (1 << 30) - 1, (p - 1) // 2 - (1 << 30), ((p + 1) // 2 + (1 << 30)) % p]
+    # operands whose balanced limbs are extreme: limbs of +-2^30 in both positions
+    lim_ext = []
+    for a in (-(1 << 30), (1 << 30) - 1):
+        for b in (-(1 << 30), (1 << 30) - 1, 1 << 30):
+            x = b * B + a
+            if abs(x) <= (p - 1) // 2:
+                lim_ext.append(x % p)
+    for trial in range(300):
+        if trial < 20:
+            row = [ext[(trial + i) % len(ext)] for i in range(kt)]
+            vals = [ext[(trial * 3 + 2 * i) % len(ext)] for i in range(kt)]
+        elif trial < 60 and lim_ext:
+            # adversarial: constants whose Montgomery form has extreme limbs, values with extreme limbs, all the same sign
+            inv = pow(R93, -1, p)
+            row = [lim_ext[(trial + i) % len(lim_ext)] * inv % p for i in range(kt)] if trial & 1 else [lim_ext[trial % len(lim_ext)] * inv % p] * kt
+            vals = [lim_ext[(trial // 2 + i) % len(lim_ext)] for i in range(kt)] if trial & 2 else [lim_ext[(trial // 3) % len(lim_ext)]] * kt
+        else:
+            row = [rnd.randrange(p) for _ in range(kt)]
+            vals = [rnd.randrange(p) for _ in range(kt)]
+        assert dot3(p, row, vals) == sum(m * v for m, v in zip(row, vals)) % p
