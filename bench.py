@@ -471,7 +471,7 @@ def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, s
 
 
 # shapes the library serves with the limb GEMM on the matrix cores by default (sda_capi.cpp: compiled MFMA shape, k + t >= 12)
-MFMA_DEFAULT_SHAPES = {(8, 7), (12, 3), (10, 5), (4, 11)}
+MFMA_DEFAULT_SHAPES = {(12, 3), (10, 5), (4, 11)}        # (8, 7): the three-digit limb-31 kernel since round 4
 
 
 def _profiles_json(fname):

@@ -842,7 +842,9 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
             g->fft = true; g->l31 = g->l31g = g->fast = false;
             st = build_fft(g, fa, fb, fG, ftw);
         } else if (packed_mfma_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64) &&
-                   !knob(KNOB_NO_MFMA) && (g->k + g->t >= 12 || knob(KNOB_FORCE_MFMA))) {
+                   !knob(KNOB_NO_MFMA) && ((g->k + g->t >= 12 && !(g->l31 && packed_l31_r_bits(g->k, g->t) == 93)) || knob(KNOB_FORCE_MFMA))) {
+            // round 4: (8,7) now has a three-digit limb-31 instance (one reduction per 15-term dot product), which is ahead of the
+            // limb GEMM again - 62.2 vs 58.2 Gelem/s, interleaved A/B - so the limb GEMM keeps the other 12..16-term shapes
             // the limb GEMM on the matrix cores: measured ahead of the limb-31 kernel from k + t = 15 with n = 26 (+12 %),
             // behind it for k + t = 10 and below (knob SDA_FORCE_MFMA takes it for every compiled shape, SDA_NO_MFMA never)
             g->mfma = true; g->l31 = g->l31g = g->fast = false;

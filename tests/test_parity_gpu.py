@@ -1626,8 +1626,18 @@ def test_limb31_kernel_serves_8_7_26_when_the_limb_gemm_is_switched_off(gpu, mon
 @pytest.mark.parametrize("n", [15, 27, 31, 32, 79, 80, 81, 242])
 def test_limb_gemm_clerk_counts(gpu, n):
     """odd and extreme clerk counts of the limb-GEMM kernel (its clerk loop alternates two accumulator sets; 242 clerks is
-    what its constant table may hold): share points 3^1 .. 3^n"""
+    what its constant table may hold): share points 3^1 .. 3^n.  (Up to 29 clerks the three-digit limb-31 kernel is the
+    default for (8,7) since round 4: the knob keeps this test on the limb GEMM.)"""
+    set_knob("SDA_FORCE_MFMA", 1)
     _share_gen_vs_oracle(8, 7, n, 8 * 200 + 5, w3=W[3], odd_stride=n in (27, 80))
+
+
+@pytest.mark.parametrize("k,t,n,dim", [(8, 7, 26, 8 * 64 * 5 + 3), (8, 7, 27, 8 * 300 + 1), (8, 2, 26, 8 * 1000 + 7), (3, 4, 8, 3 * 2000 + 2),
+                                       (8, 7, 15, 8 * 100), (3, 4, 7, 3 * 100 + 1)])
+def test_three_digit_limb31_kernels_vs_oracle(gpu, k, t, n, dim):
+    """the shapes compiled in the three-digit form (R = 2^93: groups of seven terms, carry normalisation, one reduction per dot
+    product) through their DEFAULT path over the 62-bit prime: injected any-i64 randomness, device CSPRNG, reconstruct"""
+    _share_gen_vs_oracle(k, t, n, dim, w3=W[3] if n not in (8, 26) else None)
 
 
 def _share_gen_vs_oracle(k, t, n, dim, w3=None, odd_stride=False):
