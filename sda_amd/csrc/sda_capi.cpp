@@ -629,6 +629,25 @@ static void l31_pack_matrix(const std::vector<uint64_t>& Mm, uint64_t p, unsigne
 
 static int l31_params(uint64_t p, L31Params& lp);
 
+// The three-digit kernels put a remainder of one term into an 8-term last group (k + t = 15: 7 + 8).  Eight products of two
+// limbs can pass a signed 64-bit column only when all eight constant limbs are -2^30; checked here on the actual constants
+// for ANY values (|limb| <= 2^30) plus what the normalisation carries in: false -> the handle takes another kernel.
+static bool l31_eight_term_group_ok(const std::vector<uint64_t>& Mm, uint32_t kt, uint64_t p) {
+    if (kt <= 7 || kt % 7 != 1 || Mm.empty()) return true;
+    std::vector<uint64_t> packed;
+    l31_pack_matrix(Mm, p, 93, packed);
+    for (size_t r = 0; r + kt <= Mm.size(); r += kt) {
+        uint64_t s0 = 0, s1 = 0;
+        for (uint32_t i = kt - 8; i < kt; ++i) {
+            const int64_t m0 = (int32_t)(uint32_t)packed[r + i], m1 = (int32_t)(uint32_t)(packed[r + i] >> 32);
+            s0 += (uint64_t)(m0 < 0 ? -m0 : m0);
+            s1 += (uint64_t)(m1 < 0 ? -m1 : m1);
+        }
+        if ((s0 << 30) + (1ull << 32) >= (1ull << 63) || (s1 << 30) + (1ull << 33) >= (1ull << 63)) return false;
+    }
+    return true;
+}
+
 // one matrix in the form the limb-31 kernels take: the kernarg copy (compiled / run-time (k, t) kernels) or device memory
 static int l31_place_matrix(sda_share_generator* g, const std::vector<uint64_t>& Mm, MatArg*& arg, DevBuf& dev) {
     std::vector<uint64_t> packed;
@@ -831,6 +850,13 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
     if (st == SDA_OK) st = g->ctx.init();
     if (st == SDA_OK && !g->additive) {
         g->l31 = packed_l31_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64);
+        if (g->l31 && packed_l31_r_bits(g->k, g->t) == 93) {
+            // the 8-term last group of a three-digit shape is admitted on the constants of BOTH share maps
+            std::vector<uint64_t> sys_tmp;
+            bool ok = l31_eight_term_group_ok(g->Mmont, g->k + g->t, g->mod.m);
+            if (ok && build_systematic_share_matrix(*scheme, g->mod.m, sys_tmp)) ok = l31_eight_term_group_ok(sys_tmp, g->k + g->t, g->mod.m);
+            if (!ok) g->l31 = false;
+        }
         g->fast = !g->l31 && packed_fast_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC);
         g->l31g = !g->l31 && !g->fast && packed_l31_global_path_available(g->k, g->t) && !knob(KNOB_FORCE_GENERIC) &&
                   !knob(KNOB_FORCE_MONT64);

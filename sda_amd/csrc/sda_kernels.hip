@@ -434,12 +434,16 @@ __device__ __forceinline__ uint64_t l31_redc3(const L31Cols& c, const L31Params&
 template <int KT>
 __device__ __forceinline__ uint64_t l31_dot3(const uint64_t* __restrict__ row, const int32_t (&v0)[KT], const int32_t (&v1)[KT],
                                              const L31Params& P) {
-    constexpr int FULL = KT / 7, REST = KT % 7;
+    // groups of seven; a remainder of ONE term joins the group before it (15 = 7 + 8: saves a normalisation) - eight products
+    // of 2^60 can pass 2^63 only if all eight limbs are -2^30, which the host rules out on the actual constants
+    // (l31_eight_term_group_ok in sda_capi.cpp; the shape is served by another kernel otherwise)
+    constexpr bool EIGHT = KT > 7 && KT % 7 == 1;
+    constexpr int FULL = EIGHT ? KT / 7 - 1 : KT / 7, REST = EIGHT ? 8 : KT % 7;
     static_assert(FULL >= 1 || REST >= 1, "empty dot product");
     L31Cols c;
     if constexpr (FULL == 0) {
         l31_cols_add<REST, true>(c, row, v0, v1);
-        return l31_redc3<false, false>(c, P);
+        return l31_redc3<(REST >= 7), false>(c, P);
     } else {
         l31_cols_add<7, true>(c, row, v0, v1);
 #pragma unroll
@@ -450,7 +454,7 @@ __device__ __forceinline__ uint64_t l31_dot3(const uint64_t* __restrict__ row, c
         if constexpr (REST > 0) {
             if (FULL == 1) l31_normalize<true>(c); else l31_normalize<false>(c);
             l31_cols_add<REST, false>(c, row + 7 * FULL, v0 + 7 * FULL, v1 + 7 * FULL);
-            return l31_redc3<false, true>(c, P);
+            return l31_redc3<(REST >= 7), true>(c, P);
         } else {
             return FULL > 1 ? l31_redc3<true, true>(c, P) : l31_redc3<true, false>(c, P);
         }

@@ -40,8 +40,21 @@ def centre(v, p):
 
 
 def groups_of(kt):
-    """l31_dot3: groups of seven, the remainder last"""
-    return [7] * (kt // 7) + ([kt % 7] if kt % 7 else [])
+    """l31_dot3: groups of seven, the remainder last; a remainder of ONE term joins the group before it (7 + 8 for 15 terms),
+    which the host admits only after checking the actual constants (host_admits_eight)"""
+    sizes = [7] * (kt // 7) + ([kt % 7] if kt % 7 else [])
+    if len(sizes) >= 2 and sizes[-1] == 1:
+        sizes = sizes[:-2] + [8]
+    return sizes
+
+
+def host_admits_eight(cons, sizes):
+    """sda_capi.cpp: an 8-term last group needs every column to stay inside a signed 64-bit register for ANY values (limbs of
+    magnitude <= 2^30): sum |m0| 2^30 + 2^32 < 2^63 and the same for m1 - false only when all eight limbs are -2^30"""
+    if sizes[-1] != 8:
+        return True
+    grp = cons[-8:]
+    return (sum(abs(m0) for m0, _ in grp) << 30) + (1 << 32) < (1 << 63) and (sum(abs(m1) for _, m1 in grp) << 30) + (1 << 33) < (1 << 63)
 
 
 def dot3(p, row, vals):
@@ -53,6 +66,8 @@ def dot3(p, row, vals):
     C0 = C1a = C1b = C2 = C3 = 0
     g = 0
     sizes = groups_of(len(row))
+    if not host_admits_eight(cons, sizes):
+        return sum(m * v for m, v in zip(row, vals)) % p          # the library then serves the shape with another kernel
     for gi, size in enumerate(sizes):
         if gi > 0:                                            # ---- l31_normalize: carries forward, no reduction
             t0 = C0 >> 31
@@ -74,7 +89,7 @@ def dot3(p, row, vals):
     X = C0 + (C1a + C1b) * B + C2 * B * B + C3 * B * B * B
     # ---- l31_redc3
     q0 = sext31((C0 & 0xFFFFFFFF) * pinvB)
-    if sizes[-1] == 7:
+    if sizes[-1] >= 7:
         # a full last group: C0 + q0 p0 can pass 2^63 (7 products of 2^60 + 2^61) - the quotient by B is formed from the floor
         # of C0 and the exact quotient of its low limb plus q0 p0
         low = i64((C0 & MB) + q0 * p0)
