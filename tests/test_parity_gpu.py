@@ -1638,6 +1638,24 @@ def test_three_digit_limb31_kernels_vs_oracle(gpu, k, t, n, dim):
     """the shapes compiled in the three-digit form (R = 2^93: groups of seven terms, carry normalisation, one reduction per dot
     product) through their DEFAULT path over the 62-bit prime: injected any-i64 randomness, device CSPRNG, reconstruct"""
     _share_gen_vs_oracle(k, t, n, dim, w3=W[3] if n not in (8, 26) else None)
+    # adversarial operands: secrets and injected draws whose balanced 31-bit limbs are all extreme (+-2^30) and all alike within
+    # a batch, so that every product of a column has the same sign and the largest magnitude the limbs allow
+    from sda_amd import crypto
+    from oracle import coracle
+    w2 = _root(P62, k + t + 1)
+    w3 = W[3] if n not in (8, 26) else _root(P62, n + 1)
+    gen = crypto.ShareGenerator(crypto.PackedShamir(k, n, t, P62, w2, w3))
+    ext = []
+    for a in (-(1 << 30), (1 << 30) - 1):
+        for b in (-(1 << 30) + 1, (1 << 30) - 1, -(1 << 30)):
+            x = b * (1 << 31) + a
+            if abs(x) <= (P62 - 1) // 2:
+                ext.append(x % P62)
+    ext += [0, 1, P62 - 1, (P62 - 1) // 2, (P62 + 1) // 2]
+    B = len(ext) * len(ext)
+    secrets = np.array([ext[(b // len(ext))] for b in range(B) for _ in range(k)], dtype=np.int64)
+    rand = np.array([ext[(b % len(ext))] for b in range(B) for _ in range(t)], dtype=np.int64)
+    assert np.array_equal(gen.generate(secrets, rand), coracle.packed_generate(P62, k, t, n, w2, w3, secrets, rand))
 
 
 def _share_gen_vs_oracle(k, t, n, dim, w3=None, odd_stride=False):
