@@ -18,6 +18,33 @@
 // k and t are kernel arguments (KTMAX = 4 / 8 / 12 / 16 bounds k + t); the matrix travels in the kernarg segment as
 // int32 constants (MatArg reinterpreted: 896 entries), rows back to back, zero padded by three entries.
 
+// sda-drbg-v1 draws for a modulus below 2^32: the same words, the same acceptance rule (lo64(x m) >= 2^64 mod m) and value
+// (hi64(x m)) as drbg_pair, with the 96-bit product x m formed from two 32 x 32 -> 64 multiply-adds instead of a 64 x 64 one
+__device__ __forceinline__ bool lemire_sample_m32(uint64_t x, uint32_t m, uint64_t thr, uint64_t& out) {
+    const uint64_t t0 = (uint64_t)(uint32_t)x * m;
+    const uint64_t t1 = (uint64_t)(uint32_t)(x >> 32) * m + (t0 >> 32);
+    out = t1 >> 32;
+    return ((t1 << 32) | (uint32_t)t0) >= thr;
+}
+template <int ROUNDS>
+__device__ __forceinline__ void drbg_pair_m32(const DrbgKey& key, const QuadCol& qc, uint64_t stream, uint64_t pair, uint32_t T,
+                                              uint32_t i, const ModParams& mod, uint64_t& r0, uint64_t& r1) {
+    const uint32_t c = threadIdx.x & 3;
+    const uint64_t I = (pair >> 2) * (uint64_t)T + i;
+    const uint32_t ctr = c == 0 ? (uint32_t)I : c == 1 ? (uint32_t)(I >> 32) : c == 2 ? (uint32_t)stream
+                                                                              : ((uint32_t)(stream >> 32) & 0xFFFFFFu);
+    uint32_t o0, o1, o2, o3;
+    chacha_block_quad<ROUNDS>(qc.cst, qc.kb, qc.kc, ctr, o0, o1, o2, o3);
+    const bool ok0 = lemire_sample_m32(((uint64_t)o0 << 32) | o1, (uint32_t)mod.m, mod.lemire_thr, r0);
+    const bool ok1 = lemire_sample_m32(((uint64_t)o2 << 32) | o3, (uint32_t)mod.m, mod.lemire_thr, r1);
+    if (__builtin_expect(!ok0, 0))
+        r0 = drbg_retry<ROUNDS>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
+                                (2 * pair) * (uint64_t)T + i, mod.m, mod.lemire_thr);
+    if (__builtin_expect(!ok1, 0))
+        r1 = drbg_retry<ROUNDS>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
+                                (2 * pair + 1) * (uint64_t)T + i, mod.m, mod.lemire_thr);
+}
+
 __device__ __forceinline__ int32_t n31_centre(uint64_t v, const N31Params& P) {          // canonical [0, p) -> centred
     const uint32_t x = (uint32_t)v;
     return (int32_t)(x >= P.h ? x - P.p : x);
@@ -94,7 +121,7 @@ __device__ __forceinline__ void packed_gen_n31_body(const GenLayout& L, uint32_t
                 a = in0 ? canon_i64(rp[b0 * t + (i - k)], mod.m, mod.mu) : 0;
                 b = in1 ? canon_i64(rp[(b0 + 1) * t + (i - k)], mod.m, mod.mu) : 0;
             } else {
-                drbg_pair<ROUNDS>(key, qc, stream, pair, t, (uint32_t)i - k, mod, a, b);
+                drbg_pair_m32<ROUNDS>(key, qc, stream, pair, t, (uint32_t)i - k, mod, a, b);
                 if (direct) {                                                // draw i - k IS share i - k
                     int64_t* o = op + (size_t)((uint32_t)i - k) * L.out_stride_clerk;
                     if (vec && in1) store2(o, a, b);
