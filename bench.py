@@ -254,7 +254,7 @@ class Env:
         # A/B runs (tools/*.sh) and the one-rank RCCL test select non-default kernels by environment variable; the release
         # library reads none, so the bench - a measurement tool - hands them to its test-only entry point (sda_hip_debug.h)
         for name in ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
-                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY"):
+                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM"):
             if os.environ.get(name):
                 v = os.environ[name]
                 capi.check(self.lib.sda_debug_set_knob(name.encode(), int(v) if v.lstrip("-").isdigit() else 1))
@@ -636,7 +636,10 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     kern = ("fused_additive_kernel" if w["kind"] != "packed" else
             "fused_packed_n31_kernel" if narrow and w["k"] + w["t"] <= 16 else
             "fused_packed_mfma_kernel" if (w["k"], w["t"]) in MFMA_DEFAULT_SHAPES else
-            "fused_packed_l31_kernel" if w["k"] + w["t"] <= 16 else "packed_gen_fft_kernel + combine_update_kernel (no dual-role form)")
+            "fused_packed_l31_kernel" if w["k"] + w["t"] <= 16 else
+            "packed_gen_ngemm_kernel + combine_update_kernel (no dual-role form)"
+            if narrow and prime_of(w) < (1 << 23) and not os.environ.get("SDA_NO_NGEMM") else
+            "packed_gen_fft_kernel + combine_update_kernel (no dual-role form)")
     has_dual = w["kind"] != "packed" or w["k"] + w["t"] <= 16
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
                 "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid (shares "

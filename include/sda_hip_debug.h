@@ -20,6 +20,8 @@
  *   SDA_WIRE_WG_PER_CU n, SDA_SBOX_WG_PER_CU n   residency caps (unused dynamic LDS) of the varint stream kernels / the XSalsa20 kernel
  *   SDA_NO_XCD_MAP 1           transform kernel with fewer than 8 batches per workgroup: plain group order (default: the
  *                              workgroups that share a 128-byte line of a clerk row are placed on one XCD)
+ *   SDA_NO_NGEMM 1             large shapes over a prime below 2^23 through the transform kernel (default: the limb GEMM on the
+ *                              matrix cores, ngemm_kernels.hip)
  *   SDA_FORCE_COLLECTIVES 1    a one-rank communicator still goes through RCCL send/recv to itself
  * Built with -DSDA_AB_KNOBS (tools/build_ab_variant.sh; never by __graft_entry__.build()) an unset knob falls back to the
  * environment variable of the same name. */

@@ -134,6 +134,22 @@ size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds, bool nar
 hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
                                       hipStream_t s);
 
+// packed Shamir over a narrow prime (p < 2^23) as a limb GEMM on the matrix cores: any (k, t) with k + t <= 512, any n
+// (ngemm_kernels.hip).  Draws are the transform kernel's (tss's nodes), ChaCha20 only.
+struct NGemmPlan {
+    uint32_t k, t, n;
+    uint32_t ks;               // 64-term steps of the compiled instance: 1, 2, 4 or 8 (>= ceil((k + t) / 64), zero padded)
+    uint32_t row_tiles;        // ceil(n / 16)
+    int32_t c[5];              // centred representatives of 256^j 2^32 mod p: column j -> Montgomery operand
+    N31Params np;
+    const uint8_t* A;          // device: [row_tiles][ks][3 digits][64 lanes][16 bytes] - the A fragments of M's balanced digits,
+                               // zero beyond n rows / k + t terms
+};
+size_t ngemm_tile_bytes(uint32_t ks);
+bool packed_ngemm_path_available(uint32_t k, uint32_t t, uint64_t p);
+uint32_t packed_ngemm_steps(uint32_t k, uint32_t t);
+hipError_t launch_packed_generate_ngemm(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, hipStream_t s);
+
 // packed Shamir, any shape: matrix in global memory, randomness must be materialised (L.rand != 0)
 hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
                                           const ModParams& mod, const MontParams& mont,

@@ -1,0 +1,456 @@
+// Packed-Shamir share generation over a NARROW prime (p < 2^23: tss's shipped 746497 and 5038849, full_loop.rs's 433) for
+// LARGE shapes (k + t > 16, e.g. tss's PSS_155_728_100) as a limb GEMM on the matrix cores.
+//
+// packed_shamir.rs:42 -> tss share(): shares = M [secrets ; draws], M the n x (k + t) matrix of the polynomial through
+// (1, 0), the secrets at omega_secrets^(1..k) and the draws at omega_secrets^(k+1..k+t), evaluated at omega_shares^(1..n).
+// The transform kernel (fft_kernels.hip) computes this product with tss's own radix-2 / radix-3 structure in ~15 vector
+// instructions per secret and is bound by the vector ALUs at 0.42 of the HBM roofline.  Over a prime this small the DENSE
+// product is cheaper on this chip: a centred residue |x| <= p / 2 < 2^22 is THREE balanced base-256 digits (int8), so
+//     column c = sum over terms and la + lb = c of digit_la(M) digit_lb(value)          (c = 0..4)
+// is nine v_mfma_i32_16x16x64_i8 per 16 shares x 16 batches x 64 terms - 2.4 M multiply-adds per batch of PSS_155_728_100 at
+// 16384 per instruction - and the five 32-bit column sums of one share come back to ONE residue with five v_mad_i64_i32 by
+// c_j = 256^j 2^32 mod p and one three-instruction Montgomery reduction (R = 2^32).  Per secret: ~17 matrix-core cycles per
+// SIMD and ~1.5 vector instructions of epilogue, beside the t / k ChaCha20 draws that every form of this path pays.
+//
+// Work decomposition.  A workgroup (4 waves) owns 64 NT consecutive batches of one participant; wave w holds the value
+// digits of its 16 NT batches for ALL terms in registers (B operands: NT x KS x 3 fragments) and the workgroup sweeps the
+// n / 16 row tiles of the matrix, whose digits the host laid out fragment by fragment ([row tile][64-term step][digit][lane]
+// 16 bytes): a tile is copied global -> registers -> LDS (double buffered, the copy of tile r + 1 in flight under the
+// products of tile r) and read back with conflict-free 16-byte LDS loads.  Shares leave as 128-byte row segments (16
+// batches x 8 bytes), non-temporal.  Values reach the B-operand layout through an LDS tile [digit][batch][64 terms],
+// one 64-term step at a time; the draws are the per-lane sda-drbg-v1 blocks of the transform kernel (one block = draw i of
+// 8 consecutive batches), so both kernels produce identical shares from identical inputs and keys.
+//
+// Exactness and every bound (digits, columns, the reduction's operand): tests/test_ngemm_model.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "capi_internal.hpp"
+#include "chacha.hpp"
+#include "drbg_lane.hpp"
+#include "kernels.hpp"
+#include "modarith.hpp"
+
+namespace sda {
+
+typedef int ng_v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t ng_v4u __attribute__((ext_vector_type(4)));
+
+static constexpr int kNgCompute = 8;                // compute waves per workgroup (two per SIMD), one workgroup per CU
+static constexpr int kNgWorkers = 64 * kNgCompute;
+static constexpr int kNgThreads = kNgWorkers + 64;  // + the loader wave
+static constexpr int kNgRow = 80;                 // bytes of one (digit, batch) row of the value tile: 64 terms + 16 (bank spread)
+
+// c x + acc as ONE v_mad_i64_i32.  Written in plain C on purpose: the operand x comes straight out of an MFMA accumulator, and
+// only instructions the compiler selects itself get the wait states that a matrix-core result needs before a vector
+// instruction may read it (an inline-asm v_mad_i64_i32 placed right behind the v_mfma read stale registers: rows 4 g + 0 of
+// the first batch tile, measured).  The constants sit in VGPRs (pinned once per kernel) because hipcc selects the 64-bit
+// multiply-add only for vector x vector operands.
+__device__ __forceinline__ int32_t ng_pin_vgpr(int32_t c) {
+    asm volatile("" : "+v"(c));
+    return c;
+}
+__device__ __forceinline__ int64_t ng_mad(int32_t v_c, int32_t x, int64_t acc) { return (int64_t)v_c * (int64_t)x + acc; }
+// canonical residue -> the three balanced base-256 digits of its centred representative, in bytes 0..2 (two's complement)
+__device__ __forceinline__ uint32_t ng_digits(uint32_t v, const N31Params& P) {
+    const uint32_t x = v >= P.h ? v - P.p : v;
+    return (x + 0x00808080u) ^ 0x00808080u;
+}
+__device__ __forceinline__ void ng_put(uint8_t* tile, uint32_t wgb, uint32_t batch, uint32_t term, uint32_t d) {
+    uint8_t* q = tile + (size_t)batch * kNgRow + term;
+    q[0] = (uint8_t)d;
+    q[(size_t)wgb * kNgRow] = (uint8_t)(d >> 8);
+    q[(size_t)2 * wgb * kNgRow] = (uint8_t)(d >> 16);
+}
+// S = sum_j C_j c_j (|S| < p 2^31) -> S 2^-32 mod p, canonical: q = lo(S) (-p^-1); (S + q p) / 2^32 = hi(S) + mulhi(q, p) +
+// (lo(S) != 0) lies in (-p, p); the unsigned minimum of t and t + p is the canonical one (t < 0 wraps to a huge value)
+__device__ __forceinline__ uint32_t ng_redc(int64_t S, const N31Params& P) {
+    const uint32_t sl = (uint32_t)S;
+    const int32_t sh = (int32_t)(S >> 32);
+    const int32_t q = (int32_t)(sl * P.pinv);
+    const uint32_t t = (uint32_t)(sh + __mulhi(q, (int32_t)P.p) + (sl != 0 ? 1 : 0));
+    const uint32_t u = t + P.p;
+    return u < t ? u : t;
+}
+
+// any i64 -> canonical residue: the common case (already canonical) inline, the rest behind a call - the staging code is
+// executed a few times per workgroup and has to stay small (see ng_stage)
+__device__ __noinline__ uint64_t ng_canon_slow(int64_t x, uint64_t m, uint64_t mu) { return canon_i64(x, m, mu); }
+__device__ __forceinline__ uint32_t ng_canon(int64_t x, const ModParams& mod) {
+    return (uint64_t)x < mod.m ? (uint32_t)x : (uint32_t)ng_canon_slow(x, mod.m, mod.mu);
+}
+
+// ---- the three passes of a 64-term step of the values [secrets (zero-padded, batched.rs:37-43) ; draws ; zeros] --------------
+// Each pass is ONE function (not inlined) shared by all steps: inlined per step the kernel was 121 KB of code for four steps,
+// streamed once per workgroup through an instruction cache of 64 KB that two CUs share.  (A run-time loop over the steps keeps
+// one copy too, but then the B fragments - indexed by the step - leave the registers: 11.8 -> 29.5 ms per tile, measured.)
+
+// secrets / injected draws / zero padding of the step -> digit tile.  lane = term, one batch per wave and round; ALL the loads
+// are issued before the first value is used (clamped addresses, no branches in between): one memory latency per step
+template <int WGB>
+__device__ __noinline__ void ng_load_pass(uint8_t* Bt, const int64_t* sp, const int64_t* rp, uint64_t len, uint64_t batches, uint64_t b0,
+                                          uint32_t k, uint32_t t, uint32_t t_lo, uint64_t m, uint64_t mu, uint32_t p32, uint32_t h32) {
+    constexpr int ROUNDS_ = WGB / kNgCompute;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, kt = k + t;
+    const ModParams mod{m, mu, 0};
+    N31Params np; np.p = p32; np.h = h32; np.pinv = 0; np.pad = 0;
+    const uint32_t term = t_lo + lane;
+    const bool is_secret = term < k, is_draw = !is_secret && term < kt;
+    const int64_t* src = is_secret ? sp : rp;                               // rp may be null: then no lane of a draw term loads
+    const uint32_t per = is_secret ? k : t, off = is_secret ? term : term - k;
+    const uint64_t lim = is_secret ? len : batches * (uint64_t)t;
+    const bool reads = is_secret || (is_draw && rp != nullptr);
+    int64_t raw[ROUNDS_];
+    // every batch of the workgroup and every secret of those batches exists (all workgroups but a participant's last): no
+    // clamps, no per-element bounds, one pointer increment per round
+    const bool full = b0 + WGB <= batches && (b0 + WGB) * (uint64_t)k <= len;
+    if (full) {
+        if (reads) {
+            const int64_t* q = src + (b0 + wave) * per + off;
+            const size_t step = (size_t)kNgCompute * per;
+#pragma unroll
+            for (int it = 0; it < ROUNDS_; ++it) raw[it] = q[(size_t)it * step];
+        }
+        if (!is_draw || rp != nullptr) {                                    // CSPRNG draws are written by ng_draw_pass
+            uint8_t* dst = Bt + (size_t)wave * kNgRow + lane;
+#pragma unroll
+            for (int it = 0; it < ROUNDS_; ++it) {
+                const uint32_t d = reads ? ng_digits(ng_canon(raw[it], mod), np) : 0u;
+                uint8_t* w = dst + (size_t)it * (kNgCompute * kNgRow);
+                w[0] = (uint8_t)d;
+                w[(size_t)WGB * kNgRow] = (uint8_t)(d >> 8);
+                w[(size_t)2 * WGB * kNgRow] = (uint8_t)(d >> 16);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < ROUNDS_; ++it) {
+        const uint64_t b = b0 + (uint32_t)it * (uint32_t)kNgCompute + wave;
+        uint64_t e = b * per + off;
+        e = e < lim ? e : 0;
+        raw[it] = reads ? src[e] : 0;
+    }
+    if (!is_draw || rp != nullptr) {
+#pragma unroll
+        for (int it = 0; it < ROUNDS_; ++it) {
+            const uint32_t bl = (uint32_t)it * (uint32_t)kNgCompute + wave;
+            const uint64_t b = b0 + bl, e = b * per + off;
+            const uint32_t v = reads && b < batches && e < lim ? ng_canon(raw[it], mod) : 0u;
+            ng_put(Bt, WGB, bl, lane, ng_digits(v, np));
+        }
+    }
+}
+
+// the CSPRNG draws d_lo .. d_lo + cd - 1 of the workgroup's batches -> digit tile (sda-drbg-v1, one block = draw i of 8 batches)
+template <int WGB>
+__device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t stream, uint64_t b0, uint32_t k, uint32_t t, uint32_t t_lo,
+                                          uint32_t d_lo, uint32_t cd, uint64_t m, uint64_t lemire_thr, uint32_t p32, uint32_t h32) {
+    N31Params np; np.p = p32; np.h = h32; np.pinv = 0; np.pad = 0;
+    const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
+#pragma unroll 1
+    for (uint32_t u = threadIdx.x; u < (uint32_t)(WGB / 8) * cd; u += kNgWorkers) {
+        const uint32_t nb = u / cd, i = d_lo + (u - nb * cd);
+        const uint64_t I = ((b0 >> 3) + nb) * (uint64_t)t + i;
+        uint32_t o[16];
+        chacha_block_lane<20>(kk, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream, (uint32_t)(stream >> 32) & 0xFFFFFFu, o);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int cc = jj >> 1, e = jj & 1;
+            const uint64_t xw = ((uint64_t)o[8 * e + cc] << 32) | o[8 * e + 4 + cc];
+            uint64_t val;
+            if (!f_lemire32(xw, (uint32_t)m, lemire_thr, val))
+                val = f_drbg_retry<20>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream,
+                                       (b0 + 8u * nb + jj) * (uint64_t)t + i, m, lemire_thr);
+            ng_put(Bt, WGB, 8u * nb + jj, k + i - t_lo, ng_digits((uint32_t)val, np));
+        }
+    }
+}
+
+// systematic share map: draw i of a batch IS its share i.  The step's draws are read back from the tile (three digits ->
+// canonical value) with lane = batch, so that a row leaves in 512-byte pieces (a lane that stored its own block's eight values
+// wrote 64 rows per instruction: 12.2 -> 16.0 ms per 500-participant tile, measured)
+template <int WGB>
+__device__ __noinline__ void ng_direct_pass(const uint8_t* Bt, int64_t* op, size_t stride_clerk, uint64_t b0, uint64_t batches, uint32_t k,
+                                            uint32_t t_lo, uint32_t d_lo, uint32_t d_hi, uint32_t p32) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // four terms per tile read (one dword per digit plane): the term offsets of the step's draws, rounded out to multiples of 4
+    const uint32_t o_lo = (k + d_lo - t_lo) & ~3u, o_hi = k + d_hi - t_lo;                   // byte offsets in a tile row, o_hi <= 64
+    for (uint32_t bg = 0; bg < (uint32_t)(WGB / 64); ++bg) {
+        const uint32_t bl = 64u * bg + lane;
+        const uint64_t b = b0 + bl;
+        const uint8_t* q = Bt + (size_t)bl * kNgRow;
+        for (uint32_t o = o_lo + 4u * wave; o < o_hi; o += 4u * (uint32_t)kNgCompute) {
+            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(q + o);
+            const uint32_t w1 = *reinterpret_cast<const uint32_t*>(q + (size_t)WGB * kNgRow + o);
+            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(q + (size_t)2 * WGB * kNgRow + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int32_t x = (int32_t)(int8_t)(w0 >> (8 * j)) + 256 * (int32_t)(int8_t)(w1 >> (8 * j)) + 65536 * (int32_t)(int8_t)(w2 >> (8 * j));
+                const uint32_t v = x < 0 ? (uint32_t)x + p32 : (uint32_t)x;
+                const uint32_t term = t_lo + o + (uint32_t)j;                                    // draw term - k = share row
+                if (b < batches && term >= k + d_lo && term < k + d_hi)
+                    __builtin_nontemporal_store((long long)v, reinterpret_cast<long long*>(op + (size_t)(term - k) * stride_clerk + b));
+            }
+        }
+    }
+}
+
+// step STEP: the three passes, then the B fragments of the step (a template recursion: the fragment array must be indexed by
+// constants to stay in registers)
+template <int KS, int NT, int STEP>
+__device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS][3], uint8_t* Bt, const GenLayout& L, const ModParams& mod, const DrbgKey& key,
+                                         const NGemmPlan& P, const int64_t* sp, const int64_t* rp, int64_t* op, uint64_t stream, uint64_t b0,
+                                         uint64_t batches
+#ifdef NG_TIMING
+                                         , uint64_t (&ng_tm)[4]
+#endif
+                                         ) {
+    constexpr int WB = 16 * NT, WGB = kNgCompute * WB;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, col = lane & 15u, g = lane >> 4;
+    const uint32_t k = P.k, t = P.t, kt = k + t, t_lo = 64u * STEP;
+    const bool worker = wave < (uint32_t)kNgCompute;
+    const bool loads = t_lo < k || rp != nullptr || t_lo + 64u > kt;         // uniform: something besides CSPRNG draws in this step
+    const bool draws_here = !rp && t_lo + 64u > k && t_lo < kt;              // draws d_lo .. d_hi - 1 fall into this step
+    const uint32_t d_lo = t_lo > k ? t_lo - k : 0u, d_hi = draws_here ? (t_lo + 64u < kt ? t_lo + 64u : kt) - k : d_lo;
+#ifdef NG_TIMING
+    const uint64_t tq0 = __builtin_readcyclecounter();
+#endif
+    if (worker) {
+        if (loads) ng_load_pass<WGB>(Bt, sp, rp, L.len, batches, b0, k, t, t_lo, mod.m, mod.mu, P.np.p, P.np.h);
+#ifdef NG_TIMING
+        ng_tm[0] += __builtin_readcyclecounter() - tq0;
+#endif
+        if (draws_here) ng_draw_pass<WGB>(Bt, key, stream, b0, k, t, t_lo, d_lo, d_hi - d_lo, mod.m, mod.lemire_thr, P.np.p, P.np.h);
+    }
+#ifdef NG_TIMING
+    const uint64_t tq1 = __builtin_readcyclecounter();
+#endif
+    __syncthreads();
+#ifdef NG_TIMING
+    const uint64_t tq2 = __builtin_readcyclecounter();
+    ng_tm[1] += tq1 - tq0; ng_tm[2] += tq2 - tq1;
+#endif
+    if (worker) {
+        if (draws_here && L.direct_rows) ng_direct_pass<WGB>(Bt, op, L.out_stride_clerk, b0, batches, k, t_lo, d_lo, d_hi, P.np.p);
+#ifdef NG_TIMING
+        ng_tm[3] += __builtin_readcyclecounter() - tq2;
+#endif
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int lb = 0; lb < 3; ++lb)
+                bfrag[nt][STEP][lb] = *reinterpret_cast<const ng_v4i*>(Bt + ((size_t)lb * WGB + wave * WB + 16 * nt + col) * kNgRow + 16 * g);
+    }
+    __syncthreads();
+#ifdef NG_TIMING
+    if constexpr (STEP + 1 < KS) ng_stage<KS, NT, STEP + 1>(bfrag, Bt, L, mod, key, P, sp, rp, op, stream, b0, batches, ng_tm);
+#else
+    if constexpr (STEP + 1 < KS) ng_stage<KS, NT, STEP + 1>(bfrag, Bt, L, mod, key, P, sp, rp, op, stream, b0, batches);
+#endif
+}
+
+template <int KS> struct NgRing { static constexpr int depth = KS == 8 ? 2 : 4; };   // LDS slots of A tiles (two workgroups per CU)
+
+#ifdef NG_LOADER_REGS
+template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+#else
+template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
+
+template <int KS, int NT>
+// 168 registers: three waves per SIMD, i.e. the ten waves of two workgroups on a CU's four SIMDs
+__global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void packed_gen_ngemm_kernel(GenLayout L, ModParams mod, DrbgKey key, NGemmPlan P,
+                                                                        uint64_t chunks, uint64_t batches) {
+    constexpr int WB = 16 * NT, WGB = kNgCompute * WB;                       // batches per wave / per workgroup
+    constexpr int PIECES = KS * 3, ATILE = PIECES * 1024;           // one row tile: PIECES fragments of 1 KiB
+    constexpr int DEPTH = NgRing<KS>::depth;
+    extern __shared__ __align__(16) uint8_t ng_lds[];
+    uint8_t* Abuf = ng_lds;                                          // [DEPTH][ATILE]
+    uint8_t* Bt = ng_lds + DEPTH * ATILE;                            // [3][WGB][kNgRow]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, col = lane & 15u, g = lane >> 4;
+    const uint64_t p = blockIdx.x / chunks, chunk = blockIdx.x - p * chunks;
+    const uint64_t b0 = chunk * WGB;
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
+    const uint64_t stream = L.first_participant + p;
+    const uint32_t tiles = P.row_tiles;
+    // Wave 4 is the LOADER: it only moves A tiles global -> LDS (global_load_lds, 1 KiB per instruction, no registers) and keeps
+    // the barriers.  The four compute waves never load in the row loop, so nothing ever waits for their share stores: vmcnt is
+    // an in-order counter, and with the loads in the compute waves every tile waited for the previous tile's non-temporal
+    // stores to be acknowledged by HBM (52 % of the wave cycles in wait states, measured).
+    const bool loader = wave == (uint32_t)kNgCompute;
+    auto issue_tile = [&](uint32_t tile, uint32_t slot) {
+        const uint8_t* src = P.A + (size_t)tile * ATILE + lane * 16;
+        uint8_t* dst = Abuf + slot * ATILE;
+#ifdef NG_LOADER_REGS
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q)
+            *reinterpret_cast<ng_v4u*>(dst + q * 1024 + lane * 16) = *reinterpret_cast<const ng_v4u*>(src + q * 1024);
+#else
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+#endif
+    };
+    if (loader) {
+        for (uint32_t tile = 0; tile < (uint32_t)(DEPTH - 1) && tile < tiles; ++tile) issue_tile(tile, tile);
+        ng_wait_vm<0>();                                            // landed before the first of the staging phase's barriers
+    }
+
+    // ---- values -> B fragments, one 64-term step at a time -------------------------------------------------------------------
+#ifdef NG_TIMING
+    const uint64_t ng_t0 = __builtin_readcyclecounter();
+#endif
+    ng_v4i bfrag[NT][KS][3];
+    int64_t* op = L.out + p * L.out_stride_participant;
+#ifdef NG_TIMING
+    uint64_t ng_tm[4] = {0, 0, 0, 0};
+    ng_stage<KS, NT, 0>(bfrag, Bt, L, mod, key, P, sp, rp, op, stream, b0, batches, ng_tm);
+    const uint64_t ng_t1 = __builtin_readcyclecounter();
+#else
+    ng_stage<KS, NT, 0>(bfrag, Bt, L, mod, key, P, sp, rp, op, stream, b0, batches);
+#endif
+
+    // ---- the row tiles ---------------------------------------------------------------------------------------------------
+    if (loader) {
+        uint32_t slot = DEPTH - 1;                                  // slot of tile rt + DEPTH - 1
+        for (uint32_t rt = 0; rt < tiles; ++rt) {
+            const uint32_t nxt = rt + DEPTH - 1;
+            if (nxt < tiles) {
+                issue_tile(nxt, slot);                              // the slot tile rt - 1 was read from (free since the last barrier)
+                ng_wait_vm<PIECES * (DEPTH - 2) < 63 ? PIECES * (DEPTH - 2) : 0>();     // tile rt + 1 has landed
+            } else {
+                ng_wait_vm<0>();
+            }
+            slot = slot + 1 == (uint32_t)DEPTH ? 0u : slot + 1;
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    // this lane's output rows: 4 g + i of every tile, batch column bw (+ 16 per batch tile)
+    const uint64_t bw = b0 + wave * WB + col;
+    // (systematic share map: the matrix has the rows direct_rows .. n - 1, rows 0 .. direct_rows - 1 were the draws)
+    int64_t* orow = op + bw + (size_t)((rp ? 0u : L.direct_rows) + 4u * g) * L.out_stride_clerk;
+    const size_t tile_step = 16 * L.out_stride_clerk;
+    const int32_t c0 = ng_pin_vgpr(P.c[0]), c1 = ng_pin_vgpr(P.c[1]), c2 = ng_pin_vgpr(P.c[2]), c3 = ng_pin_vgpr(P.c[3]), c4 = ng_pin_vgpr(P.c[4]);
+    // The two compute waves of a SIMD run half a period apart: waves 0-3 multiply tile r and THEN reduce and store it, waves 4-7
+    // first reduce and store tile r - 1 and then multiply tile r - so one wave's products run beside the other's vector work.
+    // (With every wave in the same order the per-tile barrier keeps all of them in lockstep: all on the matrix cores, then all on
+    // the vector ALUs - 3700 cycles per tile where 2300 are matrix-core time, measured.)
+    const bool late = wave >= (uint32_t)(kNgCompute / 2);
+    ng_v4i acc[NT][5];
+    auto products = [&](uint32_t slot_) {
+        const uint8_t* Acur = Abuf + slot_ * ATILE;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[nt][c] = ng_v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int la = 0; la < 3; ++la) {
+                const ng_v4i a = *reinterpret_cast<const ng_v4i*>(Acur + ((size_t)(ks * 3 + la) * 64 + lane) * 16);
+#pragma unroll
+                for (int lb = 0; lb < 3; ++lb)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bfrag[nt][ks][lb], acc[nt][la + lb], 0, 0, 0);
+            }
+    };
+    // shares = rows 16 rt + 4 g + i of tile rt, canonical, clerk-major (batched.rs:46-48): all of them first (straight-line
+    // code), then the stores under their masks
+    auto finish = [&](uint32_t rt) {
+        uint32_t share[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int64_t S = ng_mad(c0, acc[nt][0][i], 0);
+                S = ng_mad(c1, acc[nt][1][i], S);
+                S = ng_mad(c2, acc[nt][2][i], S);
+                S = ng_mad(c3, acc[nt][3][i], S);
+                S = ng_mad(c4, acc[nt][4][i], S);
+                share[nt][i] = ng_redc(S, P.np);
+                asm volatile("" : "+v"(share[nt][i]));
+            }
+        const uint32_t row0 = 16u * rt + 4u * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (bw + 16u * nt < batches) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (row0 + (uint32_t)i < P.n)
+                        __builtin_nontemporal_store((long long)share[nt][i], reinterpret_cast<long long*>(orow + (size_t)i * L.out_stride_clerk + 16 * nt));
+            }
+        orow += tile_step;
+    };
+    uint32_t slot = 0;
+    for (uint32_t rt = 0; rt < tiles; ++rt) {
+        if (late && rt) finish(rt - 1);
+        products(slot);
+        slot = slot + 1 == (uint32_t)DEPTH ? 0u : slot + 1;
+        if (!late) finish(rt);
+        __syncthreads();                                            // tile rt + 1 is in LDS (the loader waited for it); slot of tile rt is free
+    }
+    if (late) finish(tiles - 1);
+#ifdef NG_TIMING
+    if (tid == 0) {                                                 // timing build only: overwrites two shares with cycle counts
+        int64_t* o = L.out + p * L.out_stride_participant + b0;
+        o[0] = (int64_t)(ng_t1 - ng_t0);
+        o[1] = (int64_t)(__builtin_readcyclecounter() - ng_t1);
+        o[2] = (int64_t)ng_tm[0]; o[3] = (int64_t)ng_tm[1]; o[4] = (int64_t)ng_tm[2]; o[5] = (int64_t)ng_tm[3];
+    }
+#endif
+}
+
+bool packed_ngemm_path_available(uint32_t k, uint32_t t, uint64_t p) {
+    return k >= 1 && k + t >= 1 && k + t <= 512 && p < (1ull << 23);
+}
+uint32_t packed_ngemm_steps(uint32_t k, uint32_t t) {                // 64-term steps the compiled instances provide: 1, 2, 4, 8
+    const uint32_t need = (k + t + 63) / 64;
+    return need <= 1 ? 1u : need <= 2 ? 2u : need <= 4 ? 4u : 8u;
+}
+
+size_t ngemm_tile_bytes(uint32_t ks) { return (size_t)ks * 3 * 1024; }     // one row tile of A fragments
+
+template <int KS, int NT>
+static hipError_t ngemm_launch(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, hipStream_t s) {
+    constexpr int WGB = 16 * kNgCompute * NT;
+    const uint64_t batches = (L.len + P.k - 1) / P.k;
+    const uint64_t chunks = (batches + WGB - 1) / WGB;
+    if (chunks * L.participants == 0) return hipSuccess;
+    const size_t lds = NgRing<KS>::depth * ngemm_tile_bytes(KS) + 3 * (size_t)WGB * kNgRow;
+    auto kern = packed_gen_ngemm_kernel<KS, NT>;
+    if (lds > 64 * 1024)
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
+    const uint64_t max_blocks = 0x7FFFFFFFull;
+    uint64_t per = max_blocks / chunks;
+    if (per == 0) return hipErrorInvalidConfiguration;
+    if (per > L.participants) per = L.participants;
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        GenLayout S = L;
+        const uint64_t cnt = per < L.participants - p0 ? per : L.participants - p0;
+        S.secrets = L.secrets + p0 * L.secrets_stride;
+        if (L.rand) S.rand = L.rand + p0 * L.rand_stride;
+        S.out = L.out + p0 * L.out_stride_participant;
+        S.participants = cnt;
+        S.first_participant = L.first_participant + p0;
+        kern<<<dim3((unsigned)(chunks * cnt)), dim3(kNgThreads), lds, s>>>(S, mod, key, P, chunks, batches);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_packed_generate_ngemm(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, hipStream_t s) {
+    switch (P.ks) {
+        case 1: return ngemm_launch<1, 4>(L, mod, key, P, s);
+        case 2: return ngemm_launch<2, 2>(L, mod, key, P, s);
+        case 4: return ngemm_launch<4, 2>(L, mod, key, P, s);
+        case 8: return ngemm_launch<8, 1>(L, mod, key, P, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace sda

@@ -101,7 +101,7 @@ namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
     "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES",
-    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP"};
+    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP", "SDA_NO_NGEMM"};
 std::atomic<long> g_knobs[sda::KNOB_COUNT];
 }  // namespace
 long sda::knob(sda::Knob k) {
@@ -525,6 +525,9 @@ struct sda_share_generator {
     bool mfma = false;                   // limb GEMM on the matrix cores (d_M holds the byte-reversed balanced constants)
     FftPlan fplan{};
     DevBuf d_fft;
+    bool ngemm = false;                  // narrow prime (p < 2^23): the transform shapes run as a limb GEMM on the matrix cores instead
+    NGemmPlan gplan{}, gplan_sys{};      // tss's share map (n rows) / the systematic one (n - t rows, shares 0..t-1 = the draws)
+    DevBuf d_ngemm, d_ngemm_sys;
     L31Params lp{};
     Drbg drbg;
     Ctx ctx;
@@ -821,6 +824,47 @@ static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G,
     return SDA_OK;
 }
 
+// The narrow limb GEMM's constants (ngemm_kernels.hip): the plain matrix M = Mmont 2^-64, centred, in three balanced base-256
+// digits, laid out as the A fragments of v_mfma_i32_16x16x64_i8 - [row tile][64-term step][digit][lane = row | g << 4][16 terms] -
+// zero beyond n rows / k + t terms; and c_j = 256^j 2^32 mod p (centred) for the epilogue's Montgomery operand.
+static int build_ngemm_plan(sda_share_generator* g, const std::vector<uint64_t>& Mm, uint32_t rows, DevBuf& dev, NGemmPlan& P) {
+    const uint64_t p = g->mod.m;
+    const uint32_t kt = g->k + g->t, ks = packed_ngemm_steps(g->k, g->t), tiles = (rows + 15) / 16;
+    uint64_t inv64, inv;
+    if (!h_invmod(h_powmod(2, 64, p), p, inv64) || !h_invmod(p, 1ull << 32, inv)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not odd");
+    const size_t tile_bytes = ngemm_tile_bytes(ks);
+    std::vector<uint8_t> A((size_t)tiles * tile_bytes, 0);
+    for (uint32_t r = 0; r < rows; ++r)
+        for (uint32_t i = 0; i < kt; ++i) {
+            const uint64_t m = h_mulmod(Mm[(size_t)r * kt + i], inv64, p);
+            const int64_t x = m > (p - 1) / 2 ? (int64_t)m - (int64_t)p : (int64_t)m;
+            const uint32_t d = ((uint32_t)(int32_t)x + 0x00808080u) ^ 0x00808080u;
+            const uint32_t rt = r >> 4, row = r & 15u, step = i >> 6, gq = (i >> 4) & 3u, j = i & 15u;
+            for (uint32_t la = 0; la < 3; ++la)
+                A[(size_t)rt * tile_bytes + (((size_t)step * 3 + la) * 64 + (row | gq << 4)) * 16 + j] = (uint8_t)(d >> (8 * la));
+        }
+    SDA_TRY(dev.reserve(A.size() + 16));
+    if (!A.empty()) HIP_TRY(hipMemcpy(dev.p, A.data(), A.size(), hipMemcpyHostToDevice));
+    P.k = g->k; P.t = g->t; P.n = rows; P.ks = ks; P.row_tiles = tiles;
+    P.np.p = (uint32_t)p; P.np.pinv = (uint32_t)((1ull << 32) - inv); P.np.h = (uint32_t)((p + 1) / 2); P.np.pad = 0;
+    uint64_t c = (1ull << 32) % p;
+    for (int j = 0; j < 5; ++j) {
+        P.c[j] = c > (p - 1) / 2 ? (int32_t)((int64_t)c - (int64_t)p) : (int32_t)c;
+        c = h_mulmod(c, 256, p);
+    }
+    P.A = dev.as<uint8_t>();
+    return SDA_OK;
+}
+static int build_ngemm(sda_share_generator* g) {
+    SDA_TRY(build_ngemm_plan(g, g->Mmont, g->n, g->d_ngemm, g->gplan));
+    // with the library's own randomness the draws ARE shares 0..t-1 (the systematic share map of the matrix-form kernels):
+    // t of the n rows cost nothing (PSS_155_728_100: 155 of 728)
+    g->sys_default = build_systematic_share_matrix(g->scheme, g->mod.m, g->Msys);
+    if (g->sys_default) SDA_TRY(build_ngemm_plan(g, g->Msys, g->n - g->t, g->d_ngemm_sys, g->gplan_sys));
+    g->ngemm = true;
+    return SDA_OK;
+}
+
 extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_share_generator_t** out) {
     if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -867,6 +911,11 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
             fft_shape(g, fa, fb, fG, ftw)) {
             g->fft = true; g->l31 = g->l31g = g->fast = false;
             st = build_fft(g, fa, fb, fG, ftw);
+            // over a prime below 2^23 (tss's own) the dense product on the matrix cores is ahead of the transform (k + t > 16:
+            // below that the one-limb vector kernels serve the shape); same draws, same shares - the transform plan stays built
+            // for the other ChaCha round counts and A/B runs (knob SDA_NO_NGEMM)
+            if (st == SDA_OK && g->fplan.narrow && !knob(KNOB_NO_NGEMM) && g->k + g->t > 16 && packed_ngemm_path_available(g->k, g->t, g->mod.m))
+                st = build_ngemm(g);
         } else if (packed_mfma_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64) &&
                    !knob(KNOB_NO_MFMA) && ((g->k + g->t >= 12 && !(g->l31 && packed_l31_r_bits(g->k, g->t) == 93)) || knob(KNOB_FORCE_MFMA))) {
             // round 4: (8,7) now has a three-digit limb-31 instance (one reduction per 15-term dot product), which is ahead of the
@@ -918,7 +967,7 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
 extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
     if (!g) return;
     if (g->ctx.device >= 0) (void)hipSetDevice(g->ctx.device);
-    g->d_M.release(); g->d_Msys.release(); g->d_fft.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
+    g->d_M.release(); g->d_Msys.release(); g->d_fft.release(); g->d_ngemm.release(); g->d_ngemm_sys.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
     if (g->aux) { (void)hipStreamSynchronize(g->aux); (void)hipStreamDestroy(g->aux); }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
@@ -1044,8 +1093,19 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
         return SDA_OK;
     }
     if (g->fft) {
-        HIP_TRY(launch_packed_generate_fft(L, g->mod, key, g->fplan, g->drbg.rounds, s));
-        return SDA_OK;
+        if (g->ngemm && (d_rand || g->drbg.rounds == 20)) {
+            HIP_TRY(launch_packed_generate_ngemm(L, g->mod, key, sys ? g->gplan_sys : g->gplan, s));
+            return SDA_OK;
+        }
+        if (!sys) {
+            HIP_TRY(launch_packed_generate_fft(L, g->mod, key, g->fplan, g->drbg.rounds, s));
+            return SDA_OK;
+        }
+        // the systematic map under another ChaCha round count (A/B only): the any-shape kernel below, matrices uploaded on first use
+        if (!g->d_Msys.p) {
+            SDA_TRY(g->d_Msys.reserve(g->Msys.size() * 8 + 8));
+            HIP_TRY(hipMemcpy(g->d_Msys.p, g->Msys.data(), g->Msys.size() * 8, hipMemcpyHostToDevice));
+        }
     }
     if (g->mfma) {
         HIP_TRY(launch_packed_generate_mfma(L, g->n, g->k, g->t, g->mod, g->mont, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key,
@@ -1247,7 +1307,10 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     // that shape the clerk sum of the previous tile is issued on a side stream and runs in the wave slots the transform
     // kernel leaves free: fork after whatever precedes this call on `stream`, join before anything that follows it
     const bool both = prev_participants > 0 && participants > 0 && len > 0;
-    if (st == SDA_OK && !fused && both && g->fft && !knob(KNOB_NO_SIDE_STREAM)) {
+    // (the narrow limb GEMM fills every SIMD's registers with its own nine waves per CU: a clerk sum on a side stream found no
+    // room beside it - 18.9 ms per 500-participant tile of PSS_155_728_100 against 16.9 for the two launches back to back)
+    const bool gemm_form = g->fft && g->ngemm && g->drbg.rounds == 20;
+    if (st == SDA_OK && !fused && both && g->fft && !gemm_form && !knob(KNOB_NO_SIDE_STREAM)) {
         st = g->side_stream();
         if (st == SDA_OK) {
             hipError_t e = hipEventRecord(g->ev_fork, s);

@@ -121,6 +121,7 @@ def test_narrow_transform_kernel_vs_oracle_and_wide(gpu, p, k, t, n, w2, w3, dim
     sec2 = rng.integers(0, p, size=(2, dim), dtype=np.int64)
     results = []
     for narrow in (True, "no_lazy", False):                                 # lazy radix-3 levels (default where (4b+4)p < 2^32), reduced, wide
+        set_knob("SDA_NO_NGEMM", 1)                                         # the transform kernel itself (tests/test_ngemm_gpu.py: the limb GEMM)
         if k + t <= 32:
             set_knob("SDA_FORCE_FFT", 1)
         set_knob("SDA_NO_NARROW", 0 if narrow else 1)

@@ -1,0 +1,137 @@
+"""-m gpu parity tests of the narrow limb GEMM (sda_amd/csrc/ngemm_kernels.hip): packed-Shamir share generation of the large
+tss-valid shapes over a prime below 2^23 (tss's own 746497 and 5038849) on the matrix cores.  Every case is checked against the
+oracle (packed_shamir.rs:42 -> tss share(), restated in oracle/) with injected randomness and with the device CSPRNG, and
+against the transform kernel serving the same handle parameters (knob SDA_NO_NGEMM, include/sda_hip_debug.h): all three agree
+bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import set_knob
+
+pytestmark = pytest.mark.gpu
+
+KEY = bytes((i * 11 + 3) & 0xFF for i in range(32))
+TSS_P1, TSS_P2 = 746497, 5038849
+
+
+def _root(p, order):
+    assert (p - 1) % order == 0
+    for g in range(2, 2000):
+        w = pow(g, (p - 1) // order, p)
+        if all(pow(w, order // f, p) != 1 for f in (2, 3) if order % f == 0):
+            return w
+    raise AssertionError("no root")
+
+
+CASES = [
+    (TSS_P1, 100, 155, 728, 95660, 610121, 100 * 150 + 37),          # tss's PSS_155_728_100, its own roots: 4 steps, 151 batches (two workgroups, ragged)
+    (TSS_P1, 100, 155, 728, 95660, 610121, 1),                       # a single secret
+    (TSS_P2, 100, 155, 19682, 4318906, 1814687, 250),                # tss's PSS_155_19682_100: 1231 row tiles
+    (TSS_P1, 40, 23, 242, None, None, 40 * 300 + 1),                 # 63 terms: one step, 256 batches per workgroup, 301 batches
+    (TSS_P1, 70, 57, 242, None, None, 70 * 260),                     # 127 terms: two steps
+    (TSS_P1, 300, 211, 728, None, None, 300 * 70 + 11),              # 511 terms: eight steps, 64 batches per workgroup
+    (TSS_P2, 20, 11, 80, None, None, 20 * 100 + 3),                  # 31 terms, n = 80: five row tiles
+    (TSS_P1, 9, 22, 242, None, None, 9 * 129),                       # draws start inside the first step; n = 242: the last row tile ragged
+]
+
+
+@pytest.mark.parametrize("p,k,t,n,w2,w3,dim", CASES)
+def test_narrow_limb_gemm_vs_oracle_and_transform(gpu, p, k, t, n, w2, w3, dim):
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    w2 = w2 or _root(p, k + t + 1)
+    w3 = w3 or _root(p, n + 1)
+    rng = np.random.default_rng(k * 1000 + n)
+    secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
+    secrets[: min(dim, 6)] = [0, p - 1, p, -1, p // 2, p // 2 + 1][: min(dim, 6)]
+    P = 3
+    sec2 = rng.integers(0, p, size=(P, dim), dtype=np.int64)
+    results = []
+    for gemm in (True, False):
+        set_knob("SDA_NO_NGEMM", 0 if gemm else 1)
+        if k + t <= 32:
+            set_knob("SDA_FORCE_FFT", 1)                               # small tss-valid shapes default to the matrix kernels
+        sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+        gen = crypto.ShareGenerator(sch)
+        # the limb GEMM's draws are shares 0..t-1 (systematic map, like every matrix-form kernel); the transform kernel's are tss's nodes
+        assert gen.csprng_share_map() == (gen.SHARE_MAP_SYSTEMATIC if gemm and t > 0 else gen.SHARE_MAP_TSS_NODES)
+        B = gen.batch_count(dim)
+        rand = np.random.default_rng(7).integers(-(1 << 62), 1 << 62, size=B * t, dtype=np.int64)
+        got = gen.generate(secrets, rand)
+        assert np.array_equal(got, coracle.packed_generate(p, k, t, n, w2, w3, secrets, rand)), gemm
+        gen.set_drbg_key(KEY)
+        d_sec = DeviceBuffer.from_numpy(sec2)
+        Bs = (B + 15) // 16 * 16 + 16
+        first = (1 << 33) + 9
+        for share_map in ((gen.SHARE_MAP_SYSTEMATIC, gen.SHARE_MAP_TSS_NODES) if gemm else (gen.SHARE_MAP_TSS_NODES,)):
+            gen.set_csprng_share_map(share_map)
+            d_out = DeviceBuffer(P * n * Bs).zero()
+            gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=first)
+            o = d_out.to_numpy().reshape(P, n, Bs)
+            for q in range(P):
+                w = coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec2[q], coracle.drbg_fill(KEY, first + q, B, t, p), share_map)
+                assert np.array_equal(o[q, :, :B], w), (gemm, share_map, q)
+            assert not o[:, :, B:].any()                               # nothing beyond a row's batches
+        results.append((got, o.copy()))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+
+
+def test_narrow_limb_gemm_odd_strides_and_clerk_major_layout(gpu):
+    """job-major output ([clerk][participant][batch]) with an odd row stride and an unaligned base: the 8-byte stores need no
+    alignment; nothing is written past a row"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    p, k, t, n = TSS_P1, 40, 23, 242
+    w2, w3 = _root(p, 64), _root(p, 243)
+    dim, P, first = 40 * 77 + 5, 2, 123
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    B = gen.batch_count(dim)
+    Bs = B | 1
+    rng = np.random.default_rng(5)
+    stride = dim + 3
+    sec = rng.integers(-(1 << 62), 1 << 62, size=(P, stride), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec)
+    d_out = DeviceBuffer(n * P * Bs + 1).zero()
+    gen.generate_batch_dev(d_sec.ptr, P, dim, stride, d_out.ptr + 8, Bs, P * Bs, first_participant=first)
+    out = d_out.to_numpy()[1:].reshape(n, P, Bs)
+    for q in range(P):
+        want = coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[q, :dim], coracle.drbg_fill(KEY, first + q, B, t, p),
+                                              gen.csprng_share_map())
+        assert np.array_equal(out[:, q, :B], want), q
+    assert not out[:, :, B:].any()
+
+
+def test_narrow_limb_gemm_share_combine_reveal_roundtrip(gpu):
+    """tss's PSS_155_728_100 over tss's prime through the pipelined step (share generation of tile i beside the clerk sum of
+    tile i - 1), then the reveal from an arbitrary t + k clerks = the sum of the secrets"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    p, k, t, n, w2, w3 = TSS_P1, 100, 155, 728, 95660, 610121
+    dim, P, tiles = 100 * 40 + 7, 5, 3
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    comb = crypto.ShareCombiner(sch)
+    B = gen.batch_count(dim)
+    Bs = (B + 15) // 16 * 16
+    rng = np.random.default_rng(11)
+    secs = [rng.integers(0, p, size=(P, dim), dtype=np.int64) for _ in range(tiles)]
+    d_secs = [DeviceBuffer.from_numpy(s) for s in secs]
+    bufs = [DeviceBuffer(n * P * Bs).zero() for _ in range(2)]
+    comb.begin_dev(n, B)
+    for i in range(tiles + 1):
+        gen.generate_combine_dev(comb, d_secs[i].ptr if i < tiles else 0, P if i < tiles else 0, dim, dim, bufs[i % 2].ptr, Bs, P * Bs,
+                                 d_prev=bufs[(i - 1) % 2].ptr if i > 0 else 0, prev_participants=P if i > 0 else 0,
+                                 first_participant=i * P)
+    d_sums = DeviceBuffer(n * B)
+    comb.finish_dev(d_sums.ptr)
+    sums = d_sums.to_numpy().reshape(n, B)
+    idx = sorted(rng.choice(n, size=t + k, replace=False).tolist())
+    rec = crypto.SecretReconstructor(sch, dim).reconstruct([(i, sums[i]) for i in idx])
+    truth = np.zeros(dim, dtype=np.int64)
+    for s in secs:
+        truth = (truth + s.sum(axis=0)) % p
+    assert np.array_equal(rec, truth)

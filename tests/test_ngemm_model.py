@@ -1,0 +1,95 @@
+"""Big-int model of the narrow limb GEMM (sda_amd/csrc/ngemm_kernels.hip): residues of a prime below 2^23 as three balanced
+base-256 digits, five signed 32-bit column sums per share (what v_mfma_i32_16x16x64_i8 accumulates), the epilogue's
+sum_j C_j c_j with c_j = 256^j 2^32 mod p in a signed 64-bit register and the Montgomery reduction with R = 2^32.  Every
+register is checked against its width and the result against plain modular arithmetic, for random and extreme operands at
+the largest term count the kernels take (k + t = 512)."""
+import random
+
+import pytest
+
+PRIMES = [3, 433, 746497, 5038849, 8388593]          # 8388593: the largest prime below 2^23
+
+
+def digits(v, p):
+    """ng_digits: canonical residue -> three balanced digits of its centred representative"""
+    h = (p + 1) // 2
+    x = (v - p if v >= h else v) & 0xFFFFFFFF
+    y = ((x + 0x00808080) & 0xFFFFFFFF) ^ 0x00808080
+    d = [((y >> (8 * i)) & 0xFF) for i in range(3)]
+    d = [b - 256 if b >= 128 else b for b in d]
+    c = v - p if v >= h else v
+    assert d[0] + 256 * d[1] + 65536 * d[2] == c, (v, p, d)
+    return d
+
+
+def wrap32(x):
+    x &= 0xFFFFFFFF
+    return x - (1 << 32) if x >> 31 else x
+
+
+def share(row, vals, p):
+    """one dot product the way the kernel forms it; returns the canonical share"""
+    C = [0] * 5
+    for m, v in zip(row, vals):
+        dm, dv = digits(m, p), digits(v, p)
+        for a in range(3):
+            for b in range(3):
+                C[a + b] += dm[a] * dv[b]
+    for c in C:
+        assert -(1 << 31) <= c < (1 << 31)                       # the MFMA accumulators
+    cj = []
+    x = (1 << 32) % p
+    for _ in range(5):
+        cj.append(x - p if x > (p - 1) // 2 else x)
+        x = x * 256 % p
+    S = 0
+    for c, k in zip(C, cj):
+        S += c * k
+        assert -(1 << 63) <= S < (1 << 63)                        # v_mad_i64_i32 chain
+    assert abs(S) < p << 31                                       # the reduction's operand bound
+    pinv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+    sl, sh = S & 0xFFFFFFFF, S >> 32
+    q = wrap32(sl * pinv)
+    assert (S + q * p) % (1 << 32) == 0
+    t = sh + ((q * p) >> 32) + (1 if sl else 0)
+    assert t == (S + q * p) >> 32 and -p < t < p
+    tu = t & 0xFFFFFFFF
+    u = (tu + p) & 0xFFFFFFFF
+    r = u if u < tu else tu                                       # v_min_u32
+    assert 0 <= r < p
+    return r
+
+
+@pytest.mark.parametrize("p", PRIMES)
+def test_digits_cover_every_residue_class_edge(p):
+    for v in {0, 1, p - 1, p // 2, p // 2 + 1, (p + 1) // 2, max(0, p // 2 - 1), 127, 128, 129, 32767, 32768, 32896} | \
+            {random.Random(p).randrange(p) for _ in range(2000)}:
+        if 0 <= v < p:
+            digits(v, p)
+
+
+@pytest.mark.parametrize("p", PRIMES)
+@pytest.mark.parametrize("terms", [17, 63, 255, 512])
+def test_dot_products_exact(p, terms):
+    rng = random.Random(p * 1000 + terms)
+    h = p // 2
+    extremes = [h, h + 1, p - 1, 0, 1]
+    for trial in range(12):
+        if trial < 5:                                             # all operands at one extreme: the largest column sums
+            row = [extremes[trial]] * terms
+            vals = [extremes[(trial * 2) % 5]] * terms
+        elif trial < 8:
+            row = [rng.choice(extremes) for _ in range(terms)]
+            vals = [rng.choice(extremes) for _ in range(terms)]
+        else:
+            row = [rng.randrange(p) for _ in range(terms)]
+            vals = [rng.randrange(p) for _ in range(terms)]
+        want = sum(m * v for m, v in zip(row, vals)) % p
+        assert share(row, vals, p) == want
+
+
+def test_column_bound_holds_for_any_operands_at_512_terms():
+    # |digit| <= 128, three digit pairs share the middle column: 3 * 512 * 128 * 128 < 2^31
+    assert 3 * 512 * 128 * 128 < 1 << 31
+    # sum_j |C_j| <= terms * (sum |dM|) (sum |dV|) <= 512 * 384 * 384, |c_j| <= p / 2: |S| < p 2^31
+    assert 512 * 384 * 384 // 2 < 1 << 31

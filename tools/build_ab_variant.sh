@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/.."
 OUT=sda_amd/lib/ab_obj; mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSDA_AB_KNOBS"
-for f in sda_kernels.hip varint_kernels.hip wire_kernels.hip sealedbox_kernels.hip fft_kernels.hip signed_kernels.hip narrow_kernels.hip sda_capi.cpp sda_comm.cpp sda_wire.cpp sda_sealedbox.cpp; do
+for f in sda_kernels.hip varint_kernels.hip wire_kernels.hip sealedbox_kernels.hip fft_kernels.hip ngemm_kernels.hip signed_kernels.hip narrow_kernels.hip sda_capi.cpp sda_comm.cpp sda_wire.cpp sda_sealedbox.cpp; do
   [ -f sda_amd/csrc/$f ] || continue
   (cd /tmp && /opt/rocm/bin/hipcc $FLAGS -c $OLDPWD/sda_amd/csrc/$f -o $OLDPWD/$OUT/$f.o) &
 done
