@@ -62,13 +62,12 @@ __device__ __forceinline__ void ng_put(uint8_t* tile, uint32_t wgb, uint32_t bat
     q[(size_t)wgb * kNgRow] = (uint8_t)(d >> 8);
     q[(size_t)2 * wgb * kNgRow] = (uint8_t)(d >> 16);
 }
-// S = sum_j C_j c_j (|S| < p 2^31) -> S 2^-32 mod p, canonical: q = lo(S) (-p^-1); (S + q p) / 2^32 = hi(S) + mulhi(q, p) +
-// (lo(S) != 0) lies in (-p, p); the unsigned minimum of t and t + p is the canonical one (t < 0 wraps to a huge value)
+// S = sum_j C_j c_j (|S| < p 2^31) -> S 2^-32 mod p, canonical.  q = lo(S) p^-1 (signed 32 bits): q p has the low word of S, so
+// (S - q p) / 2^32 = hi(S) - mulhi(q, p) with no borrow to look after - three instructions - and lies in (-p, p); the unsigned
+// minimum of t and t + p is the canonical one (a negative t wraps to a huge value)
 __device__ __forceinline__ uint32_t ng_redc(int64_t S, const N31Params& P) {
-    const uint32_t sl = (uint32_t)S;
-    const int32_t sh = (int32_t)(S >> 32);
-    const int32_t q = (int32_t)(sl * P.pinv);
-    const uint32_t t = (uint32_t)(sh + __mulhi(q, (int32_t)P.p) + (sl != 0 ? 1 : 0));
+    const int32_t q = (int32_t)((uint32_t)S * P.pinv);              // P.pinv = +p^-1 mod 2^32 in this kernel's plan
+    const uint32_t t = (uint32_t)((int32_t)(S >> 32) - __mulhi(q, (int32_t)P.p));
     const uint32_t u = t + P.p;
     return u < t ? u : t;
 }

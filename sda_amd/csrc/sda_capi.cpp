@@ -846,7 +846,7 @@ static int build_ngemm_plan(sda_share_generator* g, const std::vector<uint64_t>&
     SDA_TRY(dev.reserve(A.size() + 16));
     if (!A.empty()) HIP_TRY(hipMemcpy(dev.p, A.data(), A.size(), hipMemcpyHostToDevice));
     P.k = g->k; P.t = g->t; P.n = rows; P.ks = ks; P.row_tiles = tiles;
-    P.np.p = (uint32_t)p; P.np.pinv = (uint32_t)((1ull << 32) - inv); P.np.h = (uint32_t)((p + 1) / 2); P.np.pad = 0;
+    P.np.p = (uint32_t)p; P.np.pinv = (uint32_t)inv /* +p^-1 mod 2^32: ng_redc subtracts */; P.np.h = (uint32_t)((p + 1) / 2); P.np.pad = 0;
     uint64_t c = (1ull << 32) % p;
     for (int j = 0; j < 5; ++j) {
         P.c[j] = c > (p - 1) / 2 ? (int32_t)((int64_t)c - (int64_t)p) : (int32_t)c;

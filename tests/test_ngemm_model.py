@@ -47,12 +47,13 @@ def share(row, vals, p):
         S += c * k
         assert -(1 << 63) <= S < (1 << 63)                        # v_mad_i64_i32 chain
     assert abs(S) < p << 31                                       # the reduction's operand bound
-    pinv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+    pinv = pow(p, -1, 1 << 32)
     sl, sh = S & 0xFFFFFFFF, S >> 32
     q = wrap32(sl * pinv)
-    assert (S + q * p) % (1 << 32) == 0
-    t = sh + ((q * p) >> 32) + (1 if sl else 0)
-    assert t == (S + q * p) >> 32 and -p < t < p
+    assert (S - q * p) % (1 << 32) == 0
+    t = sh - ((q * p) >> 32)                                      # v_mul_hi_i32 (floor): no borrow, the low words are equal
+    assert -(1 << 31) <= sh < (1 << 31)
+    assert t == (S - q * p) >> 32 and -p < t < p
     tu = t & 0xFFFFFFFF
     u = (tu + p) & 0xFFFFFFFF
     r = u if u < tu else tu                                       # v_min_u32
