@@ -859,7 +859,7 @@ static int build_ngemm(sda_share_generator* g) {
     SDA_TRY(build_ngemm_plan(g, g->Mmont, g->n, g->d_ngemm, g->gplan));
     // with the library's own randomness the draws ARE shares 0..t-1 (the systematic share map of the matrix-form kernels):
     // t of the n rows cost nothing (PSS_155_728_100: 155 of 728)
-    g->sys_default = build_systematic_share_matrix(g->scheme, g->mod.m, g->Msys);
+    if (g->Msys.empty()) g->sys_default = build_systematic_share_matrix(g->scheme, g->mod.m, g->Msys);
     if (g->sys_default) SDA_TRY(build_ngemm_plan(g, g->Msys, g->n - g->t, g->d_ngemm_sys, g->gplan_sys));
     g->ngemm = true;
     return SDA_OK;
@@ -958,6 +958,13 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
         const bool forced = knob(KNOB_FORCE_GENERIC) || knob(KNOB_FORCE_MONT64) || knob(KNOB_FORCE_MFMA) || knob(KNOB_FORCE_FFT);
         if (st == SDA_OK && !g->fft && !forced && !knob(KNOB_NO_NARROW) && packed_n31_path_available(g->k, g->t, g->n, g->mod.m))
             st = build_n31(g);
+        // ... and beyond the one-limb kernels' 16 terms ANY shape over a prime below 2^23 takes the limb GEMM on the matrix cores
+        // (it only needs the share matrix, not tss's transform structure)
+        if (st == SDA_OK && !g->ngemm && !g->n31 && !forced && !knob(KNOB_NO_NARROW) && !knob(KNOB_NO_NGEMM) && g->k + g->t > 16 &&
+            packed_ngemm_path_available(g->k, g->t, g->mod.m)) {
+            st = build_ngemm(g);
+            if (st == SDA_OK) g->sys = g->sys_default;
+        }
     }
     if (st != SDA_OK) { sda_share_generator_free(g); return st; }
     *out = g;
@@ -1077,6 +1084,10 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
     }
     if (g->n31 && (d_rand || g->drbg.rounds == 20)) {
         HIP_TRY(launch_packed_generate_n31(L, g->n, g->k, g->t, g->mod, g->n31p, sys ? *g->matarg_n31_sys : *g->matarg_n31, key, s));
+        return SDA_OK;
+    }
+    if (g->ngemm && !g->fft && (d_rand || g->drbg.rounds == 20)) {
+        HIP_TRY(launch_packed_generate_ngemm(L, g->mod, key, sys ? g->gplan_sys : g->gplan, s));
         return SDA_OK;
     }
     if (g->l31) {

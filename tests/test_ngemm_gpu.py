@@ -32,6 +32,8 @@ CASES = [
     (TSS_P1, 300, 211, 728, None, None, 300 * 70 + 11),              # 511 terms: eight steps, 64 batches per workgroup
     (TSS_P2, 20, 11, 80, None, None, 20 * 100 + 3),                  # 31 terms, n = 80: five row tiles
     (TSS_P1, 9, 22, 242, None, None, 9 * 129),                       # draws start inside the first step; n = 242: the last row tile ragged
+    (TSS_P1, 20, 13, 50, "o64", "o81", 20 * 77 + 3),                 # NOT tss-valid (34 of 64 nodes, 50 of 80 share points): no transform kernel
+    (TSS_P1, 33, 0, 80, "o64", "o81", 33 * 50 + 1),                  # no privacy threshold: no draws, no systematic map
 ]
 
 
@@ -40,8 +42,9 @@ def test_narrow_limb_gemm_vs_oracle_and_transform(gpu, p, k, t, n, w2, w3, dim):
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     from oracle import coracle
-    w2 = w2 or _root(p, k + t + 1)
-    w3 = w3 or _root(p, n + 1)
+    tss_valid = not isinstance(w2, str)
+    w2 = _root(p, int(w2[1:])) if isinstance(w2, str) else w2 or _root(p, k + t + 1)
+    w3 = _root(p, int(w3[1:])) if isinstance(w3, str) else w3 or _root(p, n + 1)
     rng = np.random.default_rng(k * 1000 + n)
     secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
     secrets[: min(dim, 6)] = [0, p - 1, p, -1, p // 2, p // 2 + 1][: min(dim, 6)]
@@ -50,12 +53,12 @@ def test_narrow_limb_gemm_vs_oracle_and_transform(gpu, p, k, t, n, w2, w3, dim):
     results = []
     for gemm in (True, False):
         set_knob("SDA_NO_NGEMM", 0 if gemm else 1)
-        if k + t <= 32:
+        if k + t <= 32 and tss_valid:
             set_knob("SDA_FORCE_FFT", 1)                               # small tss-valid shapes default to the matrix kernels
         sch = crypto.PackedShamir(k, n, t, p, w2, w3)
         gen = crypto.ShareGenerator(sch)
         # the limb GEMM's draws are shares 0..t-1 (systematic map, like every matrix-form kernel); the transform kernel's are tss's nodes
-        assert gen.csprng_share_map() == (gen.SHARE_MAP_SYSTEMATIC if gemm and t > 0 else gen.SHARE_MAP_TSS_NODES)
+        assert gen.csprng_share_map() == (gen.SHARE_MAP_SYSTEMATIC if (gemm or not tss_valid) and t > 0 else gen.SHARE_MAP_TSS_NODES)
         B = gen.batch_count(dim)
         rand = np.random.default_rng(7).integers(-(1 << 62), 1 << 62, size=B * t, dtype=np.int64)
         got = gen.generate(secrets, rand)
@@ -64,7 +67,7 @@ def test_narrow_limb_gemm_vs_oracle_and_transform(gpu, p, k, t, n, w2, w3, dim):
         d_sec = DeviceBuffer.from_numpy(sec2)
         Bs = (B + 15) // 16 * 16 + 16
         first = (1 << 33) + 9
-        for share_map in ((gen.SHARE_MAP_SYSTEMATIC, gen.SHARE_MAP_TSS_NODES) if gemm else (gen.SHARE_MAP_TSS_NODES,)):
+        for share_map in ((gen.SHARE_MAP_SYSTEMATIC, gen.SHARE_MAP_TSS_NODES) if (gemm or not tss_valid) and t > 0 else (gen.SHARE_MAP_TSS_NODES,)):
             gen.set_csprng_share_map(share_map)
             d_out = DeviceBuffer(P * n * Bs).zero()
             gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=first)

@@ -19,10 +19,11 @@ def root(p, order):
 
 
 lib = capi.load()
-for _k in ("SDA_NO_XCD_MAP", "SDA_NO_NARROW", "SDA_NO_LAZY"):
+for _k in ("SDA_NO_XCD_MAP", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM"):
     if os.environ.get(_k):
         capi.check(lib.sda_debug_set_knob(_k.encode(), 1))
 ONLY = os.environ.get("ONLY_SMALL_G")
+NARROW_ONLY = os.environ.get("NARROW_ONLY")
 dim = 1 << 20
 TSS_P1, TSS_P2 = 746497, 5038849          # tss's own primes: p - 1 = 2^10 * 3^6 and 2^8 * 3^9 (the uint32_t transform kernel)
 SHAPES = [(100, 155, 728, 500, None), (100, 155, 19682, 40, None), (100, 155, 2186, 200, None), (40, 23, 242, 500, None), (70, 57, 242, 500, None),
@@ -30,6 +31,8 @@ SHAPES = [(100, 155, 728, 500, None), (100, 155, 19682, 40, None), (100, 155, 21
           (70, 57, 242, 500, TSS_P1)]
 for (k, t, n, P, small) in SHAPES:
     if ONLY and n not in (19682, 2186):
+        continue
+    if NARROW_ONLY and not small:
         continue
     p = small or (P62B if n + 1 == 19683 else P62)
     sch = crypto.PackedShamir(k, n, t, p, root(p, k + t + 1), root(p, n + 1))
