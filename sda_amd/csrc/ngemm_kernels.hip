@@ -12,14 +12,19 @@
 // c_j = 256^j 2^32 mod p and one three-instruction Montgomery reduction (R = 2^32).  Per secret: ~17 matrix-core cycles per
 // SIMD and ~1.5 vector instructions of epilogue, beside the t / k ChaCha20 draws that every form of this path pays.
 //
-// Work decomposition.  A workgroup (4 waves) owns 64 NT consecutive batches of one participant; wave w holds the value
-// digits of its 16 NT batches for ALL terms in registers (B operands: NT x KS x 3 fragments) and the workgroup sweeps the
-// n / 16 row tiles of the matrix, whose digits the host laid out fragment by fragment ([row tile][64-term step][digit][lane]
-// 16 bytes): a tile is copied global -> registers -> LDS (double buffered, the copy of tile r + 1 in flight under the
-// products of tile r) and read back with conflict-free 16-byte LDS loads.  Shares leave as 128-byte row segments (16
-// batches x 8 bytes), non-temporal.  Values reach the B-operand layout through an LDS tile [digit][batch][64 terms],
-// one 64-term step at a time; the draws are the per-lane sda-drbg-v1 blocks of the transform kernel (one block = draw i of
-// 8 consecutive batches), so both kernels produce identical shares from identical inputs and keys.
+// Work decomposition.  ONE workgroup per CU: 8 compute waves (two per SIMD) + 1 loader wave.  The workgroup owns 128 NT
+// consecutive batches of one participant; compute wave w holds the value digits of its 16 NT batches for ALL terms in
+// registers (B operands: NT x KS x 3 fragments) and the workgroup sweeps the row tiles of the matrix, whose digits the host
+// laid out fragment by fragment ([row tile][64-term step][digit][lane] 16 bytes).  The LOADER wave streams those tiles
+// global -> LDS with global_load_lds_dwordx4 into a ring of slots, two tiles ahead, with counted s_waitcnt vmcnt - it has no
+// stores in its in-order counter, so no tile ever waits for share stores to be acknowledged; the compute waves read the
+// fragments back with conflict-free 16-byte LDS loads.  Shares leave as 128-byte row segments (16 batches x 8 bytes),
+// non-temporal.  Values reach the B-operand layout through an LDS tile [digit][batch][64 terms], one 64-term step at a time;
+// the draws are the per-lane sda-drbg-v1 blocks of the transform kernel (one block = draw i of 8 consecutive batches), so
+// both kernels produce identical shares from identical inputs and keys.  With the library's own randomness the draws ARE
+// shares 0..t-1 (systematic share map, include/sda_hip.h) and the matrix has only the other n - t rows.
+// Measurements behind these choices (MFMA / vector co-issue, the vmcnt trap, the half-period offset of the wave pairs):
+// DESIGN.md 4 "Narrow limb GEMM".
 //
 // Exactness and every bound (digits, columns, the reduction's operand): tests/test_ngemm_model.py.
 #include <hip/hip_runtime.h>
@@ -274,8 +279,8 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
     const uint64_t stream = L.first_participant + p;
     const uint32_t tiles = P.row_tiles;
-    // Wave 4 is the LOADER: it only moves A tiles global -> LDS (global_load_lds, 1 KiB per instruction, no registers) and keeps
-    // the barriers.  The four compute waves never load in the row loop, so nothing ever waits for their share stores: vmcnt is
+    // The last wave is the LOADER: it only moves A tiles global -> LDS (global_load_lds, 1 KiB per instruction, no registers) and
+    // keeps the barriers.  The compute waves never load in the row loop, so nothing ever waits for their share stores: vmcnt is
     // an in-order counter, and with the loads in the compute waves every tile waited for the previous tile's non-temporal
     // stores to be acknowledged by HBM (52 % of the wave cycles in wait states, measured).
     const bool loader = wave == (uint32_t)kNgCompute;
