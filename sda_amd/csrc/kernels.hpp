@@ -149,6 +149,10 @@ size_t ngemm_tile_bytes(uint32_t ks);
 bool packed_ngemm_path_available(uint32_t k, uint32_t t, uint64_t p);
 uint32_t packed_ngemm_steps(uint32_t k, uint32_t t);
 hipError_t launch_packed_generate_ngemm(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, hipStream_t s);
+// dual-role form: the clerk sum of the previous tile (two 512-column items per workgroup) at fixed positions of the same grid
+hipError_t launch_fused_packed_ngemm(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, uint64_t* acc_lo,
+                                     int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs, size_t dimension, hipStream_t s,
+                                     bool* fused);
 
 // packed Shamir, any shape: matrix in global memory, randomness must be materialised (L.rand != 0)
 hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,

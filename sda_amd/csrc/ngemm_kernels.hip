@@ -32,6 +32,7 @@
 
 #include "capi_internal.hpp"
 #include "chacha.hpp"
+#include "clerk_sum.hpp"
 #include "drbg_lane.hpp"
 #include "kernels.hpp"
 #include "modarith.hpp"
@@ -254,6 +255,18 @@ __device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS][3], uint8_t* Bt
 #endif
 }
 
+// ---- dual-role launch (DESIGN.md 5 "Schedules"): position c * period of the grid is the c-th clerk-sum workgroup of the PREVIOUS tile
+// (two items of 512 columns x one job x one row split, one per half of the compute waves; exact 128-bit sums, carry-propagating
+// atomics when the rows are split), every other position a share-generation workgroup of this tile.  The clerk sum is bound by HBM
+// and the share generation by the SIMDs' issue slots: a CU in the clerk role streams while its neighbours multiply.
+struct NgFuse {
+    uint64_t* acc_lo; int64_t* acc_hi; const int64_t* prev;
+    size_t job_stride, n_rows, row_stride, dimension, rows_per_split;
+    uint32_t col_blocks, jobs, splits, pad;
+    uint64_t n_gen, n_comb, n_comb_wg, period;                    // n_comb items in n_comb_wg workgroups; 0: share generation only
+};
+static constexpr int kNgClerkUnroll = 8;      // row loads in flight per lane in the clerk role (4: 14.9, 8: 14.6, 16: 14.9, 32: 15.9 ms per tile)
+
 template <int KS> struct NgRing { static constexpr int depth = KS == 8 ? 2 : 4; };   // LDS slots of A tiles (two workgroups per CU)
 
 #ifdef NG_LOADER_REGS
@@ -265,7 +278,7 @@ template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_
 template <int KS, int NT>
 // 168 registers: three waves per SIMD, i.e. the ten waves of two workgroups on a CU's four SIMDs
 __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void packed_gen_ngemm_kernel(GenLayout L, ModParams mod, DrbgKey key, NGemmPlan P,
-                                                                        uint64_t chunks, uint64_t batches) {
+                                                                        uint64_t chunks, uint64_t batches, NgFuse F) {
     constexpr int WB = 16 * NT, WGB = kNgCompute * WB;                       // batches per wave / per workgroup
     constexpr int PIECES = KS * 3, ATILE = PIECES * 1024;           // one row tile: PIECES fragments of 1 KiB
     constexpr int DEPTH = NgRing<KS>::depth;
@@ -273,7 +286,23 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     uint8_t* Abuf = ng_lds;                                          // [DEPTH][ATILE]
     uint8_t* Bt = ng_lds + DEPTH * ATILE;                            // [3][WGB][kNgRow]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, col = lane & 15u, g = lane >> 4;
-    const uint64_t p = blockIdx.x / chunks, chunk = blockIdx.x - p * chunks;
+    uint64_t item = blockIdx.x;
+    if (F.n_comb_wg) {                                               // dual-role grid: which role is this workgroup's?
+        const uint64_t q = item / F.period, rem = item - q * F.period;
+        if (rem == 0 && q < F.n_comb_wg) {
+            const uint64_t it = 2 * q + (tid >> 8);                  // threads 0-255: item 2 q, threads 256-511: item 2 q + 1
+            if (tid < 512u && it < F.n_comb) {
+                const uint64_t bx = it % F.col_blocks, rest = it / F.col_blocks;
+                combine_pair<true, kNgClerkUnroll>(F.acc_lo, F.acc_hi, F.prev, F.job_stride, F.n_rows, F.row_stride, F.dimension,
+                                                   F.rows_per_split, F.splits > 1, bx * 256u + (tid & 255u), rest % F.jobs, rest / F.jobs);
+            }
+            return;
+        }
+        const uint64_t before = q + (rem ? 1 : 0);                   // clerk positions below this one
+        item -= before < F.n_comb_wg ? before : F.n_comb_wg;
+        if (item >= F.n_gen) return;                                 // surplus position
+    }
+    const uint64_t p = item / chunks, chunk = item - p * chunks;
     const uint64_t b0 = chunk * WGB;
     const int64_t* sp = L.secrets + p * L.secrets_stride;
     const int64_t* rp = L.rand ? L.rand + p * L.rand_stride : nullptr;
@@ -441,7 +470,7 @@ static hipError_t ngemm_launch(const GenLayout& L, const ModParams& mod, const D
         S.out = L.out + p0 * L.out_stride_participant;
         S.participants = cnt;
         S.first_participant = L.first_participant + p0;
-        kern<<<dim3((unsigned)(chunks * cnt)), dim3(kNgThreads), lds, s>>>(S, mod, key, P, chunks, batches);
+        kern<<<dim3((unsigned)(chunks * cnt)), dim3(kNgThreads), lds, s>>>(S, mod, key, P, chunks, batches, NgFuse{});
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
@@ -453,6 +482,62 @@ hipError_t launch_packed_generate_ngemm(const GenLayout& L, const ModParams& mod
         case 2: return ngemm_launch<2, 2>(L, mod, key, P, s);
         case 4: return ngemm_launch<4, 2>(L, mod, key, P, s);
         case 8: return ngemm_launch<8, 1>(L, mod, key, P, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int KS, int NT>
+static hipError_t ngemm_launch_fused(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, NgFuse F,
+                                     size_t prev_rows, hipStream_t s, bool* fused) {
+    constexpr int WGB = 16 * kNgCompute * NT;
+    const uint64_t batches = (L.len + P.k - 1) / P.k;
+    const uint64_t chunks = (batches + WGB - 1) / WGB;
+    F.n_gen = chunks * L.participants;
+    const bool have_comb = F.prev && prev_rows > 0 && F.jobs > 0 && F.dimension > 0;
+    F.col_blocks = (uint32_t)((((F.dimension + 1) / 2) + 255) / 256);
+    // clerk-sum items of up to 512 rows (as in the other dual-role launches)
+    uint64_t splits = have_comb ? (prev_rows + 511) / 512 : 1;
+    if (splits > 64) splits = 64;
+    F.rows_per_split = have_comb ? (prev_rows + splits - 1) / splits : 1;
+    splits = have_comb ? (prev_rows + F.rows_per_split - 1) / F.rows_per_split : 1;
+    F.splits = (uint32_t)splits;
+    F.n_comb = have_comb ? (uint64_t)F.col_blocks * F.jobs * splits : 0;
+    F.n_comb_wg = (F.n_comb + 1) / 2;
+    // workgroup b runs on XCD b % 8: an odd period spreads the clerk positions over all of them
+    F.period = F.n_comb_wg ? F.n_gen / F.n_comb_wg + 1 : 1;
+    if (F.n_comb_wg && (F.period & 1) == 0) F.period = F.period > 2 ? F.period - 1 : 3;
+    uint64_t grid = F.n_gen + F.n_comb_wg;
+    if (F.n_comb_wg && (F.n_comb_wg - 1) * F.period + 1 > grid) grid = (F.n_comb_wg - 1) * F.period + 1;
+    if (grid == 0) { *fused = true; return hipSuccess; }
+    if (grid > 0x7FFFFFFFull) return hipSuccess;                                  // not fused: the caller issues the two launches
+    if (F.n_comb_wg == 0) { *fused = true; return ngemm_launch<KS, NT>(L, mod, key, P, s); }
+    const size_t lds = NgRing<KS>::depth * ngemm_tile_bytes(KS) + 3 * (size_t)WGB * kNgRow;
+    auto kern = packed_gen_ngemm_kernel<KS, NT>;
+    if (lds > 64 * 1024)
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
+    *fused = true;
+    kern<<<dim3((unsigned)grid), dim3(kNgThreads), lds, s>>>(L, mod, key, P, chunks ? chunks : 1, batches, F);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_packed_ngemm(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, uint64_t* acc_lo,
+                                     int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs, size_t dimension, hipStream_t s,
+                                     bool* fused) {
+    *fused = false;
+    if (L.rand) return hipSuccess;
+    const bool have_comb = d_prev && prev_rows > 0 && jobs > 0 && dimension > 0;
+    // the clerk role reads the previous tile with 16-byte loads
+    if (have_comb && !(((reinterpret_cast<uintptr_t>(d_prev) & 15u) == 0) && (L.out_stride_clerk % 2 == 0) && (L.out_stride_participant % 2 == 0)))
+        return hipSuccess;
+    NgFuse F{};
+    F.acc_lo = acc_lo; F.acc_hi = acc_hi; F.prev = d_prev;
+    F.job_stride = L.out_stride_clerk; F.row_stride = L.out_stride_participant;
+    F.n_rows = prev_rows; F.dimension = dimension; F.jobs = (uint32_t)jobs;
+    switch (P.ks) {
+        case 1: return ngemm_launch_fused<1, 4>(L, mod, key, P, F, prev_rows, s, fused);
+        case 2: return ngemm_launch_fused<2, 2>(L, mod, key, P, F, prev_rows, s, fused);
+        case 4: return ngemm_launch_fused<4, 2>(L, mod, key, P, F, prev_rows, s, fused);
+        case 8: return ngemm_launch_fused<8, 1>(L, mod, key, P, F, prev_rows, s, fused);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1302,6 +1302,9 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
         he = launch_fused_packed_n31(L, g->n, g->k, g->t, g->mod, g->n31p, sys ? *g->matarg_n31_sys : *g->matarg_n31, key,
                                      c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs, c->dimension,
                                      s, &fused);
+    } else if (g->ngemm && g->drbg.rounds == 20) {
+        he = launch_fused_packed_ngemm(L, g->mod, key, sys ? g->gplan_sys : g->gplan, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev,
+                                       prev_participants, c->jobs, c->dimension, s, &fused);
     } else if (g->l31) {
         he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds,
                                      c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "chacha.hpp"
+#include "clerk_sum.hpp"
 #include "kernels.hpp"
 #include "modarith.hpp"
 
@@ -25,7 +26,6 @@ namespace sda {
 
 static constexpr int kThreads = 256;
 
-typedef long long ll2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
 // =================================================================================================
@@ -984,53 +984,8 @@ __device__ __forceinline__ void combine_body(uint64_t* __restrict__ acc_lo, int6
                                              const int64_t* __restrict__ shares, size_t job_stride, size_t n_rows,
                                              size_t row_stride, size_t dimension, size_t rows_per_split, bool atomic,
                                              size_t bx, size_t by, size_t bz) {
-    const size_t pair = bx * kThreads + threadIdx.x;
-    const size_t c0 = 2 * pair;
-    if (c0 >= dimension) return;
-    const bool two = c0 + 1 < dimension;
-    const size_t job = by;
-    const size_t r_begin = bz * rows_per_split;
-    size_t r_end = r_begin + rows_per_split;
-    if (r_end > n_rows) r_end = n_rows;
-    const int64_t* base = shares + job * job_stride + c0;
-
-    uint64_t lo0 = 0, lo1 = 0;
-    int64_t hi0 = 0, hi1 = 0;
-    size_t r = r_begin;
-    if (VEC && two) {
-        for (; r + UNROLL <= r_end; r += UNROLL) {
-            ll2 v[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                v[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(base + (r + u) * row_stride));
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) { acc_add(lo0, hi0, v[u].x); acc_add(lo1, hi1, v[u].y); }
-        }
-        for (; r < r_end; ++r) {
-            ll2 v = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(base + r * row_stride));
-            acc_add(lo0, hi0, v.x); acc_add(lo1, hi1, v.y);
-        }
-    } else {
-        for (; r < r_end; ++r) {
-            acc_add(lo0, hi0, base[r * row_stride]);
-            if (two) acc_add(lo1, hi1, base[r * row_stride + 1]);
-        }
-    }
-
-    const size_t idx = job * dimension + c0;
-    if (atomic) {
-        acc_atomic_add(acc_lo + idx, acc_hi + idx, lo0, hi0);
-        if (two) acc_atomic_add(acc_lo + idx + 1, acc_hi + idx + 1, lo1, hi1);
-    } else {
-        uint64_t l = acc_lo[idx]; int64_t h = acc_hi[idx];
-        uint64_t nl = l + lo0; h += hi0 + (nl < l ? 1 : 0);
-        acc_lo[idx] = nl; acc_hi[idx] = h;
-        if (two) {
-            l = acc_lo[idx + 1]; h = acc_hi[idx + 1];
-            nl = l + lo1; h += hi1 + (nl < l ? 1 : 0);
-            acc_lo[idx + 1] = nl; acc_hi[idx + 1] = h;
-        }
-    }
+    combine_pair<VEC, UNROLL>(acc_lo, acc_hi, shares, job_stride, n_rows, row_stride, dimension, rows_per_split, atomic,
+                              bx * kThreads + threadIdx.x, by, bz);                       // clerk_sum.hpp
 }
 
 template <bool VEC, int UNROLL>

@@ -109,14 +109,17 @@ def test_narrow_limb_gemm_odd_strides_and_clerk_major_layout(gpu):
 
 
 def test_narrow_limb_gemm_share_combine_reveal_roundtrip(gpu):
-    """tss's PSS_155_728_100 over tss's prime through the pipelined step (share generation of tile i beside the clerk sum of
-    tile i - 1), then the reveal from an arbitrary t + k clerks = the sum of the secrets"""
+    """tss's PSS_155_728_100 over tss's prime through the pipelined step (the dual-role launch: share generation of tile i and the
+    clerk sum of tile i - 1 in one grid), clerk sums against the oracle, then the reveal from an arbitrary t + k clerks = the sum
+    of the secrets"""
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     p, k, t, n, w2, w3 = TSS_P1, 100, 155, 728, 95660, 610121
     dim, P, tiles = 100 * 40 + 7, 5, 3
     sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    from oracle import coracle
     gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
     comb = crypto.ShareCombiner(sch)
     B = gen.batch_count(dim)
     Bs = (B + 15) // 16 * 16
@@ -132,6 +135,12 @@ def test_narrow_limb_gemm_share_combine_reveal_roundtrip(gpu):
     d_sums = DeviceBuffer(n * B)
     comb.finish_dev(d_sums.ptr)
     sums = d_sums.to_numpy().reshape(n, B)
+    # every clerk's sum against the oracle's combine over the oracle's shares of all 15 participants (dual-role launch: the clerk
+    # sum of tile i - 1 runs in workgroups of the grid that generates tile i)
+    want = [coracle.packed_generate_csprng(p, k, t, n, w2, w3, secs[i][q], coracle.drbg_fill(KEY, i * P + q, B, t, p), gen.csprng_share_map())
+            for i in range(tiles) for q in range(P)]
+    for c in (0, 1, t - 1, t, n // 2, n - 1):
+        assert np.array_equal(sums[c], coracle.combine(p, np.stack([wq[c] for wq in want]))), c
     idx = sorted(rng.choice(n, size=t + k, replace=False).tolist())
     rec = crypto.SecretReconstructor(sch, dim).reconstruct([(i, sums[i]) for i in idx])
     truth = np.zeros(dim, dtype=np.int64)
