@@ -637,7 +637,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
             "fused_packed_n31_kernel" if narrow and w["k"] + w["t"] <= 16 else
             "fused_packed_mfma_kernel" if (w["k"], w["t"]) in MFMA_DEFAULT_SHAPES else
             "fused_packed_l31_kernel" if w["k"] + w["t"] <= 16 else
-            "packed_gen_ngemm_kernel" if narrow and prime_of(w) < (1 << 23) and not os.environ.get("SDA_NO_NGEMM") else
+            "packed_gen_ngemm_kernel" if narrow and prime_of(w) <= 0x7F7F7F and not os.environ.get("SDA_NO_NGEMM") else
             "packed_gen_fft_kernel + combine_update_kernel (no dual-role form)")
     has_dual = w["kind"] != "packed" or w["k"] + w["t"] <= 16 or kern == "packed_gen_ngemm_kernel"
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,

@@ -210,7 +210,7 @@ int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int rounds);
  * (j < t).  t + k + 1 distinct points fix such a polynomial, so for fixed secrets draws <-> tss randomness is a bijection
  * and uniform draws give the SAME joint distribution of the n shares; t of the n modular dot products per batch
  * disappear ((3,4,8): half of them).  SDA_SHARE_MAP_TSS_NODES is kept for the transform kernel (tss-valid shapes with
- * k + t > 32 over a prime of 2^23 or more, where the draws are inputs of tss's own transform; below 2^23 those shapes run
+ * k + t > 32 over a prime above 0x7F7F7F (~2^23), where the draws are inputs of tss's own transform; up to that bound those shapes run
  * as a matrix product on the matrix cores and take the systematic map too), for t = 0, when a share point collides with a node,
  * and on request (set_csprng_share_map: A/B measurements, round-3 fixtures).  Draw range: the device CSPRNG draws
  * uniformly from [0, p); tss 0.2 draws from [0, p - 1) (rand's Range::new(0, prime - 1)) - the library's range is the

@@ -134,7 +134,8 @@ size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds, bool nar
 hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
                                       hipStream_t s);
 
-// packed Shamir over a narrow prime (p < 2^23) as a limb GEMM on the matrix cores: any (k, t) with k + t <= 512, any n
+// packed Shamir over a narrow prime (p <= 0x7F7F7F, just below 2^23: three balanced base-256 digits per residue) as a limb GEMM on the
+// matrix cores: any (k, t) with k + t <= 512, any n
 // (ngemm_kernels.hip).  Draws are the transform kernel's (tss's nodes), ChaCha20 only.
 struct NGemmPlan {
     uint32_t k, t, n;

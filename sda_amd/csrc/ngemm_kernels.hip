@@ -40,11 +40,12 @@
 namespace sda {
 
 typedef int ng_v4i __attribute__((ext_vector_type(4)));
-typedef uint32_t ng_v4u __attribute__((ext_vector_type(4)));
 
 static constexpr int kNgCompute = 8;                // compute waves per workgroup (two per SIMD), one workgroup per CU
 static constexpr int kNgWorkers = 64 * kNgCompute;
 static constexpr int kNgThreads = kNgWorkers + 64;  // + the loader wave
+typedef __attribute__((address_space(3))) uint8_t* ng_lptr;     // LDS pointers inside the non-inlined passes: a generic pointer argument costs
+                                                                 // a 64-bit address computation per access
 static constexpr int kNgRow = 80;                 // bytes of one (digit, batch) row of the value tile: 64 terms + 16 (bank spread)
 
 // c x + acc as ONE v_mad_i64_i32.  Written in plain C on purpose: the operand x comes straight out of an MFMA accumulator, and
@@ -57,16 +58,15 @@ __device__ __forceinline__ int32_t ng_pin_vgpr(int32_t c) {
     return c;
 }
 __device__ __forceinline__ int64_t ng_mad(int32_t v_c, int32_t x, int64_t acc) { return (int64_t)v_c * (int64_t)x + acc; }
-// canonical residue -> the three balanced base-256 digits of its centred representative, in bytes 0..2 (two's complement)
-__device__ __forceinline__ uint32_t ng_digits(uint32_t v, const N31Params& P) {
-    const uint32_t x = v >= P.h ? v - P.p : v;
-    return (x + 0x00808080u) ^ 0x00808080u;
-}
-__device__ __forceinline__ void ng_put(uint8_t* tile, uint32_t wgb, uint32_t batch, uint32_t term, uint32_t d) {
-    uint8_t* q = tile + (size_t)batch * kNgRow + term;
+// canonical residue v < 2^23 - 2^15 -> its three balanced base-256 digits in bytes 0..2 (two's complement): the bytes of
+// (v + 0x808080) ^ 0x808080.  Values are NOT centred (only the matrix is): the column and reduction bounds hold for any digits
+// in [-128, 127] (tests/test_ngemm_model.py), and a digit split of two instructions is what the staging passes can afford
+__device__ __forceinline__ uint32_t ng_digits(uint32_t v) { return (v + 0x00808080u) ^ 0x00808080u; }
+__device__ __forceinline__ void ng_put(ng_lptr tile, uint32_t wgb, uint32_t batch, uint32_t term, uint32_t d) {
+    ng_lptr q = tile + batch * kNgRow + term;
     q[0] = (uint8_t)d;
-    q[(size_t)wgb * kNgRow] = (uint8_t)(d >> 8);
-    q[(size_t)2 * wgb * kNgRow] = (uint8_t)(d >> 16);
+    q[wgb * kNgRow] = (uint8_t)(d >> 8);
+    q[2 * wgb * kNgRow] = (uint8_t)(d >> 16);
 }
 // S = sum_j C_j c_j (|S| < p 2^31) -> S 2^-32 mod p, canonical.  q = lo(S) p^-1 (signed 32 bits): q p has the low word of S, so
 // (S - q p) / 2^32 = hi(S) - mulhi(q, p) with no borrow to look after - three instructions - and lies in (-p, p); the unsigned
@@ -94,64 +94,71 @@ __device__ __forceinline__ uint32_t ng_canon(int64_t x, const ModParams& mod) {
 // are issued before the first value is used (clamped addresses, no branches in between): one memory latency per step
 template <int WGB>
 __device__ __noinline__ void ng_load_pass(uint8_t* Bt, const int64_t* sp, const int64_t* rp, uint64_t len, uint64_t batches, uint64_t b0,
-                                          uint32_t k, uint32_t t, uint32_t t_lo, uint64_t m, uint64_t mu, uint32_t p32, uint32_t h32) {
+                                          uint32_t k, uint32_t t, uint32_t t_lo, uint64_t m, uint64_t mu) {
     constexpr int ROUNDS_ = WGB / kNgCompute;
+    typedef const __attribute__((address_space(1))) int64_t* gptr;           // (a generic pointer argument would be read with flat loads)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, kt = k + t;
     const ModParams mod{m, mu, 0};
-    N31Params np; np.p = p32; np.h = h32; np.pinv = 0; np.pad = 0;
     const uint32_t term = t_lo + lane;
     const bool is_secret = term < k, is_draw = !is_secret && term < kt;
-    const int64_t* src = is_secret ? sp : rp;                               // rp may be null: then no lane of a draw term loads
+    const bool reads = is_secret || (is_draw && rp != nullptr);
+    if (is_draw && rp == nullptr) return;                                    // CSPRNG draws are written by ng_draw_pass
+    ng_lptr dst = (ng_lptr)Bt + wave * kNgRow + lane;
+    constexpr uint32_t PLANE = WGB * kNgRow, ROUND = kNgCompute * kNgRow;
+    if (!reads) {                                                            // zero padding beyond k + t
+#pragma unroll
+        for (int it = 0; it < ROUNDS_; ++it) { dst[it * ROUND] = 0; dst[PLANE + it * ROUND] = 0; dst[2 * PLANE + it * ROUND] = 0; }
+        return;
+    }
+    gptr src = (gptr)(is_secret ? sp : rp);
     const uint32_t per = is_secret ? k : t, off = is_secret ? term : term - k;
     const uint64_t lim = is_secret ? len : batches * (uint64_t)t;
-    const bool reads = is_secret || (is_draw && rp != nullptr);
     int64_t raw[ROUNDS_];
     // every batch of the workgroup and every secret of those batches exists (all workgroups but a participant's last): no
     // clamps, no per-element bounds, one pointer increment per round
     const bool full = b0 + WGB <= batches && (b0 + WGB) * (uint64_t)k <= len;
+    uint64_t any = 0;
     if (full) {
-        if (reads) {
-            const int64_t* q = src + (b0 + wave) * per + off;
-            const size_t step = (size_t)kNgCompute * per;
+        gptr q = src + (b0 + wave) * per + off;
+        const size_t step = (size_t)kNgCompute * per;
 #pragma unroll
-            for (int it = 0; it < ROUNDS_; ++it) raw[it] = q[(size_t)it * step];
+        for (int it = 0; it < ROUNDS_; ++it) raw[it] = q[(size_t)it * step];
+    } else {
+#pragma unroll
+        for (int it = 0; it < ROUNDS_; ++it) {
+            const uint64_t b = b0 + (uint32_t)it * (uint32_t)kNgCompute + wave, e = b * per + off;
+            raw[it] = b < batches && e < lim ? src[e] : 0;                   // zero padding (batched.rs:37-43)
         }
-        if (!is_draw || rp != nullptr) {                                    // CSPRNG draws are written by ng_draw_pass
-            uint8_t* dst = Bt + (size_t)wave * kNgRow + lane;
+    }
+    bool bad = false;                                                        // some value of this lane is not canonical yet
 #pragma unroll
-            for (int it = 0; it < ROUNDS_; ++it) {
-                const uint32_t d = reads ? ng_digits(ng_canon(raw[it], mod), np) : 0u;
-                uint8_t* w = dst + (size_t)it * (kNgCompute * kNgRow);
-                w[0] = (uint8_t)d;
-                w[(size_t)WGB * kNgRow] = (uint8_t)(d >> 8);
-                w[(size_t)2 * WGB * kNgRow] = (uint8_t)(d >> 16);
-            }
+    for (int it = 0; it < ROUNDS_; ++it) {
+        any |= (uint64_t)raw[it] >> 32;
+        bad |= (uint32_t)raw[it] >= (uint32_t)m;                             // m < 2^23
+    }
+    if (bad || any != 0) {
+#pragma unroll 1
+        for (int it = 0; it < ROUNDS_; ++it) {
+            int64_t x = raw[0];
+#pragma unroll
+            for (int j = 1; j < ROUNDS_; ++j) x = j == it ? raw[j] : x;      // raw[] lives in registers: select, do not index
+            const uint32_t d = ng_digits(ng_canon(x, mod));
+            dst[it * ROUND] = (uint8_t)d; dst[PLANE + it * ROUND] = (uint8_t)(d >> 8); dst[2 * PLANE + it * ROUND] = (uint8_t)(d >> 16);
         }
         return;
     }
 #pragma unroll
     for (int it = 0; it < ROUNDS_; ++it) {
-        const uint64_t b = b0 + (uint32_t)it * (uint32_t)kNgCompute + wave;
-        uint64_t e = b * per + off;
-        e = e < lim ? e : 0;
-        raw[it] = reads ? src[e] : 0;
-    }
-    if (!is_draw || rp != nullptr) {
-#pragma unroll
-        for (int it = 0; it < ROUNDS_; ++it) {
-            const uint32_t bl = (uint32_t)it * (uint32_t)kNgCompute + wave;
-            const uint64_t b = b0 + bl, e = b * per + off;
-            const uint32_t v = reads && b < batches && e < lim ? ng_canon(raw[it], mod) : 0u;
-            ng_put(Bt, WGB, bl, lane, ng_digits(v, np));
-        }
+        const uint32_t d = ng_digits((uint32_t)raw[it]);
+        dst[it * ROUND] = (uint8_t)d; dst[PLANE + it * ROUND] = (uint8_t)(d >> 8); dst[2 * PLANE + it * ROUND] = (uint8_t)(d >> 16);
     }
 }
 
 // the CSPRNG draws d_lo .. d_lo + cd - 1 of the workgroup's batches -> digit tile (sda-drbg-v1, one block = draw i of 8 batches)
 template <int WGB>
 __device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t stream, uint64_t b0, uint32_t k, uint32_t t, uint32_t t_lo,
-                                          uint32_t d_lo, uint32_t cd, uint64_t m, uint64_t lemire_thr, uint32_t p32, uint32_t h32) {
-    N31Params np; np.p = p32; np.h = h32; np.pinv = 0; np.pad = 0;
+                                          uint32_t d_lo, uint32_t cd, uint64_t m, uint64_t lemire_thr) {
+    ng_lptr B = (ng_lptr)Bt;
     const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
 #pragma unroll 1
     for (uint32_t u = threadIdx.x; u < (uint32_t)(WGB / 8) * cd; u += kNgWorkers) {
@@ -167,7 +174,7 @@ __device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t str
             if (!f_lemire32(xw, (uint32_t)m, lemire_thr, val))
                 val = f_drbg_retry<20>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream,
                                        (b0 + 8u * nb + jj) * (uint64_t)t + i, m, lemire_thr);
-            ng_put(Bt, WGB, 8u * nb + jj, k + i - t_lo, ng_digits((uint32_t)val, np));
+            ng_put(B, WGB, 8u * nb + jj, k + i - t_lo, ng_digits((uint32_t)val));
         }
     }
 }
@@ -177,25 +184,26 @@ __device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t str
 // wrote 64 rows per instruction: 12.2 -> 16.0 ms per 500-participant tile, measured)
 template <int WGB>
 __device__ __noinline__ void ng_direct_pass(const uint8_t* Bt, int64_t* op, size_t stride_clerk, uint64_t b0, uint64_t batches, uint32_t k,
-                                            uint32_t t_lo, uint32_t d_lo, uint32_t d_hi, uint32_t p32) {
+                                            uint32_t t_lo, uint32_t d_lo, uint32_t d_hi) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // four terms per tile read (one dword per digit plane): the term offsets of the step's draws, rounded out to multiples of 4
     const uint32_t o_lo = (k + d_lo - t_lo) & ~3u, o_hi = k + d_hi - t_lo;                   // byte offsets in a tile row, o_hi <= 64
     for (uint32_t bg = 0; bg < (uint32_t)(WGB / 64); ++bg) {
         const uint32_t bl = 64u * bg + lane;
         const uint64_t b = b0 + bl;
-        const uint8_t* q = Bt + (size_t)bl * kNgRow;
+        const __attribute__((address_space(3))) uint8_t* q = (const __attribute__((address_space(3))) uint8_t*)Bt + bl * kNgRow;
+        typedef const __attribute__((address_space(3))) uint32_t* lw;
         for (uint32_t o = o_lo + 4u * wave; o < o_hi; o += 4u * (uint32_t)kNgCompute) {
-            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(q + o);
-            const uint32_t w1 = *reinterpret_cast<const uint32_t*>(q + (size_t)WGB * kNgRow + o);
-            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(q + (size_t)2 * WGB * kNgRow + o);
+            const uint32_t w0 = *(lw)(q + o);
+            const uint32_t w1 = *(lw)(q + WGB * kNgRow + o);
+            const uint32_t w2 = *(lw)(q + 2 * WGB * kNgRow + o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int32_t x = (int32_t)(int8_t)(w0 >> (8 * j)) + 256 * (int32_t)(int8_t)(w1 >> (8 * j)) + 65536 * (int32_t)(int8_t)(w2 >> (8 * j));
-                const uint32_t v = x < 0 ? (uint32_t)x + p32 : (uint32_t)x;
+                const uint32_t v = (uint32_t)((int32_t)(int8_t)(w0 >> (8 * j)) + 256 * (int32_t)(int8_t)(w1 >> (8 * j)) +
+                                              65536 * (int32_t)(int8_t)(w2 >> (8 * j)));        // the digits of the canonical value itself
                 const uint32_t term = t_lo + o + (uint32_t)j;                                    // draw term - k = share row
                 if (b < batches && term >= k + d_lo && term < k + d_hi)
-                    __builtin_nontemporal_store((long long)v, reinterpret_cast<long long*>(op + (size_t)(term - k) * stride_clerk + b));
+                    __builtin_nontemporal_store((long long)v, (__attribute__((address_space(1))) long long*)(op + (size_t)(term - k) * stride_clerk + b));
             }
         }
     }
@@ -222,11 +230,11 @@ __device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS][3], uint8_t* Bt
     const uint64_t tq0 = __builtin_readcyclecounter();
 #endif
     if (worker) {
-        if (loads) ng_load_pass<WGB>(Bt, sp, rp, L.len, batches, b0, k, t, t_lo, mod.m, mod.mu, P.np.p, P.np.h);
+        if (loads) ng_load_pass<WGB>(Bt, sp, rp, L.len, batches, b0, k, t, t_lo, mod.m, mod.mu);
 #ifdef NG_TIMING
         ng_tm[0] += __builtin_readcyclecounter() - tq0;
 #endif
-        if (draws_here) ng_draw_pass<WGB>(Bt, key, stream, b0, k, t, t_lo, d_lo, d_hi - d_lo, mod.m, mod.lemire_thr, P.np.p, P.np.h);
+        if (draws_here) ng_draw_pass<WGB>(Bt, key, stream, b0, k, t, t_lo, d_lo, d_hi - d_lo, mod.m, mod.lemire_thr);
     }
 #ifdef NG_TIMING
     const uint64_t tq1 = __builtin_readcyclecounter();
@@ -237,7 +245,7 @@ __device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS][3], uint8_t* Bt
     ng_tm[1] += tq1 - tq0; ng_tm[2] += tq2 - tq1;
 #endif
     if (worker) {
-        if (draws_here && L.direct_rows) ng_direct_pass<WGB>(Bt, op, L.out_stride_clerk, b0, batches, k, t_lo, d_lo, d_hi, P.np.p);
+        if (draws_here && L.direct_rows) ng_direct_pass<WGB>(Bt, op, L.out_stride_clerk, b0, batches, k, t_lo, d_lo, d_hi);
 #ifdef NG_TIMING
         ng_tm[3] += __builtin_readcyclecounter() - tq2;
 #endif
@@ -269,11 +277,7 @@ static constexpr int kNgClerkUnroll = 8;      // row loads in flight per lane in
 
 template <int KS> struct NgRing { static constexpr int depth = KS == 8 ? 2 : 4; };   // LDS slots of A tiles (two workgroups per CU)
 
-#ifdef NG_LOADER_REGS
-template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
-#else
 template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-#endif
 
 template <int KS, int NT>
 // 168 registers: three waves per SIMD, i.e. the ten waves of two workgroups on a CU's four SIMDs
@@ -316,16 +320,10 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     auto issue_tile = [&](uint32_t tile, uint32_t slot) {
         const uint8_t* src = P.A + (size_t)tile * ATILE + lane * 16;
         uint8_t* dst = Abuf + slot * ATILE;
-#ifdef NG_LOADER_REGS
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q)
-            *reinterpret_cast<ng_v4u*>(dst + q * 1024 + lane * 16) = *reinterpret_cast<const ng_v4u*>(src + q * 1024);
-#else
 #pragma unroll
         for (int q = 0; q < PIECES; ++q)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
                                              (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-#endif
     };
     if (loader) {
         for (uint32_t tile = 0; tile < (uint32_t)(DEPTH - 1) && tile < tiles; ++tile) issue_tile(tile, tile);
@@ -439,7 +437,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 }
 
 bool packed_ngemm_path_available(uint32_t k, uint32_t t, uint64_t p) {
-    return k >= 1 && k + t >= 1 && k + t <= 512 && p < (1ull << 23);
+    return k >= 1 && k + t >= 1 && k + t <= 512 && p <= 0x7F7F7Full;   // v + 0x808080 < 2^24 for every residue: three digits
 }
 uint32_t packed_ngemm_steps(uint32_t k, uint32_t t) {                // 64-term steps the compiled instances provide: 1, 2, 4, 8
     const uint32_t need = (k + t + 63) / 64;

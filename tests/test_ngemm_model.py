@@ -1,4 +1,4 @@
-"""Big-int model of the narrow limb GEMM (sda_amd/csrc/ngemm_kernels.hip): residues of a prime below 2^23 as three balanced
+"""Big-int model of the narrow limb GEMM (sda_amd/csrc/ngemm_kernels.hip): residues of a prime up to 0x7F7F7F as three balanced
 base-256 digits, five signed 32-bit column sums per share (what v_mfma_i32_16x16x64_i8 accumulates), the epilogue's
 sum_j C_j c_j with c_j = 256^j 2^32 mod p in a signed 64-bit register and the Montgomery reduction with R = 2^32.  Every
 register is checked against its width and the result against plain modular arithmetic, for random and extreme operands at
@@ -7,17 +7,18 @@ import random
 
 import pytest
 
-PRIMES = [3, 433, 746497, 5038849, 8388593]          # 8388593: the largest prime below 2^23
+PRIMES = [3, 433, 746497, 5038849, 8355691]          # 8355691: the largest prime the kernels take (p <= 0x7F7F7F)
 
 
-def digits(v, p):
-    """ng_digits: canonical residue -> three balanced digits of its centred representative"""
+def digits(v, p, centred):
+    """ng_digits (values: the canonical residue itself) / the host's split of the matrix (centred representative): three balanced
+    base-256 digits"""
     h = (p + 1) // 2
-    x = (v - p if v >= h else v) & 0xFFFFFFFF
+    c = (v - p if v >= h else v) if centred else v
+    x = c & 0xFFFFFFFF
     y = ((x + 0x00808080) & 0xFFFFFFFF) ^ 0x00808080
     d = [((y >> (8 * i)) & 0xFF) for i in range(3)]
     d = [b - 256 if b >= 128 else b for b in d]
-    c = v - p if v >= h else v
     assert d[0] + 256 * d[1] + 65536 * d[2] == c, (v, p, d)
     return d
 
@@ -31,7 +32,7 @@ def share(row, vals, p):
     """one dot product the way the kernel forms it; returns the canonical share"""
     C = [0] * 5
     for m, v in zip(row, vals):
-        dm, dv = digits(m, p), digits(v, p)
+        dm, dv = digits(m, p, True), digits(v, p, False)
         for a in range(3):
             for b in range(3):
                 C[a + b] += dm[a] * dv[b]
@@ -66,7 +67,8 @@ def test_digits_cover_every_residue_class_edge(p):
     for v in {0, 1, p - 1, p // 2, p // 2 + 1, (p + 1) // 2, max(0, p // 2 - 1), 127, 128, 129, 32767, 32768, 32896} | \
             {random.Random(p).randrange(p) for _ in range(2000)}:
         if 0 <= v < p:
-            digits(v, p)
+            digits(v, p, True)
+            digits(v, p, False)
 
 
 @pytest.mark.parametrize("p", PRIMES)
