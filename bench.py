@@ -70,7 +70,11 @@ WORKLOADS = {
                          desc="reference-valid tss shape t=7 k=8 n=26 over a 31-bit prime (narrow kernels), dim 1048576"),
     "narrow_pss728": dict(kind="packed", n=728, k=100, t=155, participants=10_000, tile_max=500, prime=746497, w2=95660, w3=610121,
                           desc="tss's shipped PSS_155_728_100 (k=100, t=155, n=728) over tss's own prime 746497 and roots: the "
-                               "uint32_t transform kernel, dim 1048576"),
+                               "limb GEMM on the matrix cores (ngemm_kernels.hip), dim 1048576"),
+    # tss's other shipped parameter set: 19682 clerks, 197 share values per secret (two share buffers of 66 GB at 40 participants)
+    "narrow_pss19682": dict(kind="packed", n=19682, k=100, t=155, participants=1_000, tile_max=40, prime=5038849, w2=4318906, w3=1814687,
+                            desc="tss's shipped PSS_155_19682_100 (k=100, t=155, n=19682) over tss's own prime 5038849 and roots: the "
+                                 "limb GEMM on the matrix cores, dim 1048576"),
     # config 5 on ONE GPU: its 100k participants are spread over 8 GPUs (12.5k each); the dimension is what differs, and
     # the reveal over 16 Mi secrets is part of it.  --dim defaults to 16777216 for this workload.
     "packed_dim16m": dict(kind="packed", n=8, k=3, t=1, o2=8, o3=9, participants=12_500, dim=1 << 24, tile_max=125,
@@ -921,7 +925,8 @@ def main():
                                         "packed_pss728": {k: pss[k] for k in keep if k in pss}}
         # the reference's OWN valid domain (tss multiplies i64 residues without widening): the tss-valid shapes over a 31-bit
         # prime and tss's shipped PSS_155_728_100 over its own prime 746497, through the narrow (one 32-bit limb) kernels
-        for nm, part, tile in (("narrow_ref", 6000, 1500), ("narrow26_ref", 6000, 1500), ("narrow_pss728", 2000, 500)):
+        for nm, part, tile in (("narrow_ref", 6000, 1500), ("narrow26_ref", 6000, 1500), ("narrow_pss728", 2000, 500),
+                               ("narrow_pss19682", 160, 40)):
             r = run(nm, 4, 1, participants=part, tile=tile)
             line["additional_workloads"][nm] = {k: r[k] for k in keep if k in r}
     if env.world > 1 and not args.no_additional and args.workload == "packed":

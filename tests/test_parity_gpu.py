@@ -1578,6 +1578,9 @@ def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu):
     assert {"config4_full", "config5_full", "additive", "packed_pss728", "narrow_ref", "narrow26_ref", "narrow_pss728"} <= set(legs)
     assert legs["narrow_ref"]["roofline"]["kernel"] == "fused_packed_n31_kernel" and legs["narrow_ref"]["verified_reconstruct_equals_sum"] is True
     assert legs["narrow_pss728"]["config"]["modulus"] == 746497 and legs["narrow_pss728"]["verified_reconstruct_equals_sum"] is True
+    # tss's two shipped parameter sets over tss's own primes run the limb GEMM on the matrix cores (dual-role launch)
+    assert legs["narrow_pss728"]["roofline"]["kernel"] == "packed_gen_ngemm_kernel"
+    assert legs["narrow_pss19682"]["config"]["share_count"] == 19682 and legs["narrow_pss19682"]["verified_reconstruct_equals_sum"] is True
     for key, (k, t, n) in (("config4_full", (8, 2, 26)), ("config5_full", (3, 1, 8))):
         cfg = legs[key]["config"]
         assert (cfg["secret_count"], cfg["privacy_threshold"], cfg["share_count"]) == (k, t, n)
