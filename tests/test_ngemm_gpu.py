@@ -147,3 +147,51 @@ def test_narrow_limb_gemm_share_combine_reveal_roundtrip(gpu):
     for s in secs:
         truth = (truth + s.sum(axis=0)) % p
     assert np.array_equal(rec, truth)
+
+
+def test_narrow_limb_gemm_fallbacks_keep_the_shares(gpu):
+    """what surrounds the kernel: (1) another ChaCha round count (A/B only) has no limb-GEMM instance - the transform kernel (tss's
+    nodes) or the any-shape kernel (systematic map) serve the handle, same draw -> share maps; (2) a clerk-major layout with an odd
+    row stride rules the dual-role launch out (its clerk role reads with 16-byte loads) - the two ordinary launches give the sums"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    p, k, t, n = TSS_P1, 40, 23, 242
+    w2, w3 = _root(p, 64), _root(p, 243)
+    dim, P, first = 40 * 50 + 3, 2, 5
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    rng = np.random.default_rng(3)
+    sec = rng.integers(0, p, size=(P, dim), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    gen.set_drbg_rounds(12)
+    B = gen.batch_count(dim)
+    Bs = (B + 15) // 16 * 16
+    for share_map in (gen.SHARE_MAP_SYSTEMATIC, gen.SHARE_MAP_TSS_NODES):
+        gen.set_csprng_share_map(share_map)
+        d_out = DeviceBuffer(P * n * Bs).zero()
+        gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=first)
+        o = d_out.to_numpy().reshape(P, n, Bs)
+        for q in range(P):
+            draws = coracle.drbg_fill(KEY, first + q, B, t, p, rounds=12)
+            assert np.array_equal(o[q, :, :B], coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[q], draws, share_map)), (share_map, q)
+    # (2) odd clerk-major strides through generate_combine_dev
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    comb = crypto.ShareCombiner(sch)
+    Bo = B | 1
+    bufs = [DeviceBuffer(n * P * Bo + 1).zero() for _ in range(2)]
+    comb.begin_dev(n, B)
+    tiles = 2
+    for i in range(tiles + 1):
+        gen.generate_combine_dev(comb, d_sec.ptr if i < tiles else 0, P if i < tiles else 0, dim, dim, bufs[i % 2].ptr + 8, Bo, P * Bo,
+                                 d_prev=bufs[(i - 1) % 2].ptr + 8 if i > 0 else 0, prev_participants=P if i > 0 else 0,
+                                 first_participant=first + i * P)
+    d_sums = DeviceBuffer(n * B)
+    comb.finish_dev(d_sums.ptr)
+    sums = d_sums.to_numpy().reshape(n, B)
+    want = [coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[q], coracle.drbg_fill(KEY, first + i * P + q, B, t, p), gen.csprng_share_map())
+            for i in range(tiles) for q in range(P)]
+    for c in (0, t - 1, t, n - 1):
+        assert np.array_equal(sums[c], coracle.combine(p, np.stack([wq[c] for wq in want]))), c
