@@ -1,11 +1,12 @@
-// Packed-Shamir share generation over a NARROW prime (p < 2^23: tss's shipped 746497 and 5038849, full_loop.rs's 433) for
-// LARGE shapes (k + t > 16, e.g. tss's PSS_155_728_100) as a limb GEMM on the matrix cores.
+// Packed-Shamir share generation over a NARROW prime (p <= 0x7F7F7F, just below 2^23: tss's shipped 746497 and 5038849,
+// full_loop.rs's 433) for LARGE shapes (k + t > 16, e.g. tss's PSS_155_728_100) as a limb GEMM on the matrix cores.
 //
 // packed_shamir.rs:42 -> tss share(): shares = M [secrets ; draws], M the n x (k + t) matrix of the polynomial through
 // (1, 0), the secrets at omega_secrets^(1..k) and the draws at omega_secrets^(k+1..k+t), evaluated at omega_shares^(1..n).
 // The transform kernel (fft_kernels.hip) computes this product with tss's own radix-2 / radix-3 structure in ~15 vector
 // instructions per secret and is bound by the vector ALUs at 0.42 of the HBM roofline.  Over a prime this small the DENSE
-// product is cheaper on this chip: a centred residue |x| <= p / 2 < 2^22 is THREE balanced base-256 digits (int8), so
+// product is cheaper on this chip: a residue below 2^23 is THREE balanced base-256 digits (int8; the matrix entries are
+// centred first, the values are taken as they are), so
 //     column c = sum over terms and la + lb = c of digit_la(M) digit_lb(value)          (c = 0..4)
 // is nine v_mfma_i32_16x16x64_i8 per 16 shares x 16 batches x 64 terms - 2.4 M multiply-adds per batch of PSS_155_728_100 at
 // 16384 per instruction - and the five 32-bit column sums of one share come back to ONE residue with five v_mad_i64_i32 by
