@@ -195,3 +195,42 @@ def test_narrow_limb_gemm_fallbacks_keep_the_shares(gpu):
             for i in range(tiles) for q in range(P)]
     for c in (0, t - 1, t, n - 1):
         assert np.array_equal(sums[c], coracle.combine(p, np.stack([wq[c] for wq in want]))), c
+
+
+def test_narrow_limb_gemm_random_shapes(gpu):
+    """24 random (k, t, n, dimension) over tss's two primes - term counts on both sides of every 64-term step boundary, row counts
+    on both sides of the 16-row tiles, batch counts around the workgroup sizes - each against the oracle: injected randomness and
+    the device CSPRNG under both share maps"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    rng = np.random.default_rng(20260930)
+    for trial in range(24):
+        p = (TSS_P1, TSS_P2)[trial % 2]
+        o2, o3 = (1024, 729) if p == TSS_P1 else (256, 19683)
+        kt = int(rng.choice([17, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255])) if trial < 20 else int(rng.integers(257, 512))
+        kt = min(kt, o2 - 1)
+        t = int(rng.integers(0, kt))
+        k = kt - t
+        n = int(rng.integers(kt, min(o3 - 1, kt + 300) + 1))
+        w2, w3 = _root(p, o2), _root(p, o3)
+        B = int(rng.choice([1, 7, 63, 64, 65, 127, 129, 255, 257, 300]))
+        dim = max(1, B * k - int(rng.integers(0, k)))
+        sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+        gen = crypto.ShareGenerator(sch)
+        assert gen.batch_count(dim) == B
+        secrets = rng.integers(-(1 << 62), 1 << 62, size=dim, dtype=np.int64)
+        rand = rng.integers(-(1 << 62), 1 << 62, size=B * t, dtype=np.int64)
+        assert np.array_equal(gen.generate(secrets, rand), coracle.packed_generate(p, k, t, n, w2, w3, secrets, rand)), (trial, p, k, t, n, dim)
+        gen.set_drbg_key(KEY)
+        sec = rng.integers(0, p, size=(1, dim), dtype=np.int64)
+        d_sec = DeviceBuffer.from_numpy(sec)
+        Bs = B + 3
+        for share_map in ((gen.SHARE_MAP_SYSTEMATIC, gen.SHARE_MAP_TSS_NODES) if t > 0 else (gen.SHARE_MAP_TSS_NODES,)):
+            gen.set_csprng_share_map(share_map)
+            d_out = DeviceBuffer(n * Bs).zero()
+            gen.generate_batch_dev(d_sec.ptr, 1, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=trial)
+            o = d_out.to_numpy().reshape(n, Bs)
+            w = coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[0], coracle.drbg_fill(KEY, trial, B, t, p), share_map)
+            assert np.array_equal(o[:, :B], w), (trial, p, k, t, n, dim, share_map)
+            assert not o[:, B:].any()
