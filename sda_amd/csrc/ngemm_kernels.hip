@@ -276,7 +276,7 @@ struct NgFuse {
 };
 static constexpr int kNgClerkUnroll = 8;      // row loads in flight per lane in the clerk role (4: 14.9, 8: 14.6, 16: 14.9, 32: 15.9 ms per tile)
 
-template <int KS> struct NgRing { static constexpr int depth = KS == 8 ? 2 : 4; };   // LDS slots of A tiles (two workgroups per CU)
+template <int KS> struct NgRing { static constexpr int depth = KS == 8 ? 2 : 4; };   // LDS slots of A tiles (a ring of 7 for KS = 4 changed nothing, also not for the 15 MB matrix of n = 19682)
 
 template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
