@@ -25,6 +25,13 @@ for _knob in ("SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU"):       # residency cap
         capi.check(lib.sda_debug_set_knob(_knob.encode(), int(os.environ[_knob])))
 k, t, n, dim = 3, 1, 8, 1 << 20
 P, tiles = int(os.environ.get("TILE", "1000")), int(os.environ.get("TILES", "4"))
+# PRIME=<p>: the same job over another prime with roots of order 8 and 9 - e.g. tss's own 746497 or the 31-bit 2147482801: the
+# reference's valid domain (tss multiplies i64 residues without widening), where a share is a 3- to 5-byte varint instead of 9
+if os.environ.get("PRIME"):
+    P62 = int(os.environ["PRIME"])
+    assert (P62 - 1) % 72 == 0
+    _g = next(g for g in range(2, 500) if all(pow(g, (P62 - 1) // f, P62) != 1 for f in (2, 3)))
+    W8, W9 = pow(_g, (P62 - 1) // 8, P62), pow(_g, (P62 - 1) // 9, P62)
 sch = crypto.PackedShamir(k, n, t, P62, W8, W9)
 B = (dim + k - 1) // k
 Bs = (B + 15) // 16 * 16
@@ -200,7 +207,7 @@ if PIPELINE:
     print(json.dumps({
         "schedule": "PIPELINE=1: seal(i) + open(i) on a high-priority stream, decode+sum(i-1) / share-gen(i+1) / encode(i+1) on a "
                     "low-priority stream, double-buffered wire and plaintext tiles; wall clock over the whole run",
-        "job": f"{tiles} tiles x {P} participants x dim {dim}, packed Shamir k={k} t={t} n={n}, 62-bit prime; {rows} sealed boxes per tile",
+        "job": f"{tiles} tiles x {P} participants x dim {dim}, packed Shamir k={k} t={t} n={n}, {P62.bit_length()}-bit prime {P62}; {rows} sealed boxes per tile",
         "box_bytes_per_tile": box_bytes, "box_bytes_per_secret": box_bytes / (P * dim),
         "ms_per_tile": ms_total / tiles, "elements_per_s": elements / (ms_total * 1e-3),
         "whole_config3_job_s": 100_000 * dim / (elements / (ms_total * 1e-3)),
@@ -238,7 +245,7 @@ want = (colsum.to_numpy().astype(object) * tiles) % P62
 ok = bool(np.array_equal(out.to_numpy().astype(object), want)) and status.to_bytes() == bytes(4)
 elements = tiles * P * dim
 print(json.dumps({
-    "job": f"{tiles} tiles x {P} participants x dim {dim}, packed Shamir k={k} t={t} n={n}, 62-bit prime; {rows} sealed boxes per tile",
+    "job": f"{tiles} tiles x {P} participants x dim {dim}, packed Shamir k={k} t={t} n={n}, {P62.bit_length()}-bit prime {P62}; {rows} sealed boxes per tile",
     "box_bytes_per_tile": box_bytes, "box_bytes_per_secret": box_bytes / (P * dim),
     "ms_per_tile": ms.value / tiles, "elements_per_s": elements / (ms.value * 1e-3),
     "stage_ms_per_tile": {s: v / tiles for s, v in stage_ms.items()},
