@@ -23,8 +23,14 @@ the Lagrange reveal), each with its job sharded over the N ranks.  `rccl` record
 a communicator that cannot be set up is fatal (exit code 3) unless SDA_SHARE_GPU allows the rehearsal.
 
 `roofline.bound` is the active ceiling ("hbm" / "valu") from profiles/bounds.json (counter passes of this
-round); `roofline.frac` is always the HBM fraction.  Prints ONE JSON line (rank 0).  See DESIGN.md
-"Measurement" for the byte accounting.
+round; null where no pass was taken); `roofline.frac` is always the HBM fraction; `roofline.kernel` is what the
+LIBRARY says it launched (sda_debug_last_kernel), not a guess made here.
+
+Output.  stdout carries ONE COMPACT JSON line (rank 0), at most 4096 bytes - compact_line() below, asserted here and in
+the tests: the contract's keys, `roofline`, `cpu_baseline`, and one {value, frac, bound, verified} record per
+attached workload.  Everything else (notes, sweeps, per-launch minima and maxima, the full record of every attached
+workload) goes to `bench_details.json` beside this script (--details PATH) and to stderr.  Round 4's line had grown to
+35 KB and the driver could no longer parse it.  See DESIGN.md "Measurement" for the byte accounting.
 """
 from __future__ import annotations
 
@@ -383,10 +389,15 @@ def _setup(env, name, dim, P, row_align, rounds):
 
 def _share_map_name(gen, w):
     if w["kind"] != "packed":
-        return "n/a (additive sharing: shares 0..n-2 are the draws by definition, additive.rs:42-47)"
-    return ("systematic: the t draws of a batch are its shares 0..t-1, n - t dot products per batch (include/sda_hip.h)"
+        return "n/a (additive: shares 0..n-2 are the draws, additive.rs:42-47)"
+    return ("systematic (library): the t draws of a batch are its shares 0..t-1, n-t dot products per batch"
             if gen.csprng_share_map() == gen.SHARE_MAP_SYSTEMATIC else
-            "tss nodes: draws are the values at omega_secrets^(k+1..k+t), n dot products per batch")
+            "tss nodes (reference): draws = values at omega_secrets^(k+1..k+t), n dot products per batch")
+
+
+def _library_kernel(env):
+    """what the library launched in its last generate call on this thread (include/sda_hip_debug.h) - the bench never guesses"""
+    return env.lib.sda_debug_last_kernel().decode()
 
 
 def _expected_sums(env, secrets, P, dim, firsts, q=P62):
@@ -474,10 +485,6 @@ def _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds, s
     }
 
 
-# shapes the library serves with the limb GEMM on the matrix cores by default (sda_capi.cpp: compiled MFMA shape, k + t >= 12)
-MFMA_DEFAULT_SHAPES = {(12, 3), (10, 5), (4, 11)}        # (8, 7): the three-digit limb-31 kernel since round 4
-
-
 def _profiles_json(fname):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", fname)))
@@ -523,7 +530,7 @@ def _bound(name, role, roof):
     # share-gen kernel is the dominant one and its counters are the evidence
     e = entry.get(role) or (entry.get("serial_gen") if role == "fused" else None)
     if not e:
-        return {"bound": BOUND_WITHOUT_EVIDENCE.get(name, "valu"), "bound_evidence": None}
+        return {"bound": BOUND_WITHOUT_EVIDENCE.get(name), "bound_evidence": None}    # no counter pass: no claim
     out = {"bound": e["bound"], "bound_evidence": e.get("evidence")}
     if "valu" in e:
         out["valu"] = e["valu"]
@@ -532,12 +539,14 @@ def _bound(name, role, roof):
     return out
 
 
+# (<= 120 characters each: they travel on the compact stdout line)
 INPUT_MODES = {
-    "replay": "one resident tile of synthetic participants per GPU, generated on the device before timing and re-shared by "
-              "every sub-tile with fresh share randomness (inputs resident in HBM when the timed region starts)",
-    "distinct": "every sub-tile shares DIFFERENT participants (splitmix64 of (participant, component), SURVEY.md 8d): two "
-                "secret buffers, tile i+1 generated on a side stream INSIDE the timed region while tile i runs "
-                "(+8 B written per element that the metric does not count)",
+    # one resident tile of synthetic participants per GPU, generated on the device before timing, re-shared by every sub-tile
+    # with fresh share randomness (inputs resident in HBM when the timed region starts)
+    "replay": "replay: one resident tile per GPU (filled on device before timing), re-shared by every sub-tile, fresh randomness",
+    # every sub-tile shares DIFFERENT participants (splitmix64 of (participant, component)): two secret buffers,
+    # tile i+1 generated on a side stream INSIDE the timed region while tile i runs (+8 B written per element, not counted)
+    "distinct": "distinct: every sub-tile shares different participants, next tile filled on a side stream inside the timed region",
 }
 
 
@@ -565,6 +574,8 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
         src = first_of(i) if distinct else rank * P
         capi.check(lib.sda_fill_synthetic_dev(buf.data_ptr(), P, dim, dim, src, SEED, q, stream))
 
+    kern_seen = [None]
+
     def launch(i, total, ev=None):
         """launch i of total+1: generate tile i (if i < total), sum tile i-1 (if i > 0)"""
         cur, prev = shares[i % 2], shares[(i - 1) % 2]
@@ -578,6 +589,8 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
                                  first_participant=first_of(i))
         if ev:
             capi.check(lib.sda_event_record(ev[1], None))
+        if 0 < i < total and kern_seen[0] is None:
+            kern_seen[0] = _library_kernel(env)
         if distinct and i + 1 < total:
             # tile i+1 goes into the OTHER buffer, last read by launch i-1 (already ordered before this point on the
             # launch stream): generate it on the side stream while launch i runs
@@ -636,14 +649,8 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     gen_b, comb_b = algorithmic_bytes_per_element(n, k)
     per_launch_bytes = P * dim * (gen_b + comb_b)
     gbs = tiles * per_launch_bytes / (sum(launch_ms) * 1e-3) / 1e9
-    narrow = prime_of(w) < (1 << 31) and rounds == 20
-    kern = ("fused_additive_kernel" if w["kind"] != "packed" else
-            "fused_packed_n31_kernel" if narrow and w["k"] + w["t"] <= 16 else
-            "fused_packed_mfma_kernel" if (w["k"], w["t"]) in MFMA_DEFAULT_SHAPES else
-            "fused_packed_l31_kernel" if w["k"] + w["t"] <= 16 else
-            "packed_gen_ngemm_kernel" if narrow and prime_of(w) <= 0x7F7F7F and not os.environ.get("SDA_NO_NGEMM") else
-            "packed_gen_fft_kernel + combine_update_kernel (no dual-role form)")
-    has_dual = w["kind"] != "packed" or w["k"] + w["t"] <= 16 or kern == "packed_gen_ngemm_kernel"
+    kern = kern_seen[0] or _library_kernel(env)              # a launch that carried both roles, as the library names it
+    has_dual = " + " not in kern
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
                 "dual-role launch: share-gen of tile i and clerk-sum of tile i-1 interleaved in one grid (shares "
                 "materialised in HBM by one launch, read back by the next); K+1 launches for K tiles" if has_dual else
@@ -651,6 +658,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
                 "share-gen of tile i, two launches per call", share_map=_share_map_name(gen, w))
     res["config"]["inputs"] = INPUT_MODES[inputs]
     res["config"]["distinct_participants"] = world * tiles * P if distinct else world * P
+    res["config"]["library_path"] = gen.path_name()
     res["roofline"] = {"kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic(name, P, dim, "fused_bytes_per_launch"),
                        "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": all_ms,
@@ -763,14 +771,12 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     gen_gbs = per_launch * gen_b / (gen_ms * 1e-3) / 1e9
     comb_gbs = per_launch * comb_b / (comb_ms * 1e-3) / 1e9
     dominant_gen = gen_ms >= comb_ms
-    gen_kernel = ("additive_gen_kernel" if w["kind"] != "packed" else
-                  "packed_gen_n31_kernel" if prime_of(w) < (1 << 31) and rounds == 20 and w["k"] + w["t"] <= 16 else
-                  "packed_gen_mfma_kernel" if (w["k"], w["t"]) in MFMA_DEFAULT_SHAPES else
-                  "packed_gen_l31_kernel" if w["k"] + w["t"] <= 32 else "packed_gen_fft_kernel")
+    gen_kernel = _library_kernel(env)                        # the last generate_batch_dev call, as the library names it
     res = _line(env, name, w, dim, n, k, t, P, n_sub, steps, warmup, dt, Bs, rounds,
                 "share-gen(i+1) overlapped with clerk-sum(i) on two streams, double-buffered shares" if overlap
                 else "one stream, serial", share_map=_share_map_name(gen, w))
     res["config"]["inputs"] = INPUT_MODES["replay"]
+    res["config"]["library_path"] = gen.path_name()
     res["roofline"] = {"kernel": gen_kernel if dominant_gen else "combine_update_kernel",
                        "achieved": gen_gbs if dominant_gen else comb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": (gen_gbs if dominant_gen else comb_gbs) / HBM_PEAK_GBS,
@@ -790,6 +796,75 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
     del secrets, shares, sums, total
     torch.cuda.empty_cache()
     return res
+
+
+LINE_LIMIT = 4096        # bytes of the ONE stdout line (the driver stopped parsing somewhere above 32 KB; stay far below)
+
+
+def _short(s, n=120):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "~"
+
+
+def _sig(x, digits=6):
+    """floats to `digits` significant figures (the full-precision values are in the details file)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _pick(d, keys, digits=6, keep_null=("traffic", "bound")):
+    return {k: _sig(_short(d[k]), digits) for k in keys if k in d and (d[k] is not None or k in keep_null)}
+
+
+def compact_line(full, details_path="bench_details.json"):
+    """The ONE stdout line: the contract's keys + roofline + cpu_baseline + a four-field record per attached workload; strings
+    cut to 120 characters, floats to 6 significant figures.  Everything `full` holds beyond that is in the details file."""
+    line = {k: _sig(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                       "scaling", "vs_baseline", "dtype", "data") if k in full}
+    line["config"] = _pick(full.get("config", {}), ("workload", "baseline_config", "name", "dim", "participants_total",
+                                                     "tile_participants", "modulus", "csprng_share_map", "inputs", "library_path"))
+    roof = full.get("roofline") or {}
+    line["roofline"] = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                    "both_roles_launch_ms", "avg_launch_ms", "launches"))
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "sample", "cpu_model", "physical_cores"))
+        if cpu.get("all_cores"):
+            line["cpu_baseline"]["all_cores"] = _pick(cpu["all_cores"], ("value", "cores"))
+    else:
+        line["cpu_baseline"] = None
+    line["verified_reconstruct_equals_sum"] = full.get("verified_reconstruct_equals_sum")
+    if full.get("n_gpus", 1) > 1 and full.get("rccl"):
+        line["rccl"] = _pick(full["rccl"], ("ranks", "unique_devices", "path"))
+        line["exchange_ms"] = _sig(full.get("exchange_ms"), 4)
+    extra = full.get("additional_workloads") or {}
+    if extra:
+        line["additional_workloads"] = {
+            name: {"value": _sig(r.get("value"), 5), "frac": _sig((r.get("roofline") or {}).get("frac"), 4),
+                   "bound": (r.get("roofline") or {}).get("bound"), "verified": r.get("verified_reconstruct_equals_sum"),
+                   **({"reveal_ms": _sig(r["reveal"]["ms"], 4)} if name.startswith("config5") and r.get("reveal") else {})}
+            for name, r in extra.items()}
+    line["build_id"] = full.get("build_id")
+    line["details"] = os.path.basename(details_path)
+    return line
+
+
+def emit(full, details_path, fd, full_line=False):
+    """details file + stderr first, then the compact line on `fd` (the real stdout), its size checked"""
+    try:
+        with open(details_path, "w") as f:
+            json.dump(full, f, indent=1)
+            f.write("\n")
+    except OSError as e:                                     # a read-only tree must not cost the measurement
+        print(f"[bench] could not write {details_path}: {e}", file=sys.stderr)
+    print("[bench] full record:", json.dumps(full), file=sys.stderr, flush=True)
+    if full_line:                                            # tools/*.sh only: the whole record as the stdout line
+        os.write(fd, (json.dumps(full) + "\n").encode())
+        return
+    text = json.dumps(compact_line(full, details_path), separators=(",", ":"))
+    if len(text.encode()) > LINE_LIMIT:
+        raise SystemExit(f"bench.py: the stdout line is {len(text.encode())} bytes (> {LINE_LIMIT}); trim compact_line()")
+    os.write(fd, (text + "\n").encode())
 
 
 def self_launch(n):
@@ -868,6 +943,10 @@ def main():
                          "of the WHOLE job (default: the BASELINE configuration's: 1,000,000 for config 4, 100,000 for "
                          "config 5); rehearsals pass something small")
     ap.add_argument("--leg-dim", type=int, default=0, help="config 4 / config 5 legs: vector dimension (default: the configuration's)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="measurement scripts only (tools/*.sh): print the FULL record on stdout instead of the compact line")
+    ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
+                    help="where the full record goes (stdout carries the compact line only)")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("--steps must be >= 1 and --warmup >= 0")
@@ -900,6 +979,8 @@ def main():
 
     line = run(args.workload, args.steps, args.warmup, args.participants, args.dim, args.tile)
     line["rccl"] = env.rccl
+    line["build_id"] = env.lib.sda_build_id().decode()
+    line["library"] = env.lib.sda_version().decode()
     keep = ("value", "unit", "n_gpus", "steps", "ms_per_step", "config", "kernels", "roofline", "path_roofline",
             "verified_reconstruct_equals_sum", "verified_against", "reveal", "exchange_ms", "exchange_bytes_per_gpu")
     if env.world == 1 and not args.no_additional and args.workload == "packed":
@@ -929,6 +1010,13 @@ def main():
                                ("narrow_pss19682", 160, 40)):
             r = run(nm, 4, 1, participants=part, tile=tile)
             line["additional_workloads"][nm] = {k: r[k] for k in keep if k in r}
+        # the REFERENCE's own share map on the headline shape (packed_shamir.rs:42 -> tss share: values = [0] ++ secrets ++
+        # randomness): every other number on this line is on the library's systematic map (n - t dot products per batch)
+        if not env.csprng_share_map:
+            env.csprng_share_map = "tss"
+            r = run("packed", 4, 1, participants=(args.participants or 10_000), dim=args.dim)
+            env.csprng_share_map = ""
+            line["additional_workloads"]["packed_tss_nodes"] = {k: r[k] for k in keep if k in r}
     if env.world > 1 and not args.no_additional and args.workload == "packed":
         # The two BASELINE configurations that are DEFINED on several GPUs, sharded over the ranks that
         # are here: config 4 = 1,000,000 participants of packed Shamir t=2 k=8 n=26; config 5 = 100,000 participants at
@@ -965,7 +1053,7 @@ def main():
     sys.stdout.flush()
     C.CDLL(None).fflush(None)
     if env.rank == 0:
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        emit(line, args.details, real_stdout, args.full_line)
     os.close(real_stdout)
 
 

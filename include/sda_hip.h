@@ -24,7 +24,11 @@
  *  - All host-buffer calls are blocking.  The *_dev calls take device pointers and a hipStream_t
  *    (passed as void*; NULL = the device's default stream, which every handle uses for its own
  *    work) and are asynchronous on that stream.  Work issued on different streams is NOT ordered
- *    by the library.
+ *    by the library - with ONE exception: a share combiner's accumulators.  Every *_dev call that reads or
+ *    writes them (begin_dev, update_dev, the wire-fed updates, generate_combine_dev, finish_dev) first makes its
+ *    stream wait for the previous such call when that one ran on another stream, so e.g. generate_combine_dev
+ *    on stream A followed by finish_dev on stream B returns the complete sums (the caller still orders its
+ *    own input and output BUFFERS across streams).
  *  - There is NO CPU fallback: every compute entry point returns SDA_ERR_NO_DEVICE when no gfx950
  *    device is usable.
  *  - Randomness: the reference draws from OsRng inside generate()/mask() (additive.rs:42-44,
@@ -52,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SDA_HIP_ABI_VERSION 4
+#define SDA_HIP_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum sda_status {
@@ -122,6 +126,9 @@ int      sda_masking_has_mask(const sda_masking_scheme_t* s);                /* 
 /* ---- library / device -------------------------------------------------------------------- */
 int         sda_abi_version(void);
 const char* sda_version(void);
+const char* sda_build_id(void);              /* first 16 hex digits of the sha256 over the sources, internal headers and
+                                                the public headers this binary was compiled from ("unknown" for a hand build);
+                                                __graft_entry__.source_digest() recomputes it from a tree */
 int         sda_device_count(void);          /* number of visible HIP devices, 0 if none      */
 int         sda_set_device(int ordinal);     /* device used by handles created afterwards     */
 int         sda_device_pci_bus_id(int ordinal, char* out, size_t cap);   /* "0000:05:00.0"; cap >= 16; identifies the
@@ -149,14 +156,14 @@ int sda_dev_synchronize(void);
  * mask_batch_dev answer SDA_ERR_UNSUPPORTED in this mode).  Packed Shamir's generator / reconstructor refuse it
  * (SDA_ERR_UNSUPPORTED): their signed values are tss's, an un-vendored crate - compare those modulo the prime.  Set the
  * mode right after *_new (CHANGING a combiner's mode discards its running sums: begin again; setting the mode it already has
- * is a no-op).  Memory: generate_batch_dev in this mode without injected randomness first materialises every draw of the
- * tile in the handle's one scratch buffer - participants * len * (share_count - 1) * 8 bytes (2000 participants x 1 Mi x
- * n = 8 would ask for 117 GB) - so size tiles accordingly and keep such calls on ONE stream per handle at a time.
+ * is a no-op).  generate_batch_dev in this mode without injected randomness makes its draws inside the kernel, from the
+ * same sda-drbg-v1 streams as the canonical mode (the shares of the two modes are equal modulo q): no scratch buffer.
  *
- * Streams and the transform shapes.  For packed shapes served by the transform kernel (k + t > 32) generate_combine_dev
- * issues the clerk sum of the previous tile on a low-priority side stream the GENERATOR owns and joins it back into the
- * `stream` of that call only: while generate_combine_dev is in use, every call on that combiner (update_dev, finish_dev)
- * must use the same stream; sda_share_combiner_set_residency does not apply to the side-stream sum (it runs a fixed grid). */
+ * Streams and the transform shapes.  For packed shapes served by the transform kernel (k + t > 32 over a prime above
+ * 0x7F7F7F) generate_combine_dev issues the clerk sum of the previous tile on a low-priority side stream the GENERATOR owns,
+ * joins it back into the `stream` of that call, and the combiner records that point: later calls on the combiner from ANY
+ * stream are ordered after it by the library (see "Conventions").  sda_share_combiner_set_residency does not apply to the
+ * side-stream sum (it runs a fixed grid). */
 enum sda_value_mode { SDA_VALUES_CANONICAL = 0, SDA_VALUES_RUST_SIGNED = 1 };
 
 /* ---- opaque handles: one per (scheme, role), like the reference's boxed trait objects ------ */
@@ -211,12 +218,18 @@ int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int rounds);
  * and uniform draws give the SAME joint distribution of the n shares; t of the n modular dot products per batch
  * disappear ((3,4,8): half of them).  SDA_SHARE_MAP_TSS_NODES is kept for the transform kernel (tss-valid shapes with
  * k + t > 32 over a prime above 0x7F7F7F (~2^23), where the draws are inputs of tss's own transform; up to that bound those shapes run
- * as a matrix product on the matrix cores and take the systematic map too), for t = 0, when a share point collides with a node,
+ * as a matrix product on the matrix cores and take the systematic map too - except under set_drbg_rounds(12 / 8), an A/B
+ * setting the limb GEMM does not serve: those calls go through the transform kernel, hence tss's map, and
+ * csprng_share_map() says so), for t = 0, when a share point collides with a node,
  * and on request (set_csprng_share_map: A/B measurements, round-3 fixtures).  Draw range: the device CSPRNG draws
  * uniformly from [0, p); tss 0.2 draws from [0, p - 1) (rand's Range::new(0, prime - 1)) - the library's range is the
  * one the secrecy argument wants (uniform over the field), and no reconstruction can tell the two apart. */
 enum sda_share_map { SDA_SHARE_MAP_TSS_NODES = 0, SDA_SHARE_MAP_SYSTEMATIC = 1 };
-int sda_share_generator_csprng_share_map(const sda_share_generator_t* g);          /* the map rand == NULL calls use */
+int sda_share_generator_csprng_share_map(const sda_share_generator_t* g);          /* the map the NEXT rand == NULL call uses */
+/* which kernel family the library selected for this scheme, "wide" or "wide+narrow" (sda_amd/csrc/path_select.hpp:
+ * additive | generic mont64 l31 l31_global mfma fft, + n31 | ngemm over narrow primes) - reporting only; every family
+ * computes the same shares (sharing/mod.rs:37-53 dispatches on the scheme enum alone) */
+const char* sda_share_generator_path_name(const sda_share_generator_t* g);
 int sda_share_generator_set_csprng_share_map(sda_share_generator_t* g, int map);   /* SDA_ERR_UNSUPPORTED where it does not exist */
 
 /* generate(&mut self, secrets) -> Vec<Vec<Share>>   - sharing/mod.rs:14-17, batched.rs:18-53.

@@ -33,6 +33,16 @@ extern "C" {
 int  sda_debug_set_knob(const char* name, long value);   /* SDA_ERR_INVALID_ARGUMENT for an unknown name */
 void sda_debug_reset_knobs(void);
 int  sda_debug_env_knobs_compiled_in(void);              /* 1 only in an SDA_AB_KNOBS build */
+/* What the library RAN: the kernel instance(s) launched by the last sda_share_generator_generate_batch_dev /
+ * sda_share_generator_generate_combine_dev call on this thread, named as rocprofv3 prints them ("fused_packed_l31_kernel<3, 1, 20>";
+ * two launches: "packed_gen_fft_kernel<...> + combine_update_walk_kernel (side stream)").  bench.py prints this as roofline.kernel. */
+const char* sda_debug_last_kernel(void);
+/* The kernel-selection table without a device or a handle (sda_amd/csrc/path_select.hpp: the ONE place the decision is made):
+ * `knobs` = comma-separated selection knob names from the list above (NULL or "" = defaults; the process-wide knob state is not
+ * read).  Writes "wide=... narrow=... r_bits=... call20=... call12=... injected=... fused20=... fused12=... transform_shape=.
+ * eight_term_ok=." (family names: additive n31 ngemm l31 mont64 l31_global fft mfma generic). */
+struct sda_sharing_scheme;
+int  sda_debug_select_path(const struct sda_sharing_scheme* scheme, const char* knobs, char* out, size_t cap);
 #ifdef __cplusplus
 }
 #endif

@@ -75,7 +75,11 @@ SIGNATURES = {
     "sda_debug_set_knob": (C.c_int, [C.c_char_p, C.c_long]),
     "sda_debug_reset_knobs": (None, []),
     "sda_debug_env_knobs_compiled_in": (C.c_int, []),
+    "sda_debug_last_kernel": (C.c_char_p, []),
+    "sda_debug_select_path": (C.c_int, [_SS, C.c_char_p, C.c_char_p, C.c_size_t]),
     "sda_version": (C.c_char_p, []),
+    "sda_build_id": (C.c_char_p, []),
+    "sda_share_generator_path_name": (C.c_char_p, [_H]),
     "sda_device_count": (C.c_int, []),
     "sda_set_device": (C.c_int, [C.c_int]),
     "sda_share_generator_set_value_mode": (C.c_int, [_H, C.c_int]),

@@ -200,6 +200,10 @@ class ShareGenerator(_Handle):
     def set_csprng_share_map(self, which: int):
         check(self._lib.sda_share_generator_set_csprng_share_map(self._h, which))
 
+    def path_name(self) -> str:
+        """the kernel family the library selected for this scheme ("l31", "fft+ngemm", ... - sda_amd/csrc/path_select.hpp)"""
+        return self._lib.sda_share_generator_path_name(self._h).decode()
+
     def batch_count(self, length: int) -> int:
         return int(self._lib.sda_share_generator_batch_count(self._h, length))
 

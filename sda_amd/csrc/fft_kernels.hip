@@ -420,7 +420,7 @@ static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const D
     const size_t lds = fft_lds_bytes(F.m2, F.m3, F.G, F.tw_lds != 0, sizeof(V) == 4);
     // 512 threads = 4 waves per SIMD with the two workgroups a CU's LDS holds (PSS_155_728_100, round 2: 58 ms per 500 x 1 Mi
     // tile against 66 with 256 threads, 79 with 1024, 120 with 128)
-    const long want_threads = knob(KNOB_FFT_THREADS);                           // A/B only
+    const long want_threads = F.want_threads;                                   // A/B only (knob SDA_FFT_THREADS when the handle was created)
     unsigned threads = (F.G == 1 && F.m3 > 2187) ? 1024u : 512u;
     if (want_threads >= 64 && want_threads <= 1024 && want_threads % 64 == 0) threads = (unsigned)want_threads;
     if (rounds != 20 && rounds != 12 && rounds != 8) return hipErrorInvalidValue;
@@ -431,7 +431,7 @@ static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const D
     FftPlan Fl = F;
     Fl.groups_padded = 0;
     uint64_t gridg = groups;
-    if (F.G < 8 && !knob(KNOB_NO_XCD_MAP)) {
+    if (F.G < 8 && !F.no_xcd_map) {
         const uint64_t unit = 8ull * (16u / F.G);
         gridg = (groups + unit - 1) / unit * unit;
         Fl.groups_padded = gridg;
@@ -448,6 +448,8 @@ static hipError_t fft_launch_v(const GenLayout& L, const ModParams& mod, const D
         S.out = L.out + p0 * L.out_stride_participant;
         S.participants = cnt;
         S.first_participant = L.first_participant + p0;
+        note_kernel("packed_gen_fft_kernel<%d, %s, %s, %s>", rounds, F.tw_lds ? "true" : "false", sizeof(V) == 4 ? "unsigned int" : "unsigned long",
+                    LAZY ? "true" : "false");
         kern<<<dim3((unsigned)(gridg * cnt)), dim3(threads), lds, s>>>(S, mod, key, Fl, groups, batches);
         if (hipError_t e = hipGetLastError()) return e;
     }

@@ -52,6 +52,10 @@ struct N31Params {
     uint32_t pad;
 };
 
+// The library reports what it ran (include/sda_hip_debug.h: sda_debug_last_kernel): every share-generation launcher names
+// the kernel instance it is about to launch, as rocprofv3 will print it (sda_capi.cpp keeps the last name per thread).
+void note_kernel(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
 // strides in elements
 struct GenLayout {
     const int64_t* secrets;   size_t secrets_stride;
@@ -129,6 +133,8 @@ struct FftPlan {
     uint64_t omega, omega_s;   // omega_shares^(m3 / 3) and its companion
     uint64_t scale, scale_s;   // 1 / m2 and its companion
     uint32_t magic_k1, magic_t; // floor(2^32 / d) + 1 for d = k + 1 and d = t (exact quotients of the loader's small indices)
+    uint32_t want_threads;     // host only, A/B: threads per workgroup (0 = the launcher's choice), knob SDA_FFT_THREADS at handle creation
+    uint32_t no_xcd_map;       // host only, A/B: plain group order for G < 8 (knob SDA_NO_XCD_MAP at handle creation)
 };
 size_t fft_lds_bytes(uint32_t m2, uint32_t m3, uint32_t G, bool tw_lds, bool narrow);
 hipError_t launch_packed_generate_fft(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const FftPlan& F, int rounds,
@@ -175,8 +181,12 @@ hipError_t launch_combine_finish(const uint64_t* d_acc_lo, const int64_t* d_acc_
                                  const ModParams& mod, int64_t* d_out, hipStream_t s);
 
 // ---- the reference's own signed representatives (value mode SDA_VALUES_RUST_SIGNED) - signed_kernels.hip --------------
-// additive.rs:42-47 (L.rand REQUIRED: (n-1) draws per element; shares j < n-1 are the draws, untouched)
-hipError_t launch_additive_generate_signed(const GenLayout& L, uint32_t n, int64_t q, hipStream_t s);
+// additive.rs:42-47: shares j < n-1 are the draws, untouched - injected (L.rand: (n-1) draws per element, ANY i64) or, with
+// L.rand == nullptr, the sda-drbg-v1 draws of the canonical kernel made inside the kernel (no scratch)
+hipError_t launch_additive_generate_signed(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,
+                                           hipStream_t s);
+hipError_t launch_additive_generate_signed_drbg(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,
+                                                hipStream_t s);       // sda_kernels.hip (the DPP-quad CSPRNG lives there)
 // combiner.rs:20-26: state[job][col] = (state + row) % q, rows in order; state is int64 [jobs][dimension]
 hipError_t launch_combine_update_signed(int64_t* d_state, const int64_t* d_shares, size_t jobs, size_t job_stride, size_t n_rows,
                                         size_t row_stride, size_t dimension, int64_t q, hipStream_t s);

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         if (!late) finish(rt);
         __syncthreads();                                            // tile rt + 1 is in LDS (the loader waited for it); slot of tile rt is free
     }
-    if (late) finish(tiles - 1);
+    if (late && tiles) finish(tiles - 1);                           // (a systematic plan with n == t has no matrix rows at all)
 #ifdef NG_TIMING
     if (tid == 0) {                                                 // timing build only: overwrites two shares with cycle counts
         int64_t* o = L.out + p * L.out_stride_participant + b0;
@@ -469,6 +469,7 @@ static hipError_t ngemm_launch(const GenLayout& L, const ModParams& mod, const D
         S.out = L.out + p0 * L.out_stride_participant;
         S.participants = cnt;
         S.first_participant = L.first_participant + p0;
+        note_kernel("packed_gen_ngemm_kernel<%d, %d>", KS, NT);
         kern<<<dim3((unsigned)(chunks * cnt)), dim3(kNgThreads), lds, s>>>(S, mod, key, P, chunks, batches, NgFuse{});
         if (hipError_t e = hipGetLastError()) return e;
     }
@@ -515,6 +516,7 @@ static hipError_t ngemm_launch_fused(const GenLayout& L, const ModParams& mod, c
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     *fused = true;
+    note_kernel("packed_gen_ngemm_kernel<%d, %d>", KS, NT);
     kern<<<dim3((unsigned)grid), dim3(kNgThreads), lds, s>>>(L, mod, key, P, chunks ? chunks : 1, batches, F);
     return hipGetLastError();
 }

@@ -26,6 +26,7 @@
 #include "host_math.hpp"
 #include "kernels.hpp"
 #include "modarith.hpp"
+#include "path_select.hpp"
 
 using namespace sda;
 
@@ -133,7 +134,25 @@ extern "C" int sda_debug_env_knobs_compiled_in(void) {
     return 0;
 #endif
 }
-extern "C" const char* sda_version(void) { return "sda-hip 0.4.0 (gfx950)"; }
+extern "C" const char* sda_version(void) { return "sda-hip 0.5.0 (gfx950)"; }
+
+// ---- what ran, and what this binary was built from ------------------------------------------------------------------
+// SDA_BUILD_ID is handed in by __graft_entry__.build(): the sha256 (first 16 hex digits) over the library's sources, internal
+// headers and include/*.h.  smoke() and tests recompute it from the tree: a stale prebuilt .so cannot pass for a fresh one.
+#ifndef SDA_BUILD_ID
+#define SDA_BUILD_ID "unknown"
+#endif
+extern "C" const char* sda_build_id(void) { return SDA_BUILD_ID; }
+
+static thread_local char g_last_gen_kernel[192];       // the last share-generation kernel instance launched on this thread
+static thread_local char g_last_call_kernels[320];     // ... and the launches of the last generate call, as one string
+void sda::note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_gen_kernel, sizeof g_last_gen_kernel, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sda_debug_last_kernel(void) { return g_last_call_kernels; }
 
 // -------------------------------------------------------------------------------------------------
 // device context
@@ -518,6 +537,9 @@ struct sda_share_generator {
     N31Params n31p{};
     MatArg* matarg_n31 = nullptr;        // int32 constants, tss map
     MatArg* matarg_n31_sys = nullptr;    // int32 constants, systematic map
+    PathChoice path{};                   // what select_path() decided for this scheme (path_select.hpp) ...
+    PathKnobs knobs{};                   // ... under these knobs, snapshotted when the handle was created
+    long knob_fft_g = 0, knob_no_lazy = 0, knob_no_side_stream = 0, knob_side_wgs = 0, knob_side_prio_high = 0;
     bool fast = false;
     bool l31 = false;                    // balanced-31-bit-limb kernel, matrix in the kernarg segment
     bool l31g = false;                   // the same with run-time (k, t) and the matrix in global memory (d_M)
@@ -547,7 +569,7 @@ struct sda_share_generator {
         // clerk sum takes the wave slots and registers they leave (at high priority it starved them: no gain, measured)
         hipStream_t st = nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        hipError_t e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, knob(KNOB_SIDE_STREAM_PRIORITY_HIGH) ? greatest : least);
+        hipError_t e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, knob_side_prio_high ? greatest : least);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
         if (e != hipSuccess) {                                   // all three or none: a half-built set would fail every later call
@@ -715,9 +737,9 @@ static int l31_params(uint64_t p, L31Params& lp) {
 // tss's transform structure applies when k + t + 1 = 2^a = ord(omega_secrets) and n + 1 = 3^b = ord(omega_shares)
 // (SURVEY.md App. B); the kernel also needs the group's values in LDS (p < 2^62 holds for every modulus the library takes).
 // Two workgroups per CU (80 KB each) when a group of 8 batches fits, with the twiddle tables in LDS too if there is room.
-static bool fft_narrow(uint64_t p) { return p < (1ull << 30) && !knob(KNOB_NO_NARROW); }   // 4p < 2^32: the kernel's lazy ranges in 32 bits
-static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, uint32_t& G, uint32_t& tw_lds) {
-    const bool narrow = fft_narrow(g->mod.m);
+static bool fft_narrow(uint64_t p, const PathKnobs& kn) { return p < (1ull << 30) && !kn.no_narrow; }   // 4p < 2^32: the kernel's lazy ranges in 32 bits
+static bool fft_shape(const sda_share_generator* g, const PathKnobs& kn, uint32_t& a, uint32_t& b, uint32_t& G, uint32_t& tw_lds) {
+    const bool narrow = fft_narrow(g->mod.m, kn);
     const uint64_t p = g->mod.m, m2 = (uint64_t)g->k + g->t + 1, m3 = (uint64_t)g->n + 1;
     if (p >= (1ull << 62)) return false;
     a = 0; while ((1ull << a) < m2) ++a;
@@ -741,7 +763,7 @@ static bool fft_shape(const sda_share_generator* g, uint32_t& a, uint32_t& b, ui
         for (uint32_t tw = 2; tw-- > 0 && !G;)
             if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, cand, tw != 0, narrow) <= half_cu) { G = cand; tw_lds = tw; }
     if (!G && fft_lds_bytes((uint32_t)m2, (uint32_t)m3, 1, false, narrow) <= whole_cu) { G = 1; tw_lds = 0; }
-    if (const long fg = knob(KNOB_FFT_G)) {                               // A/B only: fewer batches per workgroup
+    if (const long fg = g->knob_fft_g) {                               // A/B only: fewer batches per workgroup
         const uint32_t want = (uint32_t)fg;
         if (want == 1 || want == 2 || want == 4 || want == 8 || want == 16) {
             if (fft_lds_bytes((uint32_t)m2, (uint32_t)m3, want, true, narrow) <= half_cu) { G = want; tw_lds = 1; }
@@ -785,7 +807,7 @@ static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G,
     const uint64_t w2 = h_canon(g->scheme.omega_secrets, p), w3 = h_canon(g->scheme.omega_shares, p);
     uint64_t w2i, m2i;
     if (!h_invmod(w2, p, w2i) || !h_invmod(m2 % p, p, m2i)) return fail(SDA_ERR_INVALID_ARGUMENT, "omega_secrets is not invertible");
-    const bool narrow = fft_narrow(p);
+    const bool narrow = fft_narrow(p, g->knobs);
     FftPlan& F = g->fplan;
     F.narrow = narrow ? 1u : 0u;
     if (narrow) {                                               // the same tables as (uint32 w, uint32 floor(w 2^32 / p)) pairs
@@ -818,9 +840,11 @@ static int build_fft(sda_share_generator* g, uint32_t a, uint32_t b, uint32_t G,
     shoup_pair(m2i, p, F.scale, F.scale_s);
     if (narrow) { F.omega_s = (F.omega << 32) / p; F.scale_s = (F.scale << 32) / p; }
     F.one_s = narrow ? (1ull << 32) / p : 0;
-    F.lazy = narrow && (4ull * b + 4) * p < (1ull << 32) && !knob(KNOB_NO_LAZY) ? 1u : 0u;
+    F.lazy = narrow && (4ull * b + 4) * p < (1ull << 32) && !g->knob_no_lazy ? 1u : 0u;
     F.magic_k1 = (uint32_t)(0x100000000ull / ((uint64_t)g->k + 1)) + 1u;                 // k + 1 >= 2
     F.magic_t = g->t > 1 ? (uint32_t)(0x100000000ull / g->t) + 1u : 0u;
+    F.want_threads = (uint32_t)knob(KNOB_FFT_THREADS);
+    F.no_xcd_map = knob(KNOB_NO_XCD_MAP) ? 1u : 0u;
     return SDA_OK;
 }
 
@@ -865,6 +889,34 @@ static int build_ngemm(sda_share_generator* g) {
     return SDA_OK;
 }
 
+// the selection knobs as they stand now (include/sda_hip_debug.h): read ONCE per handle, so that a knob changed later cannot
+// switch a live handle to another kernel family or share map
+static PathKnobs snapshot_knobs() {
+    PathKnobs kn;
+    kn.force_generic = knob(KNOB_FORCE_GENERIC) != 0; kn.force_mont64 = knob(KNOB_FORCE_MONT64) != 0;
+    kn.force_fft = knob(KNOB_FORCE_FFT) != 0; kn.force_mfma = knob(KNOB_FORCE_MFMA) != 0; kn.no_mfma = knob(KNOB_NO_MFMA) != 0;
+    kn.no_narrow = knob(KNOB_NO_NARROW) != 0; kn.no_ngemm = knob(KNOB_NO_NGEMM) != 0;
+    return kn;
+}
+static void snapshot_call_knobs(sda_share_generator* g) {
+    g->knob_fft_g = knob(KNOB_FFT_G); g->knob_no_lazy = knob(KNOB_NO_LAZY); g->knob_no_side_stream = knob(KNOB_NO_SIDE_STREAM);
+    g->knob_side_wgs = knob(KNOB_SIDE_STREAM_WGS); g->knob_side_prio_high = knob(KNOB_SIDE_STREAM_PRIORITY_HIGH);
+}
+// what select_path() needs to know about the constants: host arithmetic only (g->Mmont must be built)
+static PathFacts path_facts(const sda_share_generator* g, const PathKnobs& kn) {
+    PathFacts f;
+    uint32_t a = 0, b = 0, G = 0, tw = 0;
+    f.transform_shape = fft_shape(g, kn, a, b, G, tw);
+    if (packed_l31_path_available(g->k, g->t, g->n) && packed_l31_r_bits(g->k, g->t) == 93) {
+        // the 8-term last group of a three-digit shape is admitted on the constants of BOTH share maps
+        std::vector<uint64_t> sys_tmp;
+        f.eight_term_ok = l31_eight_term_group_ok(g->Mmont, g->k + g->t, g->mod.m);
+        if (f.eight_term_ok && build_systematic_share_matrix(g->scheme, g->mod.m, sys_tmp))
+            f.eight_term_ok = l31_eight_term_group_ok(sys_tmp, g->k + g->t, g->mod.m);
+    }
+    return f;
+}
+
 extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_share_generator_t** out) {
     if (!out) return fail(SDA_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -893,82 +945,99 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
     }
     if (st == SDA_OK) st = g->ctx.init();
     if (st == SDA_OK && !g->additive) {
-        g->l31 = packed_l31_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64);
-        if (g->l31 && packed_l31_r_bits(g->k, g->t) == 93) {
-            // the 8-term last group of a three-digit shape is admitted on the constants of BOTH share maps
-            std::vector<uint64_t> sys_tmp;
-            bool ok = l31_eight_term_group_ok(g->Mmont, g->k + g->t, g->mod.m);
-            if (ok && build_systematic_share_matrix(*scheme, g->mod.m, sys_tmp)) ok = l31_eight_term_group_ok(sys_tmp, g->k + g->t, g->mod.m);
-            if (!ok) g->l31 = false;
-        }
-        g->fast = !g->l31 && packed_fast_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC);
-        g->l31g = !g->l31 && !g->fast && packed_l31_global_path_available(g->k, g->t) && !knob(KNOB_FORCE_GENERIC) &&
-                  !knob(KNOB_FORCE_MONT64);
-        // the transform form: every tss-valid shape with k + t > 32 (beyond that the matrix kernels run at one wave per SIMD
-        // or not at all); SDA_FORCE_FFT=1 selects it for any tss-valid shape (A/B runs, parity tests of small shapes)
-        uint32_t fa = 0, fb = 0, fG = 0, ftw = 0;
-        if (!knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64) && ((uint64_t)g->k + g->t > 32 || knob(KNOB_FORCE_FFT)) &&
-            fft_shape(g, fa, fb, fG, ftw)) {
-            g->fft = true; g->l31 = g->l31g = g->fast = false;
-            st = build_fft(g, fa, fb, fG, ftw);
-            // over a prime below 2^23 (tss's own) the dense product on the matrix cores is ahead of the transform (k + t > 16:
-            // below that the one-limb vector kernels serve the shape); same draws, same shares - the transform plan stays built
-            // for the other ChaCha round counts and A/B runs (knob SDA_NO_NGEMM)
-            if (st == SDA_OK && g->fplan.narrow && !knob(KNOB_NO_NGEMM) && g->k + g->t > 16 && packed_ngemm_path_available(g->k, g->t, g->mod.m))
-                st = build_ngemm(g);
-        } else if (packed_mfma_path_available(g->k, g->t, g->n) && !knob(KNOB_FORCE_GENERIC) && !knob(KNOB_FORCE_MONT64) &&
-                   !knob(KNOB_NO_MFMA) && ((g->k + g->t >= 12 && !(g->l31 && packed_l31_r_bits(g->k, g->t) == 93)) || knob(KNOB_FORCE_MFMA))) {
-            // round 4: (8,7) now has a three-digit limb-31 instance (one reduction per 15-term dot product), which is ahead of the
-            // limb GEMM again - 62.2 vs 58.2 Gelem/s, interleaved A/B - so the limb GEMM keeps the other 12..16-term shapes
-            // the limb GEMM on the matrix cores: measured ahead of the limb-31 kernel from k + t = 15 with n = 26 (+12 %),
-            // behind it for k + t = 10 and below (knob SDA_FORCE_MFMA takes it for every compiled shape, SDA_NO_MFMA never)
-            g->mfma = true; g->l31 = g->l31g = g->fast = false;
-            g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
-            st = build_mfma(g);
-        } else if (g->l31 || g->l31g) {
-            g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
-            st = build_l31(g);
-        } else if (g->fast) {
-            g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
-            g->matarg = new (std::nothrow) MatArg();
-            if (g->sys_default) g->matarg_sys = new (std::nothrow) MatArg();
-            if (!g->matarg || (g->sys_default && !g->matarg_sys)) st = fail(SDA_ERR_ALLOC, "out of memory");
-            else {
-                memset(g->matarg, 0, sizeof(MatArg));
-                memcpy(g->matarg->e, g->Mmont.data(), g->Mmont.size() * 8);
-                if (g->sys_default) {
-                    memset(g->matarg_sys, 0, sizeof(MatArg));
-                    memcpy(g->matarg_sys->e, g->Msys.data(), g->Msys.size() * 8);
+        // ONE decision (path_select.hpp), then build what it names.  The wide family serves every call; a narrow family on top of
+        // it (p < 2^31) serves the ChaCha20 / injected-randomness calls.
+        g->knobs = snapshot_knobs();
+        snapshot_call_knobs(g);
+        g->path = select_path(g->k, g->t, g->n, g->mod.m, path_facts(g, g->knobs), g->knobs);
+        g->fft = g->path.wide == WIDE_FFT; g->mfma = g->path.wide == WIDE_MFMA; g->l31 = g->path.wide == WIDE_L31;
+        g->l31g = g->path.wide == WIDE_L31_GLOBAL; g->fast = g->path.wide == WIDE_MONT64;
+        // the systematic share map (draws = shares 0..t-1) exists for every matrix-form family, not for the transform
+        if (!g->fft || g->path.narrow == NARROW_NGEMM) g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
+        switch (g->path.wide) {
+            case WIDE_FFT: {
+                uint32_t fa = 0, fb = 0, fG = 0, ftw = 0;
+                if (!fft_shape(g, g->knobs, fa, fb, fG, ftw)) st = fail(SDA_ERR_STATE, "transform plan vanished between selection and build");
+                else st = build_fft(g, fa, fb, fG, ftw);
+                break;
+            }
+            case WIDE_MFMA: st = build_mfma(g); break;
+            case WIDE_L31:
+            case WIDE_L31_GLOBAL: st = build_l31(g); break;
+            case WIDE_MONT64:
+                g->matarg = new (std::nothrow) MatArg();
+                if (g->sys_default) g->matarg_sys = new (std::nothrow) MatArg();
+                if (!g->matarg || (g->sys_default && !g->matarg_sys)) st = fail(SDA_ERR_ALLOC, "out of memory");
+                else {
+                    memset(g->matarg, 0, sizeof(MatArg));
+                    memcpy(g->matarg->e, g->Mmont.data(), g->Mmont.size() * 8);
+                    if (g->sys_default) {
+                        memset(g->matarg_sys, 0, sizeof(MatArg));
+                        memcpy(g->matarg_sys->e, g->Msys.data(), g->Msys.size() * 8);
+                    }
                 }
-            }
-        } else {
-            g->sys_default = build_systematic_share_matrix(*scheme, g->mod.m, g->Msys);
-            st = g->d_M.reserve(g->Mmont.size() * 8);
-            if (st == SDA_OK && hipMemcpy(g->d_M.p, g->Mmont.data(), g->Mmont.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
-                st = fail(SDA_ERR_HIP, "uploading the share matrix failed");
-            if (st == SDA_OK && g->sys_default) {
-                st = g->d_Msys.reserve(g->Msys.size() * 8 + 8);
-                if (st == SDA_OK && hipMemcpy(g->d_Msys.p, g->Msys.data(), g->Msys.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
-                    st = fail(SDA_ERR_HIP, "uploading the systematic share matrix failed");
-            }
+                break;
+            default:
+                st = g->d_M.reserve(g->Mmont.size() * 8);
+                if (st == SDA_OK && hipMemcpy(g->d_M.p, g->Mmont.data(), g->Mmont.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+                    st = fail(SDA_ERR_HIP, "uploading the share matrix failed");
+                if (st == SDA_OK && g->sys_default) {
+                    st = g->d_Msys.reserve(g->Msys.size() * 8 + 8);
+                    if (st == SDA_OK && hipMemcpy(g->d_Msys.p, g->Msys.data(), g->Msys.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+                        st = fail(SDA_ERR_HIP, "uploading the systematic share matrix failed");
+                }
+                break;
         }
+        if (st == SDA_OK && g->path.narrow == NARROW_N31) st = build_n31(g);
+        if (st == SDA_OK && g->path.narrow == NARROW_NGEMM) st = build_ngemm(g);
         g->sys = g->sys_default;
-        // a narrow prime (p < 2^31 - everything the reference itself can run) takes the one-limb kernels whenever the shape
-        // fits their run-time (k, t) form; the wide path chosen above stays built (other ChaCha round counts, A/B)
-        const bool forced = knob(KNOB_FORCE_GENERIC) || knob(KNOB_FORCE_MONT64) || knob(KNOB_FORCE_MFMA) || knob(KNOB_FORCE_FFT);
-        if (st == SDA_OK && !g->fft && !forced && !knob(KNOB_NO_NARROW) && packed_n31_path_available(g->k, g->t, g->n, g->mod.m))
-            st = build_n31(g);
-        // ... and beyond the one-limb kernels' 16 terms ANY shape over a prime below 2^23 takes the limb GEMM on the matrix cores
-        // (it only needs the share matrix, not tss's transform structure)
-        if (st == SDA_OK && !g->ngemm && !g->n31 && !forced && !knob(KNOB_NO_NARROW) && !knob(KNOB_NO_NGEMM) && g->k + g->t > 16 &&
-            packed_ngemm_path_available(g->k, g->t, g->mod.m)) {
-            st = build_ngemm(g);
-            if (st == SDA_OK) g->sys = g->sys_default;
-        }
     }
     if (st != SDA_OK) { sda_share_generator_free(g); return st; }
     *out = g;
     return SDA_OK;
+}
+
+// The decision table without a device (tests/test_path_select.py runs it on a machine with no GPU): validates the scheme, builds
+// the host-side facts, calls select_path() under the NAMED knobs (comma separated, NULL / "" = defaults; the process-wide knob
+// state is not read) and describes the choice and what each kind of call would run.
+extern "C" int sda_debug_select_path(const sda_sharing_scheme_t* scheme, const char* knobs, char* out, size_t cap) {
+    if (!out || cap < 8) return fail(SDA_ERR_INVALID_ARGUMENT, "out needs a buffer");
+    out[0] = 0;
+    SDA_TRY(check_scheme_kind(scheme));
+    if (sharing_is_additive(scheme)) { snprintf(out, cap, "wide=additive narrow=none call20=additive fused20=additive"); return SDA_OK; }
+    SDA_TRY(validate_packed(*scheme));
+    PathKnobs kn;
+    for (const char* q = knobs ? knobs : ""; *q;) {
+        const char* e = strchr(q, ',');
+        const size_t len = e ? (size_t)(e - q) : strlen(q);
+        const std::string name(q, len);
+        if (name == "SDA_FORCE_GENERIC") kn.force_generic = true;
+        else if (name == "SDA_FORCE_MONT64") kn.force_mont64 = true;
+        else if (name == "SDA_FORCE_FFT") kn.force_fft = true;
+        else if (name == "SDA_FORCE_MFMA") kn.force_mfma = true;
+        else if (name == "SDA_NO_MFMA") kn.no_mfma = true;
+        else if (name == "SDA_NO_NARROW") kn.no_narrow = true;
+        else if (name == "SDA_NO_NGEMM") kn.no_ngemm = true;
+        else if (!name.empty()) return fail(SDA_ERR_INVALID_ARGUMENT, "%s is not a selection knob", name.c_str());
+        q += len + (e ? 1 : 0);
+    }
+    sda_share_generator* g = new (std::nothrow) sda_share_generator();
+    if (!g) return fail(SDA_ERR_ALLOC, "out of memory");
+    g->scheme = *scheme; g->additive = false;
+    g->n = (uint32_t)scheme->share_count; g->k = (uint32_t)scheme->secret_count; g->t = (uint32_t)scheme->privacy_threshold;
+    int st = make_mod(scheme->modulus, g->mod);
+    if (st == SDA_OK) st = build_packed_share_matrix(*scheme, g->mod.m, g->Mmont);
+    if (st == SDA_OK) {
+        const PathFacts f = path_facts(g, kn);
+        const PathChoice c = select_path(g->k, g->t, g->n, g->mod.m, f, kn);
+        snprintf(out, cap, "wide=%s narrow=%s r_bits=%u call20=%s call12=%s injected=%s fused20=%s fused12=%s transform_shape=%d eight_term_ok=%d",
+                 wide_name(c.wide), narrow_name(c.narrow), c.wide == WIDE_L31 ? c.l31_r_bits : 0u, family_name(path_for_call(c, false, 20)),
+                 family_name(path_for_call(c, false, 12)), family_name(path_for_call(c, true, 20)),
+                 fused_for_call(c, 20) == FAM_GENERIC ? "none" : family_name(fused_for_call(c, 20)),
+                 fused_for_call(c, 12) == FAM_GENERIC ? "none" : family_name(fused_for_call(c, 12)), (int)f.transform_shape, (int)f.eight_term_ok);
+    }
+    sda_share_generator_free(g);
+    return st;
 }
 
 extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
@@ -1025,8 +1094,23 @@ extern "C" int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int
     return g->drbg.set_rounds(rounds);
 }
 
+// the map the device CSPRNG's draws go through on the NEXT call: the systematic one where the handle has it, except on a
+// transform-shape handle under ChaCha12 / ChaCha8 (A/B only) - the limb GEMM draws with ChaCha20 only, and the transform
+// kernel that serves those calls computes tss's own map
+static bool effective_sys(const sda_share_generator_t* g) {
+    return g->sys && !g->additive && g->t > 0 && !(g->fft && g->drbg.rounds != 20);
+}
 extern "C" int sda_share_generator_csprng_share_map(const sda_share_generator_t* g) {
-    return g && g->sys ? SDA_SHARE_MAP_SYSTEMATIC : SDA_SHARE_MAP_TSS_NODES;
+    return g && effective_sys(g) ? SDA_SHARE_MAP_SYSTEMATIC : SDA_SHARE_MAP_TSS_NODES;
+}
+// "wide[+narrow]" as select_path() chose for this scheme, e.g. "l31", "fft+ngemm", "l31+n31", "additive"
+extern "C" const char* sda_share_generator_path_name(const sda_share_generator_t* g) {
+    static thread_local char buf[48];
+    if (!g) return "";
+    if (g->additive) return "additive";
+    if (g->path.narrow == NARROW_NONE) return wide_name(g->path.wide);
+    snprintf(buf, sizeof buf, "%s+%s", wide_name(g->path.wide), narrow_name(g->path.narrow));
+    return buf;
 }
 extern "C" int sda_share_generator_set_csprng_share_map(sda_share_generator_t* g, int map) {
     if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "generator is NULL");
@@ -1056,78 +1140,52 @@ static int generate_batch_impl(sda_share_generator_t* g, const DrbgKey& key, con
     L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
     L.participants = participants; L.len = len; L.first_participant = first_participant;
     // the device CSPRNG's draws are shares 0..t-1 themselves (systematic share map); injected randomness keeps tss's map
-    const bool sys = !d_rand && !g->additive && g->sys && g->t > 0;
+    const bool sys = !d_rand && effective_sys(g);
     L.direct_rows = sys ? g->t : 0;
     if (g->additive && g->rust_signed) {
-        // the reference's representatives: shares 0..n-2 are the draws themselves, the last one the fold of (acc - r) % q.
-        // Draws that are not injected are materialised first - the same sda-drbg-v1 values the canonical kernel would use
-        if (!d_rand && g->n > 1) {
-            // every draw of the tile is materialised in the handle's one scratch buffer: participants * len * (n - 1) * 8
-            // bytes (sda_hip.h, "value modes": a fidelity mode - size tiles for it, one call at a time per handle)
-            size_t rstride = 0, total = 0;
-            if (__builtin_mul_overflow(len, (size_t)(g->n - 1), &rstride) || __builtin_mul_overflow(participants, rstride, &total) ||
-                total > (SIZE_MAX >> 3))
-                return fail(SDA_ERR_INVALID_ARGUMENT, "participants * len * (share_count - 1) draws do not fit a buffer");
-            SDA_TRY(g->d_rand.reserve(total * 8));
-            HIP_TRY(launch_drbg_fill(g->d_rand.as<int64_t>(), rstride, participants, len, g->n - 1, first_participant, g->mod, key,
-                                     g->drbg.rounds, s));
-            L.rand = g->d_rand.as<int64_t>();
-            L.rand_stride = rstride;
-        }
-        if (g->n == 1) { L.rand = d_secrets; L.rand_stride = 0; }          // no draws at all: the pointer is never read
-        HIP_TRY(launch_additive_generate_signed(L, g->n, (int64_t)g->mod.m, s));
+        // the reference's representatives: shares 0..n-2 are the draws themselves, the last one the fold of (acc - r) % q
+        // (additive.rs:42-47).  Draws that are not injected come from the same sda-drbg-v1 streams the canonical kernel uses,
+        // inside the kernel: no scratch
+        HIP_TRY(launch_additive_generate_signed(L, g->n, g->mod, key, g->drbg.rounds, s));
         return SDA_OK;
     }
     if (g->additive) {
         HIP_TRY(launch_additive_generate(L, g->n, g->mod, key, g->drbg.rounds, s));
         return SDA_OK;
     }
-    if (g->n31 && (d_rand || g->drbg.rounds == 20)) {
-        HIP_TRY(launch_packed_generate_n31(L, g->n, g->k, g->t, g->mod, g->n31p, sys ? *g->matarg_n31_sys : *g->matarg_n31, key, s));
-        return SDA_OK;
-    }
-    if (g->ngemm && !g->fft && (d_rand || g->drbg.rounds == 20)) {
-        HIP_TRY(launch_packed_generate_ngemm(L, g->mod, key, sys ? g->gplan_sys : g->gplan, s));
-        return SDA_OK;
-    }
-    if (g->l31) {
-        HIP_TRY(launch_packed_generate_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds, s));
-        return SDA_OK;
-    }
-    if (g->fast) {
-        HIP_TRY(launch_packed_generate(L, g->n, g->k, g->t, g->mod, g->mont, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds, s));
-        return SDA_OK;
-    }
-    if (g->l31g) {
-        HIP_TRY(launch_packed_generate_l31_global(L, g->n, g->k, g->t, g->mod, g->lp, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key,
-                                                  g->drbg.rounds, s));
-        return SDA_OK;
-    }
-    if (g->fft) {
-        if (g->ngemm && (d_rand || g->drbg.rounds == 20)) {
+    switch (path_for_call(g->path, d_rand != nullptr, g->drbg.rounds)) {
+        case FAM_N31:
+            HIP_TRY(launch_packed_generate_n31(L, g->n, g->k, g->t, g->mod, g->n31p, sys ? *g->matarg_n31_sys : *g->matarg_n31, key, s));
+            return SDA_OK;
+        case FAM_NGEMM:
             HIP_TRY(launch_packed_generate_ngemm(L, g->mod, key, sys ? g->gplan_sys : g->gplan, s));
             return SDA_OK;
-        }
-        if (!sys) {
+        case FAM_L31:
+            HIP_TRY(launch_packed_generate_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds, s));
+            return SDA_OK;
+        case FAM_MONT64:
+            HIP_TRY(launch_packed_generate(L, g->n, g->k, g->t, g->mod, g->mont, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds, s));
+            return SDA_OK;
+        case FAM_L31_GLOBAL:
+            HIP_TRY(launch_packed_generate_l31_global(L, g->n, g->k, g->t, g->mod, g->lp, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key,
+                                                      g->drbg.rounds, s));
+            return SDA_OK;
+        case FAM_FFT:                                         // tss's own map by construction (effective_sys() is false here)
             HIP_TRY(launch_packed_generate_fft(L, g->mod, key, g->fplan, g->drbg.rounds, s));
             return SDA_OK;
-        }
-        // the systematic map under another ChaCha round count (A/B only): the any-shape kernel below, matrices uploaded on first use
-        if (!g->d_Msys.p) {
-            SDA_TRY(g->d_Msys.reserve(g->Msys.size() * 8 + 8));
-            HIP_TRY(hipMemcpy(g->d_Msys.p, g->Msys.data(), g->Msys.size() * 8, hipMemcpyHostToDevice));
-        }
-    }
-    if (g->mfma) {
-        HIP_TRY(launch_packed_generate_mfma(L, g->n, g->k, g->t, g->mod, g->mont, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key,
-                                            g->drbg.rounds, s));
-        return SDA_OK;
+        case FAM_MFMA:
+            HIP_TRY(launch_packed_generate_mfma(L, g->n, g->k, g->t, g->mod, g->mont, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key,
+                                                g->drbg.rounds, s));
+            return SDA_OK;
+        default: break;
     }
     // any-shape path: materialise the CSPRNG draws first (identical values to the fused path)
     if (!d_rand && g->t > 0) {
         const size_t batches = (len + g->k - 1) / g->k;
-        const size_t rstride = batches * g->t;
-        SDA_TRY(g->d_rand.reserve(participants * rstride * 8));
+        size_t rstride = 0, total = 0;
+        if (__builtin_mul_overflow(batches, (size_t)g->t, &rstride) || __builtin_mul_overflow(participants, rstride, &total) || total > (SIZE_MAX >> 3))
+            return fail(SDA_ERR_INVALID_ARGUMENT, "participants * batches * privacy_threshold draws do not fit a buffer");
+        SDA_TRY(g->d_rand.reserve(total * 8));
         HIP_TRY(launch_drbg_fill(g->d_rand.as<int64_t>(), rstride, participants, batches, g->t, first_participant, g->mod,
                                  key, g->drbg.rounds, s));
         L.rand = g->d_rand.as<int64_t>();
@@ -1146,8 +1204,10 @@ extern "C" int sda_share_generator_generate_batch_dev(sda_share_generator_t* g, 
     if (!g) return fail(SDA_ERR_INVALID_ARGUMENT, "generator is NULL");
     if (participants == 0 || len == 0) return SDA_OK;
     DrbgKey key = d_rand ? DrbgKey{} : g->drbg.call_key();      // injected randomness draws nothing from the CSPRNG
+    g_last_gen_kernel[0] = 0;
     const int st = generate_batch_impl(g, key, d_secrets, participants, len, secrets_stride, d_rand, rand_stride, first_participant,
                                        d_out, out_stride_participant, out_stride_clerk, stream);
+    snprintf(g_last_call_kernels, sizeof g_last_call_kernels, "%s", g_last_gen_kernel);
     explicit_bzero(&key, sizeof key);
     return st;
 }
@@ -1197,6 +1257,23 @@ struct sda_share_combiner {
     size_t jobs = 0, dimension = 0;
     bool begun = false;
     unsigned max_wg_per_cu = 0;          // 0 = no cap (sda_share_combiner_set_residency)
+    // Cross-stream ordering of the accumulators.  Every *_dev call that touches them records `ev_done` on its stream when it has
+    // queued its work, and first makes its stream wait for the previous call's event when that call ran on ANOTHER stream.  So
+    // generate_combine_dev on stream A followed by finish_dev on stream B is ordered by the library, not by the caller
+    // (clerk.rs:80-86 has one thread and no streams: the reference's caller cannot be asked to keep such a rule).
+    hipEvent_t ev_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+    int join_pending(hipStream_t s) {
+        if (pending && s != last_stream) HIP_TRY(hipStreamWaitEvent(s, ev_done, 0));
+        return SDA_OK;
+    }
+    int mark_pending(hipStream_t s) {
+        if (!ev_done) HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_done, s));
+        last_stream = s; pending = true;
+        return SDA_OK;
+    }
 };
 
 extern "C" int sda_share_combiner_new(const sda_sharing_scheme_t* scheme, sda_share_combiner_t** out) {
@@ -1216,6 +1293,7 @@ extern "C" void sda_share_combiner_free(sda_share_combiner_t* c) {
     if (!c) return;
     if (c->ctx.device >= 0) (void)hipSetDevice(c->ctx.device);
     c->acc.release(); c->tile.release(); c->d_out.release();
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     c->ctx.destroy();
     delete c;
 }
@@ -1242,9 +1320,10 @@ extern "C" int sda_share_combiner_begin_dev(sda_share_combiner_t* c, size_t jobs
     if (!c) return fail(SDA_ERR_INVALID_ARGUMENT, "combiner is NULL");
     if (jobs > 65535) return fail(SDA_ERR_UNSUPPORTED, "at most 65535 jobs");
     SDA_TRY(c->ctx.use());
+    SDA_TRY(c->join_pending(c->ctx.pick(stream)));
     SDA_TRY(c->acc.reset(jobs * dimension, c->ctx.pick(stream)));
     c->jobs = jobs; c->dimension = dimension; c->begun = true;
-    return SDA_OK;
+    return c->mark_pending(c->ctx.pick(stream));
 }
 
 extern "C" int sda_share_combiner_set_value_mode(sda_share_combiner_t* c, int mode) {
@@ -1264,7 +1343,9 @@ extern "C" int sda_share_combiner_update_dev(sda_share_combiner_t* c, const int6
     if (n_rows == 0 || c->jobs == 0 || c->dimension == 0) return SDA_OK;
     if (!d_shares) return fail(SDA_ERR_INVALID_ARGUMENT, "d_shares is NULL");
     SDA_TRY(c->ctx.use());
-    return acc_update(c->acc, d_shares, c->jobs, job_stride, n_rows, row_stride, c->dimension, c->ctx.pick(stream), c->max_wg_per_cu);
+    SDA_TRY(c->join_pending(c->ctx.pick(stream)));
+    SDA_TRY(acc_update(c->acc, d_shares, c->jobs, job_stride, n_rows, row_stride, c->dimension, c->ctx.pick(stream), c->max_wg_per_cu));
+    return c->mark_pending(c->ctx.pick(stream));
 }
 
 // software-pipelined step: tile i+1 is generated while tile i is summed, in one dual-role launch
@@ -1289,30 +1370,40 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     L.secrets = d_secrets; L.secrets_stride = secrets_stride; L.rand = nullptr; L.rand_stride = 0;
     L.out = d_out; L.out_stride_participant = out_stride_participant; L.out_stride_clerk = out_stride_clerk;
     L.participants = len ? participants : 0; L.len = len; L.first_participant = first_participant;
-    const bool sys = !g->additive && g->sys && g->t > 0;                      // the dual-role launch always draws on the device
+    const bool sys = effective_sys(g);                                        // the dual-role launch always draws on the device
     L.direct_rows = sys ? g->t : 0;
     if (L.participants) SDA_TRY(check_streams(first_participant, participants));
+    // the clerk sums this call adds may still be running on another stream when the caller next touches the combiner
+    // (update_dev / finish_dev on a stream of its own): the combiner carries the event they wait for
+    SDA_TRY(c->join_pending(s));
     DrbgKey key = g->drbg.call_key();
     bool fused = false;
     hipError_t he = hipSuccess;
+    g_last_gen_kernel[0] = 0;
     if (g->additive) {
         he = launch_fused_additive(L, g->n, g->mod, key, g->drbg.rounds, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(),
                                    d_prev, prev_participants, c->jobs, c->dimension, s, &fused);
-    } else if (g->n31 && g->drbg.rounds == 20) {
-        he = launch_fused_packed_n31(L, g->n, g->k, g->t, g->mod, g->n31p, sys ? *g->matarg_n31_sys : *g->matarg_n31, key,
-                                     c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs, c->dimension,
-                                     s, &fused);
-    } else if (g->ngemm && g->drbg.rounds == 20) {
-        he = launch_fused_packed_ngemm(L, g->mod, key, sys ? g->gplan_sys : g->gplan, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev,
-                                       prev_participants, c->jobs, c->dimension, s, &fused);
-    } else if (g->l31) {
-        he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds,
-                                     c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
-                                     c->dimension, s, &fused);
-    } else if (g->mfma) {
-        he = launch_fused_packed_mfma(L, g->n, g->k, g->t, g->mod, g->mont, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key, g->drbg.rounds,
-                                      c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
-                                      c->dimension, s, &fused);
+    } else switch (fused_for_call(g->path, g->drbg.rounds)) {
+        case FAM_N31:
+            he = launch_fused_packed_n31(L, g->n, g->k, g->t, g->mod, g->n31p, sys ? *g->matarg_n31_sys : *g->matarg_n31, key,
+                                         c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs, c->dimension,
+                                         s, &fused);
+            break;
+        case FAM_NGEMM:
+            he = launch_fused_packed_ngemm(L, g->mod, key, sys ? g->gplan_sys : g->gplan, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev,
+                                           prev_participants, c->jobs, c->dimension, s, &fused);
+            break;
+        case FAM_L31:
+            he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds,
+                                         c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
+                                         c->dimension, s, &fused);
+            break;
+        case FAM_MFMA:
+            he = launch_fused_packed_mfma(L, g->n, g->k, g->t, g->mod, g->mont, (sys ? g->d_Msys : g->d_M).as<uint64_t>(), key, g->drbg.rounds,
+                                          c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,
+                                          c->dimension, s, &fused);
+            break;
+        default: break;                                                       // no dual-role kernel for this family
     }
     int st = SDA_OK;
     if (he != hipSuccess) st = fail(SDA_ERR_HIP, "dual-role launch failed: %s", hipGetErrorString(he));
@@ -1324,7 +1415,9 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     // (the narrow limb GEMM fills every SIMD's registers with its own nine waves per CU: a clerk sum on a side stream found no
     // room beside it - 18.9 ms per 500-participant tile of PSS_155_728_100 against 16.9 for the two launches back to back)
     const bool gemm_form = g->fft && g->ngemm && g->drbg.rounds == 20;
-    if (st == SDA_OK && !fused && both && g->fft && !gemm_form && !knob(KNOB_NO_SIDE_STREAM)) {
+    bool side = false;
+    if (st == SDA_OK && !fused && both && g->fft && !gemm_form && !g->knob_no_side_stream) {
+        side = true;
         st = g->side_stream();
         if (st == SDA_OK) {
             hipError_t e = hipEventRecord(g->ev_fork, s);
@@ -1337,7 +1430,7 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
         if (st == SDA_OK) {
             // one clerk-sum workgroup per CU (4 waves, 72 registers: what two transform workgroups leave free on every SIMD),
             // walking the job in grid strides
-            const long ww = knob(KNOB_SIDE_STREAM_WGS);                            // A/B only
+            const long ww = g->knob_side_wgs;                            // A/B only
             const unsigned walk = ww > 0 ? (unsigned)ww : 256u;
             hipError_t e = launch_combine_update(c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, c->jobs, out_stride_clerk,
                                                  prev_participants, out_stride_participant, c->dimension, g->aux, 0, walk);
@@ -1358,6 +1451,12 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
                                      d_out, out_stride_participant, out_stride_clerk, stream);
     }
     explicit_bzero(&key, sizeof key);
+    // every path above leaves clerk-sum work for `c` in flight on `s` (after the join): whoever next uses the combiner on ANOTHER
+    // stream waits for this point (sda_share_combiner::join_pending)
+    if (st == SDA_OK && prev_participants > 0) st = c->mark_pending(s);
+    if (fused) snprintf(g_last_call_kernels, sizeof g_last_call_kernels, "%s", g_last_gen_kernel);
+    else snprintf(g_last_call_kernels, sizeof g_last_call_kernels, "%s%s%s", g_last_gen_kernel, g_last_gen_kernel[0] && prev_participants ? " + " : "",
+                  prev_participants ? (side ? "combine_update_walk_kernel (side stream)" : "combine_update_kernel (two launches)") : "");
     return st;
 }
 
@@ -1374,7 +1473,9 @@ extern "C" int sda_share_combiner_finish_dev(sda_share_combiner_t* c, int64_t* d
     if (c->jobs * c->dimension == 0) return SDA_OK;
     if (!d_out) return fail(SDA_ERR_INVALID_ARGUMENT, "d_out is NULL");
     SDA_TRY(c->ctx.use());
-    return acc_finish(c->acc, c->jobs * c->dimension, c->mod, d_out, c->ctx.pick(stream));
+    SDA_TRY(c->join_pending(c->ctx.pick(stream)));
+    SDA_TRY(acc_finish(c->acc, c->jobs * c->dimension, c->mod, d_out, c->ctx.pick(stream)));
+    return c->mark_pending(c->ctx.pick(stream));
 }
 
 extern "C" int sda_share_combiner_begin(sda_share_combiner_t* c, size_t dimension) {
@@ -1429,6 +1530,7 @@ struct sda_secret_reconstructor {
     std::vector<size_t> cached_indices;
     bool have_R = false;
     bool narrow = false;                 // p < 2^31: the one-limb reveal kernel (d_R31) when the shape and layout allow
+    bool no_narrow = false;              // knob SDA_NO_NARROW when the handle was created (a live handle never switches kernels)
     N31Params n31p{};
 };
 
@@ -1459,6 +1561,7 @@ extern "C" int sda_secret_reconstructor_new(const sda_sharing_scheme_t* scheme, 
         }
     }
     if (st == SDA_OK) st = r->ctx.init();
+    r->no_narrow = knob(KNOB_NO_NARROW) != 0;
     if (st != SDA_OK) { sda_secret_reconstructor_free(r); return st; }
     *out = r;
     return SDA_OK;
@@ -1497,10 +1600,12 @@ static int prepare_R(sda_secret_reconstructor* r, const size_t* indices, size_t 
         return fail(SDA_ERR_INVALID_ARGUMENT, "clerk indices map to colliding evaluation points (duplicate index?)");
     std::vector<uint64_t> R;
     if (!h_lagrange_matrix_mont(nodes, evals, 0, p, R)) return fail(SDA_ERR_INVALID_ARGUMENT, "reconstruction matrix is singular");
-    SDA_TRY(r->d_R.reserve(R.size() * 8));
-    HIP_TRY(hipMemcpyAsync(r->d_R.p, R.data(), R.size() * 8, hipMemcpyHostToDevice, s));
+    // every host-side step that can fail, and both reservations, come BEFORE the first asynchronous copy: R and R31 are
+    // local vectors and must outlive the copies (which are synchronised below, on the only path that enqueues them)
+    r->have_R = false;
     std::vector<int32_t> R31;
-    r->narrow = p < (1ull << 31) && !knob(KNOB_NO_NARROW);
+    r->narrow = p < (1ull << 31) && !r->no_narrow;
+    SDA_TRY(r->d_R.reserve(R.size() * 8));
     if (r->narrow) {                                // the same matrix as centred int32 constants with R = 2^32
         uint64_t inv, inv32;
         if (!h_invmod(p, 1ull << 32, inv) || !h_invmod((1ull << 32) % p, p, inv32)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not odd");
@@ -1511,9 +1616,12 @@ static int prepare_R(sda_secret_reconstructor* r, const size_t* indices, size_t 
             R31[i] = mr > (p - 1) / 2 ? (int32_t)((int64_t)mr - (int64_t)p) : (int32_t)mr;
         }
         SDA_TRY(r->d_R31.reserve(R31.size() * 4 + 16));
-        HIP_TRY(hipMemcpyAsync(r->d_R31.p, R31.data(), R31.size() * 4, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(hipStreamSynchronize(s));               // R, R31 are stack vectors
+    hipError_t ce = hipMemcpyAsync(r->d_R.p, R.data(), R.size() * 8, hipMemcpyHostToDevice, s);
+    if (ce == hipSuccess && r->narrow) ce = hipMemcpyAsync(r->d_R31.p, R31.data(), R31.size() * 4, hipMemcpyHostToDevice, s);
+    const hipError_t se = hipStreamSynchronize(s);  // always: R, R31 are local vectors
+    if (ce != hipSuccess || se != hipSuccess)
+        return fail(SDA_ERR_HIP, "uploading the reconstruction matrix failed: %s", hipGetErrorString(ce != hipSuccess ? ce : se));
     r->cached_indices.assign(indices, indices + n_rows);
     r->have_R = true;
     return SDA_OK;
@@ -2134,10 +2242,11 @@ extern "C" int sda_share_combiner_update_varint_dev(sda_share_combiner_t* c, sda
     if (varint_use_stream(rows)) {
         // many rows: 16 rows of a job per workgroup, decoded values summed in an LDS column window - no decoded tile
         const RowRanges rr{d_row_offsets, nullptr, 0};
+        SDA_TRY(c->join_pending(c->ctx.pick(stream)));
         HIP_TRY(launch_varint_stream_combine(d_bytes, n_bytes, rr, c->jobs, rows_per_job, L, c->acc.lo.as<uint64_t>(),
                                              c->acc.hi.as<int64_t>(), d_status, c->ctx.pick(stream)));
         if (L == 0) HIP_TRY(launch_varint_stream_decode(d_bytes, n_bytes, rr, rows, 0, 0, nullptr, d_status, c->ctx.pick(stream)));
-        return SDA_OK;
+        return c->mark_pending(c->ctx.pick(stream));
     }
     SDA_TRY(c->tile.reserve((rows * stride ? rows * stride : 1) * 8));
     SDA_TRY(sda_varint_decode_dev(codec, d_bytes, n_bytes, d_row_offsets, rows, L, c->tile.as<int64_t>(), stride, d_status, stream));
@@ -2194,10 +2303,11 @@ extern "C" int sda_share_combiner_update_varint_rows_dev(sda_share_combiner_t* c
     SDA_TRY(c->ctx.use());
     const RowRanges rr{nullptr, d_row_bytes, slot_bytes};
     const size_t L = c->dimension;
+    SDA_TRY(c->join_pending(c->ctx.pick(stream)));
     HIP_TRY(launch_varint_stream_combine(d_bytes, rows * slot_bytes, rr, c->jobs, rows / c->jobs, L, c->acc.lo.as<uint64_t>(),
                                          c->acc.hi.as<int64_t>(), d_status, c->ctx.pick(stream)));
     if (L == 0) HIP_TRY(launch_varint_stream_decode(d_bytes, rows * slot_bytes, rr, rows, 0, 0, nullptr, d_status, c->ctx.pick(stream)));
-    return SDA_OK;
+    return c->mark_pending(c->ctx.pick(stream));
 }
 
 extern "C" int sda_share_combiner_update_varint(sda_share_combiner_t* c, sda_varint_codec_t* codec, const uint8_t* bytes,

@@ -21,6 +21,7 @@
 #include "clerk_sum.hpp"
 #include "kernels.hpp"
 #include "modarith.hpp"
+#include "signed_rem.hpp"
 
 namespace sda {
 
@@ -184,6 +185,38 @@ template <int ROUNDS, bool VEC>
 __global__ __launch_bounds__(kThreads) void additive_gen_kernel(GenLayout L, uint32_t n, ModParams mod,
                                                                 DrbgKey key, uint64_t chunks) {
     additive_gen_body<ROUNDS, VEC>(L, n, mod, key, chunks, blockIdx.x);
+}
+
+// The reference's own representatives (SDA_VALUES_RUST_SIGNED) with the library's randomness: the SAME draws as the kernel above
+// (same streams, same indexing), the secret taken as the raw i64 and the last share folded with Rust's truncated `%`
+// (additive.rs:42-47) - canonical == signed modulo q, and the draws need no scratch buffer.
+template <int ROUNDS>
+__global__ __launch_bounds__(kThreads) void signed_additive_gen_drbg_kernel(GenLayout L, uint32_t n, ModParams mod, DrbgKey key,
+                                                                            uint64_t chunks) {
+    uint64_t p, chunk;
+    split_item(blockIdx.x, chunks, p, chunk);
+    const uint64_t pair = chunk * kThreads + threadIdx.x;
+    const uint64_t b0 = 2 * pair;
+    const bool in0 = b0 < L.len, in1 = b0 + 1 < L.len;
+    const int64_t* sp = L.secrets + p * L.secrets_stride;
+    const int64_t q = (int64_t)mod.m;
+    int64_t a0 = in0 ? sp[b0] : 0, a1 = in1 ? sp[b0 + 1] : 0;
+    int64_t* op = L.out + p * L.out_stride_participant + b0;
+    const uint32_t T = n - 1;
+    const uint64_t stream = L.first_participant + p;
+    const QuadCol qc = quad_col(key);
+    for (uint32_t i = 0; i < T; ++i) {
+        uint64_t r0 = 0, r1 = 0;
+        drbg_pair<ROUNDS>(key, qc, stream, pair, T, i, mod, r0, r1);       // all four lanes of a quad take part
+        a0 = trunc_rem128((__int128)a0 - (int64_t)r0, q);
+        a1 = trunc_rem128((__int128)a1 - (int64_t)r1, q);
+        int64_t* o = op + (size_t)i * L.out_stride_clerk;
+        if (in0) o[0] = (int64_t)r0;
+        if (in1) o[1] = (int64_t)r1;
+    }
+    int64_t* o = op + (size_t)T * L.out_stride_clerk;
+    if (in0) o[0] = a0;
+    if (in1) o[1] = a1;
 }
 
 // =================================================================================================
@@ -1526,11 +1559,31 @@ static hipError_t additive_launch_r(const GenLayout& L, uint32_t n, const ModPar
     const uint64_t per = participants_per_launch(chunks, L.participants);
     if (per == 0) return hipErrorInvalidConfiguration;
     const bool vec = gen_vec_ok(L, 0);
+    note_kernel("additive_gen_kernel<%d, %s>", ROUNDS, vec ? "true" : "false");
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
         const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
         const unsigned blocks = (unsigned)(chunks * S.participants);
         if (vec) additive_gen_kernel<ROUNDS, true><<<dim3(blocks), dim3(kThreads), 0, s>>>(S, n, mod, key, chunks);
         else additive_gen_kernel<ROUNDS, false><<<dim3(blocks), dim3(kThreads), 0, s>>>(S, n, mod, key, chunks);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_additive_generate_signed_drbg(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,
+                                                hipStream_t s) {
+    if (L.rand || n < 2 || (rounds != 20 && rounds != 12 && rounds != 8)) return hipErrorInvalidValue;
+    const uint64_t chunks = ceil_div(ceil_div(L.len, 2), kThreads);
+    if (chunks * L.participants == 0) return hipSuccess;
+    const uint64_t per = participants_per_launch(chunks, L.participants);
+    if (per == 0) return hipErrorInvalidConfiguration;
+    note_kernel("signed_additive_gen_drbg_kernel<%d>", rounds);
+    for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
+        const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        const dim3 grid((unsigned)(chunks * S.participants)), block(kThreads);
+        if (rounds == 20) signed_additive_gen_drbg_kernel<20><<<grid, block, 0, s>>>(S, n, mod, key, chunks);
+        else if (rounds == 12) signed_additive_gen_drbg_kernel<12><<<grid, block, 0, s>>>(S, n, mod, key, chunks);
+        else signed_additive_gen_drbg_kernel<8><<<grid, block, 0, s>>>(S, n, mod, key, chunks);
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
@@ -1567,6 +1620,7 @@ static hipError_t packed_launch_kt(const GenLayout& L, uint32_t n, const ModPara
     const uint64_t per = participants_per_launch(chunks, L.participants);
     if (per == 0) return hipErrorInvalidConfiguration;
     const bool vec = gen_vec_ok(L, 0);
+    note_kernel("packed_gen_kernel<%d, %d, %d, %s>", K, T, ROUNDS, vec ? "true" : "false");
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
         const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
         const unsigned blocks = (unsigned)(chunks * S.participants);
@@ -1632,6 +1686,7 @@ static hipError_t packed_l31_launch_kt(const GenLayout& L, uint32_t n, const Mod
     const uint64_t per = participants_per_launch(chunks, L.participants);
     if (per == 0) return hipErrorInvalidConfiguration;
     const bool vec = gen_vec_ok(L, 0);
+    note_kernel("packed_gen_l31_kernel<%d, %d, %d, %s>", K, T, ROUNDS, vec ? "true" : "false");
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
         const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
         const unsigned blocks = (unsigned)(chunks * S.participants);
@@ -1653,6 +1708,7 @@ static hipError_t packed_l31_launch_rt(const GenLayout& L, uint32_t n, uint32_t 
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
         const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
         const bool vec = aligned16(S.out) && S.out_stride_participant % 2 == 0 && S.out_stride_clerk % 2 == 0;
+        note_kernel("packed_gen_l31_rt_kernel<%d, %d>", KTMAX, ROUNDS);
         packed_gen_l31_rt_kernel<KTMAX, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(
             S, n, k, t, mod, lp, M, key, chunks, batches, vec);
         if (hipError_t e = hipGetLastError()) return e;
@@ -1696,6 +1752,7 @@ static hipError_t packed_l31_launch_rtg(const GenLayout& L, uint32_t n, uint32_t
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
         const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
         const bool vec = aligned16(S.out) && S.out_stride_participant % 2 == 0 && S.out_stride_clerk % 2 == 0;
+        note_kernel("packed_gen_l31_rtg_kernel<%d, %d>", KTMAX, ROUNDS);
         packed_gen_l31_rtg_kernel<KTMAX, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(
             S, n, k, t, mod, lp, d_M, key, chunks, batches, vec);
         if (hipError_t e = hipGetLastError()) return e;
@@ -1754,6 +1811,7 @@ static hipError_t packed_mfma_launch_kt(const GenLayout& L, uint32_t n, uint32_t
             if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&packed_gen_mfma_kernel<K, T, ROUNDS>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_table_bytes<K, T>(n)))
                 return e;
+        note_kernel("packed_gen_mfma_kernel<%d, %d, %d>", K, T, ROUNDS);
         packed_gen_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), mfma_table_bytes<K, T>(n), s>>>(
             S, n, mod, mont, d_Mbal, key, chunks, batches, kMfmaIters, k, t);
         if (hipError_t e = hipGetLastError()) return e;
@@ -1791,6 +1849,7 @@ hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32
     if (per == 0) return hipErrorInvalidConfiguration;
     for (uint64_t p0 = 0; p0 < L.participants; p0 += per) {
         const GenLayout S = slice(L, p0, per < L.participants - p0 ? per : L.participants - p0);
+        note_kernel("packed_gen_generic_kernel");
         packed_gen_generic_kernel<<<dim3((unsigned)(chunks * S.participants)), dim3(kThreads), 0, s>>>(S, n, k, t, mod, mont,
                                                                                                        d_Mmont, chunks, batches);
         if (hipError_t e = hipGetLastError()) return e;
@@ -1903,6 +1962,7 @@ static bool fuse_plan(const GenLayout& L, uint64_t chunks, uint64_t* acc_lo, int
 template <int K, int T, int ROUNDS>
 static hipError_t fused_l31_kt(const GenLayout& L, uint32_t n, const ModParams& mod, const L31Params& lp, const MatArg& M,
                                const DrbgKey& key, const FuseArgs& F, uint64_t chunks, uint64_t batches, hipStream_t s) {
+    note_kernel("fused_packed_l31_kernel<%d, %d, %d>", K, T, ROUNDS);
     fused_packed_l31_kernel<K, T, ROUNDS><<<dim3((unsigned)F.grid), dim3(kThreads), 0, s>>>(L, n, mod, lp, M, key,
                                                                                                        chunks, batches, F);
     return hipGetLastError();
@@ -1937,6 +1997,7 @@ hipError_t launch_fused_packed_l31(const GenLayout& L, uint32_t n, uint32_t k, u
     const dim3 grid((unsigned)F.grid), block(kThreads);
 #define RT(KTMAX_)                                                                                                      \
     do {                                                                                                                 \
+        note_kernel("fused_packed_l31_rt_kernel<%d, %d>", KTMAX_, rounds);                                               \
         if (rounds == 20) fused_packed_l31_rt_kernel<KTMAX_, 20><<<grid, block, 0, s>>>(L, n, k, t, mod, lp, M, key, chunks, batches, F); \
         else if (rounds == 12) fused_packed_l31_rt_kernel<KTMAX_, 12><<<grid, block, 0, s>>>(L, n, k, t, mod, lp, M, key, chunks, batches, F); \
         else fused_packed_l31_rt_kernel<KTMAX_, 8><<<grid, block, 0, s>>>(L, n, k, t, mod, lp, M, key, chunks, batches, F); \
@@ -1956,6 +2017,7 @@ static hipError_t fused_mfma_kt(const GenLayout& L, uint32_t n, uint32_t k, uint
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_packed_mfma_kernel<K, T, ROUNDS>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_table_bytes<K, T>(n)))
             return e;
+    note_kernel("fused_packed_mfma_kernel<%d, %d, %d>", K, T, ROUNDS);
     fused_packed_mfma_kernel<K, T, ROUNDS><<<dim3((unsigned)F.grid), dim3(kThreads), mfma_table_bytes<K, T>(n), s>>>(L, n, mod, mont, d_Mbal, key, chunks, batches,
                                                                                               kMfmaFusedIters, k, t, F);
     return hipGetLastError();
@@ -1996,6 +2058,7 @@ bool packed_n31_path_available(uint32_t k, uint32_t t, uint32_t rows, uint64_t p
         const uint32_t kt_ = k + t;                                                                                      \
         const bool g16_ = np.p < (1u << 29);        /* GROUP * p < 2^33: 16 terms per reduction below 2^29, else 4 */    \
         const dim3 grid_((unsigned)(GRID)), block_(kThreads);                                                            \
+        note_kernel(#KERNEL "<%u, %d, 20>", kt_ <= 4 ? 4u : kt_ <= 8 ? 8u : kt_ <= 12 ? 12u : 16u, kt_ <= 4 ? 4 : g16_ ? 16 : 4); \
         if (kt_ <= 4) KERNEL<4, 4, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__);                                            \
         else if (kt_ <= 8) { if (g16_) KERNEL<8, 16, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); else KERNEL<8, 4, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); }   \
         else if (kt_ <= 12) { if (g16_) KERNEL<12, 16, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); else KERNEL<12, 4, 20><<<grid_, block_, 0, s>>>(__VA_ARGS__); } \
@@ -2043,6 +2106,7 @@ hipError_t launch_fused_additive(const GenLayout& L, uint32_t n, const ModParams
     if (!fuse_plan(L, chunks, acc_lo, acc_hi, d_prev, prev_rows, jobs, dimension, F)) return hipSuccess;
     *fused = true;
     const dim3 grid((unsigned)F.grid), block(kThreads);
+    note_kernel("fused_additive_kernel<%d>", rounds);
     if (rounds == 20) fused_additive_kernel<20><<<grid, block, 0, s>>>(L, n, mod, key, chunks, F);
     else if (rounds == 12) fused_additive_kernel<12><<<grid, block, 0, s>>>(L, n, mod, key, chunks, F);
     else fused_additive_kernel<8><<<grid, block, 0, s>>>(L, n, mod, key, chunks, F);

@@ -15,18 +15,11 @@
 #include <stdint.h>
 
 #include "kernels.hpp"
+#include "signed_rem.hpp"
 
 namespace sda {
 
 static constexpr int kSignedThreads = 256;
-
-// Rust's `x % q` for q > 0 and x = a + b (or a - b) formed exactly
-__device__ __forceinline__ int64_t trunc_rem128(__int128 x, int64_t q) {
-    if (x > -(__int128)q && x < (__int128)q) return (int64_t)x;                 // the common cases first: |x| < 2q
-    if (x >= q && x < 2 * (__int128)q) return (int64_t)(x - q);
-    if (x <= -(__int128)q && x > -2 * (__int128)q) return (int64_t)(x + q);
-    return (int64_t)(x % q);                                                     // C's % truncates like Rust's
-}
 
 // additive.rs:42-47 for element i of participant p: out[j][i] = rand[i (n-1) + j] (untouched), out[n-1][i] = the fold
 __global__ __launch_bounds__(kSignedThreads) void signed_additive_gen_kernel(GenLayout L, uint32_t n, int64_t q) {
@@ -67,17 +60,23 @@ __global__ __launch_bounds__(kSignedThreads) void signed_addsub_kernel(const int
 
 static inline uint64_t sdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
-hipError_t launch_additive_generate_signed(const GenLayout& L, uint32_t n, int64_t q, hipStream_t s) {
+hipError_t launch_additive_generate_signed(const GenLayout& L, uint32_t n, const ModParams& mod, const DrbgKey& key, int rounds,
+                                           hipStream_t s) {
     if (L.participants == 0 || L.len == 0) return hipSuccess;
-    if (!L.rand || n < 1) return hipErrorInvalidValue;
+    if (n < 1) return hipErrorInvalidValue;
+    // no injected draws: the kernel draws them itself, from the streams the canonical kernel would use (sda_kernels.hip) - no
+    // participants x len x (n - 1) scratch
+    if (!L.rand && n > 1) return launch_additive_generate_signed_drbg(L, n, mod, key, rounds, s);
+    const int64_t q = (int64_t)mod.m;
     const uint64_t blocks = sdiv(L.len, kSignedThreads);
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
     for (size_t p0 = 0; p0 < L.participants; p0 += 65535) {
         GenLayout S = L;
         S.secrets = L.secrets + p0 * L.secrets_stride;
-        S.rand = L.rand + p0 * L.rand_stride;
+        if (L.rand) S.rand = L.rand + p0 * L.rand_stride;
         S.out = L.out + p0 * L.out_stride_participant;
         S.participants = L.participants - p0 < 65535 ? L.participants - p0 : 65535;
+        note_kernel("signed_additive_gen_kernel");
         signed_additive_gen_kernel<<<dim3((unsigned)blocks, (unsigned)S.participants), dim3(kSignedThreads), 0, s>>>(S, n, q);
         if (hipError_t e = hipGetLastError()) return e;
     }

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(built):
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
     exported = set(re.findall(r" T (sda_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.sda_abi_version() == 4 and b"gfx950" in lib.sda_version()
+    assert lib.sda_abi_version() == 5 and b"gfx950" in lib.sda_version()
 
 
 def test_release_library_reads_no_environment_variable(built):

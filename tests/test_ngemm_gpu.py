@@ -14,6 +14,11 @@ KEY = bytes((i * 11 + 3) & 0xFF for i in range(32))
 TSS_P1, TSS_P2 = 746497, 5038849
 
 
+def capi_last_kernel():
+    from sda_amd import capi
+    return capi.load().sda_debug_last_kernel().decode()
+
+
 def _root(p, order):
     assert (p - 1) % order == 0
     for g in range(2, 2000):
@@ -150,8 +155,9 @@ def test_narrow_limb_gemm_share_combine_reveal_roundtrip(gpu):
 
 
 def test_narrow_limb_gemm_fallbacks_keep_the_shares(gpu):
-    """what surrounds the kernel: (1) another ChaCha round count (A/B only) has no limb-GEMM instance - the transform kernel (tss's
-    nodes) or the any-shape kernel (systematic map) serve the handle, same draw -> share maps; (2) a clerk-major layout with an odd
+    """what surrounds the kernel: (1) another ChaCha round count (A/B only) has no limb-GEMM instance - on this tss-valid shape the
+    transform kernel serves those calls, which is tss's map whatever was requested, and csprng_share_map() SAYS so (round 4
+    silently sent the systematic request to the any-shape kernel with every draw of the tile materialised); (2) a clerk-major layout with an odd
     row stride rules the dual-role launch out (its clerk role reads with 16-byte loads) - the two ordinary launches give the sums"""
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
@@ -168,14 +174,21 @@ def test_narrow_limb_gemm_fallbacks_keep_the_shares(gpu):
     gen.set_drbg_rounds(12)
     B = gen.batch_count(dim)
     Bs = (B + 15) // 16 * 16
-    for share_map in (gen.SHARE_MAP_SYSTEMATIC, gen.SHARE_MAP_TSS_NODES):
-        gen.set_csprng_share_map(share_map)
+    assert gen.path_name() == "fft+ngemm"
+    for asked in (gen.SHARE_MAP_SYSTEMATIC, gen.SHARE_MAP_TSS_NODES):
+        gen.set_csprng_share_map(asked)
+        share_map = gen.csprng_share_map()
+        assert share_map == gen.SHARE_MAP_TSS_NODES                     # the map the NEXT call uses, not the one asked for
         d_out = DeviceBuffer(P * n * Bs).zero()
         gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=first)
         o = d_out.to_numpy().reshape(P, n, Bs)
         for q in range(P):
             draws = coracle.drbg_fill(KEY, first + q, B, t, p, rounds=12)
             assert np.array_equal(o[q, :, :B], coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[q], draws, share_map)), (share_map, q)
+        assert capi_last_kernel().startswith("packed_gen_fft_kernel<12, ")
+    gen.set_drbg_rounds(20)                                             # back under ChaCha20 the systematic request holds again
+    gen.set_csprng_share_map(gen.SHARE_MAP_SYSTEMATIC)
+    assert gen.csprng_share_map() == gen.SHARE_MAP_SYSTEMATIC
     # (2) odd clerk-major strides through generate_combine_dev
     gen = crypto.ShareGenerator(sch)
     gen.set_drbg_key(KEY)

@@ -1100,7 +1100,26 @@ def test_any_i64_canonicalisation_property(gpu):
         assert np.array_equal(got, coracle.packed_generate(p, 3, 1, 8, w2, 3, edge[:6], rnd))
 
 
-def test_bench_under_torchrun_single_rank_rccl(gpu):
+def _run_bench(cmd, tmp_path, env=None, timeout=900, root=None):
+    """run bench.py (any launcher form): stdout must be exactly ONE compact JSON line of at most 4096 bytes (the driver parses
+    it; BENCH_r04 came back unparsed at 35 KB); the full record is read back from the --details file"""
+    import json
+    import subprocess
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    details = os.path.join(str(tmp_path), "bench_details.json")
+    out = subprocess.run(cmd + ["--details", details], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must be the ONE JSON line (banners of gloo / RCCL belong on stderr)"
+    assert len(lines[0].encode()) <= 4096, len(lines[0])
+    line = json.loads(lines[0])
+    full = json.load(open(details))
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["details"] == "bench_details.json"
+    assert line["build_id"] == full["build_id"] and len(line["build_id"]) == 16
+    return line, full, out
+
+
+def test_bench_under_torchrun_single_rank_rccl(gpu, tmp_path):
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run), with one rank and the exchange
     forced through RCCL (the library's own communicator: ncclCommInitRank, grouped ncclSend/ncclRecv to itself, the
     modular-sum kernel, the gather).  The result must verify (reconstruct == sum of secrets)."""
@@ -1112,13 +1131,11 @@ def test_bench_under_torchrun_single_rank_rccl(gpu):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
            "--warmup", "1", "--participants", "128", "--dim", "65536", "--no-cpu-baseline", "--no-additional"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, "stdout must be the ONE JSON line (banners of gloo / RCCL belong on stderr)"
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["verified_reconstruct_equals_sum"] is True
+    line, d, _ = _run_bench(cmd, tmp_path, env=env, timeout=600)
+    assert d["n_gpus"] == 1 and d["verified_reconstruct_equals_sum"] is True and line["verified_reconstruct_equals_sum"] is True
     assert d["roofline"]["bound"] in ("hbm", "valu") and d["value"] > 0
+    # the kernel name is what the LIBRARY reports it launched (sda_debug_last_kernel), as rocprofv3 prints it
+    assert line["roofline"]["kernel"] == "fused_packed_l31_kernel<3, 1, 20>" and line["config"]["library_path"] == "l31"
     # the machine-readable record of what carried the exchange: the library's communicator spans the one rank
     assert d["rccl"]["ranks"] == 1 and d["rccl"]["unique_devices"] == 1 and d["rccl"]["path"].startswith("send/recv")
     assert d["rccl"]["comm_device"] == 0
@@ -1427,7 +1444,7 @@ def test_device_entry_points_refuse_bad_arguments(gpu):
     assert gen.generate(secrets).shape == (8, 4)
 
 
-def test_bench_two_ranks_rccl_refusal_falls_back_loudly(gpu):
+def test_bench_two_ranks_rccl_refusal_falls_back_loudly(gpu, tmp_path):
     """two ranks on ONE device with the library's RCCL communicator attempted: the 128-byte id travels over gloo, both
     ranks reach ncclCommInitRank, RCCL refuses the duplicate device ("invalid usage"), every rank takes the labelled
     host-staged exchange together, and the cross-rank result still verifies.  (On a node with one GPU per rank the same
@@ -1440,12 +1457,9 @@ def test_bench_two_ranks_rccl_refusal_falls_back_loudly(gpu):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--participants", "120", "--dim", "65536", "--no-additional", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must be the ONE JSON line"
-    line = json.loads(lines[0])
+    compact, line, out = _run_bench(cmd, tmp_path, env=env, timeout=600)
     assert line["n_gpus"] == 2 and line["verified_reconstruct_equals_sum"] is True
+    assert compact["n_gpus"] == 2 and compact["rccl"]["unique_devices"] == 1 and "exchange_ms" in compact
     assert "RCCL" in line["config"]["exchange"]
     if "unavailable" in line["config"]["exchange"]:
         assert "sda_comm_init failed" in out.stderr
@@ -1473,7 +1487,7 @@ def test_bench_refused_communicator_is_fatal_without_the_rehearsal_switch(gpu):
 
 @pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--schedule", "serial", "--workload", "additive"]),
                                          (2, ["--workload", "packed26"])])          # config 4's shape (k=8, t=2, n=26)
-def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
+def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra, tmp_path):
     """bench.py's N > 1 path end to end - participant sharding, per-rank CSPRNG streams, the all-to-all / modular
     sum / all-gather exchange, max-over-ranks timing, and the cross-rank verification reconstruct(sum of every rank's
     clerk sums) == sum of every rank's secrets - with the ranks sharing this box's one GPU and gloo carrying the
@@ -1486,17 +1500,16 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(gpu, ranks, extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "3",
            "--warmup", "1", "--participants", "120", "--dim", "65536", "--no-additional", "--no-cpu-baseline"] + extra
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    compact, line, _ = _run_bench(cmd, tmp_path, env=env, timeout=600)
     assert line["n_gpus"] == ranks and line["verified_reconstruct_equals_sum"] is True
+    assert compact["config"]["participants_total"] == ranks * 3 * 40 and compact["scaling"] == "weak"
     assert line["config"]["participants_total"] == ranks * 3 * 40 and line["scaling"] == "weak"
     assert f"{ranks * 120} participants" in line["config"]["workload"]                 # the label is what was processed
     assert line["rccl"] == dict(line["rccl"], ranks=0, unique_devices=1) and "host-staged" in line["rccl"]["path"]
     assert line["exchange_bytes_per_gpu"] == 8 * line["config"]["share_count"] * -(-65536 // line["config"]["secret_count"])
 
 
-def test_bench_multi_gpu_legs_configs_4_and_5(gpu):
+def test_bench_multi_gpu_legs_configs_4_and_5(gpu, tmp_path):
     """`bench.py --gpus N` (N > 1) as the driver launches it: after the config-3 line, BASELINE config 4 (packed Shamir
     t=2 k=8 n=26) and config 5 (k=3 t=1 n=8 + Lagrange reveal) run with the job's participants sharded over the ranks,
     each leg's clerk sums meeting in one modular reduce, each leg verified against the secrets of ALL ranks.  Rehearsed on
@@ -1509,14 +1522,12 @@ def test_bench_multi_gpu_legs_configs_4_and_5(gpu):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--participants", "120", "--dim", "65536", "--no-cpu-baseline", "--leg-participants", "400", "--leg-dim", "98304"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
+    compact, line, _ = _run_bench(cmd, tmp_path, env=env, timeout=900)
     assert line["verified_reconstruct_equals_sum"] is True and line["scaling"] == "weak"
     legs = line["additional_workloads"]
-    assert set(legs) == {"config4_packed26", "config5_packed_dim16m"}
+    assert set(legs) == {"config4_packed26", "config5_packed_dim16m"} == set(compact["additional_workloads"])
+    assert all(v["verified"] is True and v["value"] > 0 for v in compact["additional_workloads"].values())
+    assert compact["additional_workloads"]["config5_packed_dim16m"]["reveal_ms"] > 0
     c4, c5 = legs["config4_packed26"], legs["config5_packed_dim16m"]
     for leg, (k, t, n) in ((c4, (8, 2, 26)), (c5, (3, 1, 8))):
         cfg = leg["config"]
@@ -1528,7 +1539,7 @@ def test_bench_multi_gpu_legs_configs_4_and_5(gpu):
     assert c5["reveal"]["dim"] == 98304 and c5["reveal"]["ms"] > 0
 
 
-def test_bench_launches_its_own_ranks(gpu):
+def test_bench_launches_its_own_ranks(gpu, tmp_path):
     """`python bench.py --gpus 2` with NO launcher around it (the form the driver used for its N = 1 record): the script
     starts its two ranks itself, stdout is exactly ONE JSON line with n_gpus 2, the `rccl` record, a `roofline` and a
     non-null `cpu_baseline` (rank 0's host cores, at any world size); the two multi-GPU legs are attached.  Ranks share
@@ -1541,12 +1552,8 @@ def test_bench_launches_its_own_ranks(gpu):
     args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--participants", "120", "--dim", "65536",
             "--leg-participants", "400", "--leg-dim", "98304"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SDA_SHARE_GPU")}
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=900,
-                         env=dict(env, SDA_SHARE_GPU="1"), cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must be the ONE JSON line"
-    line = json.loads(lines[0])
+    compact, line, _ = _run_bench([sys.executable, os.path.join(root, "bench.py")] + args, tmp_path, env=dict(env, SDA_SHARE_GPU="1"))
+    assert compact["n_gpus"] == 2 and compact["cpu_baseline"]["value"] > 0 and compact["roofline"]["frac"] > 0
     assert line["n_gpus"] == 2 and line["verified_reconstruct_equals_sum"] is True and line["scaling"] == "weak"
     assert "WEAK" in line["scaling_note"] and "STRONG" in line["scaling_note"]
     assert line["rccl"]["unique_devices"] == 1 and line["roofline"]["frac"] > 0
@@ -1561,7 +1568,7 @@ def test_bench_launches_its_own_ranks(gpu):
     assert not [l for l in refused.stdout.splitlines() if l.startswith("{")]
 
 
-def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu):
+def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu, tmp_path):
     """N = 1: BASELINE configs 4 and 5 ride on the default line as `config4_full` / `config5_full` - the whole job on one
     GPU, streamed as resident tiles, verified against the column sums (here shrunk through --leg-participants / --leg-dim;
     the driver's run uses 1,000,000 and 100,000 participants)."""
@@ -1571,15 +1578,23 @@ def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--participants", "64", "--dim", "65536",
            "--no-cpu-baseline", "--leg-participants", "300", "--leg-dim", "98304"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    compact, line, _ = _run_bench(cmd, tmp_path)
     legs = line["additional_workloads"]
-    assert {"config4_full", "config5_full", "additive", "packed_pss728", "narrow_ref", "narrow26_ref", "narrow_pss728"} <= set(legs)
-    assert legs["narrow_ref"]["roofline"]["kernel"] == "fused_packed_n31_kernel" and legs["narrow_ref"]["verified_reconstruct_equals_sum"] is True
+    assert {"config4_full", "config5_full", "additive", "packed_pss728", "narrow_ref", "narrow26_ref", "narrow_pss728", "narrow_pss19682",
+            "packed_tss_nodes"} == set(legs) == set(compact["additional_workloads"])
+    assert all(v["verified"] is True for v in compact["additional_workloads"].values())
+    # the kernel names are the library's own report of what it launched (sda_debug_last_kernel)
+    assert legs["narrow_ref"]["roofline"]["kernel"].startswith("fused_packed_n31_kernel<8, ") and legs["narrow_ref"]["verified_reconstruct_equals_sum"] is True
+    assert legs["narrow_ref"]["config"]["library_path"] == "l31+n31" and legs["config4_full"]["roofline"]["kernel"] == "fused_packed_l31_kernel<8, 2, 20>"
+    assert legs["additive"]["roofline"]["kernel"] == "fused_additive_kernel<20>"
+    assert legs["packed_pss728"]["roofline"]["kernel"].startswith("packed_gen_fft_kernel<20, ") and "side stream" in legs["packed_pss728"]["roofline"]["kernel"]
     assert legs["narrow_pss728"]["config"]["modulus"] == 746497 and legs["narrow_pss728"]["verified_reconstruct_equals_sum"] is True
     # tss's two shipped parameter sets over tss's own primes run the limb GEMM on the matrix cores (dual-role launch)
-    assert legs["narrow_pss728"]["roofline"]["kernel"] == "packed_gen_ngemm_kernel"
+    assert legs["narrow_pss728"]["roofline"]["kernel"] == "packed_gen_ngemm_kernel<4, 2>" and legs["narrow_pss728"]["config"]["library_path"] == "fft+ngemm"
+    # the reference's own share map rides along: the headline is on the library's systematic map, this leg on tss's
+    assert compact["config"]["csprng_share_map"].startswith("systematic (library)")
+    assert legs["packed_tss_nodes"]["config"]["csprng_share_map"].startswith("tss nodes (reference)")
+    assert legs["packed_tss_nodes"]["config"]["share_count"] == 8 and legs["packed_tss_nodes"]["verified_reconstruct_equals_sum"] is True
     assert legs["narrow_pss19682"]["config"]["share_count"] == 19682 and legs["narrow_pss19682"]["verified_reconstruct_equals_sum"] is True
     for key, (k, t, n) in (("config4_full", (8, 2, 26)), ("config5_full", (3, 1, 8))):
         cfg = legs[key]["config"]
@@ -1590,7 +1605,7 @@ def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu):
     assert legs["config5_full"]["reveal"]["dim"] == 98304
 
 
-def test_bench_distinct_inputs_mode(gpu):
+def test_bench_distinct_inputs_mode(gpu, tmp_path):
     """--inputs distinct: every sub-tile shares different participants (tile i+1's secrets generated on a side stream
     while tile i runs); the result is verified against the column sums of ALL of them."""
     import json
@@ -1599,9 +1614,7 @@ def test_bench_distinct_inputs_mode(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--participants", "320", "--tile", "32",
            "--dim", "65536", "--no-cpu-baseline", "--no-additional", "--inputs", "distinct"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    _, line, _ = _run_bench(cmd, tmp_path, timeout=600)
     assert line["verified_reconstruct_equals_sum"] is True
     assert line["config"]["distinct_participants"] == 320 == line["config"]["participants_total"]
     assert "320 distinct participants" in line["verified_against"]

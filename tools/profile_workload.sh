@@ -1,7 +1,7 @@
 # HBM PMC passes + kernel stats for one bench workload: bash tools/profile_workload.sh <name> [bench args...]
 R=${GRAFT_REPO_ROOT:-/root/repo}; N=$1; shift; O=$R/gpurun_out/prof_$N; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-additional "$@" > $O/bench_under_rocprof.json 2>$O/rocprof_stats.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 2 --full-line --no-cpu-baseline --no-verify --no-additional "$@" > $O/bench_under_rocprof.json 2>$O/rocprof_stats.log
 for c in fetch write; do
   timeout 600 rocprofv3 -i $R/tools/pmc_$c.txt --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-additional "$@" > /dev/null 2>$O/rocprof_$c.log
 done
