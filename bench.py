@@ -264,7 +264,8 @@ class Env:
         # A/B runs (tools/*.sh) and the one-rank RCCL test select non-default kernels by environment variable; the release
         # library reads none, so the bench - a measurement tool - hands them to its test-only entry point (sda_hip_debug.h)
         for name in ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
-                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM"):
+                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM",
+                     "SDA_NO_WIDE_GROUP"):
             if os.environ.get(name):
                 v = os.environ[name]
                 capi.check(self.lib.sda_debug_set_knob(name.encode(), int(v) if v.lstrip("-").isdigit() else 1))

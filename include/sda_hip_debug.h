@@ -22,25 +22,34 @@
  *                              workgroups that share a 128-byte line of a clerk row are placed on one XCD)
  *   SDA_NO_NGEMM 1             large shapes over a prime below 2^23 through the transform kernel (default: the limb GEMM on the
  *                              matrix cores, ngemm_kernels.hip)
+ *   SDA_NO_WIDE_GROUP 1        three-digit limb-31 shapes of 9 .. 12 terms (BASELINE config 4's (8,2)): the 7 + rest grouping even where
+ *                              the constants admit the dot product as ONE group (default: one group, one reduction, no normalisation)
  *   SDA_FORCE_COLLECTIVES 1    a one-rank communicator still goes through RCCL send/recv to itself
  * Built with -DSDA_AB_KNOBS (tools/build_ab_variant.sh; never by __graft_entry__.build()) an unset knob falls back to the
  * environment variable of the same name. */
 #ifndef SDA_HIP_DEBUG_H
 #define SDA_HIP_DEBUG_H
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
 int  sda_debug_set_knob(const char* name, long value);   /* SDA_ERR_INVALID_ARGUMENT for an unknown name */
 void sda_debug_reset_knobs(void);
 int  sda_debug_env_knobs_compiled_in(void);              /* 1 only in an SDA_AB_KNOBS build */
-/* What the library RAN: the kernel instance(s) launched by the last sda_share_generator_generate_batch_dev /
- * sda_share_generator_generate_combine_dev call on this thread, named as rocprofv3 prints them ("fused_packed_l31_kernel<3, 1, 20>";
+/* What the library RAN: the kernel instance(s) launched by the last sda_share_generator_generate / _generate_batch_dev /
+ * _generate_combine_dev call on this thread, named as rocprofv3 prints them ("fused_packed_l31_kernel<3, 1, 20>";
  * two launches: "packed_gen_fft_kernel<...> + combine_update_walk_kernel (side stream)").  bench.py prints this as roofline.kernel. */
 const char* sda_debug_last_kernel(void);
 /* The kernel-selection table without a device or a handle (sda_amd/csrc/path_select.hpp: the ONE place the decision is made):
  * `knobs` = comma-separated selection knob names from the list above (NULL or "" = defaults; the process-wide knob state is not
  * read).  Writes "wide=... narrow=... r_bits=... call20=... call12=... injected=... fused20=... fused12=... transform_shape=.
  * eight_term_ok=." (family names: additive n31 ngemm l31 mont64 l31_global fft mfma generic). */
+/* streams and memory figures for the tests, so that they need no second HIP binding in their process (a Python process that
+ * loads this library and then PyTorch ends up with two HIP runtimes): non-blocking streams, hipMemGetInfo */
+int  sda_debug_stream_create(void** stream);
+int  sda_debug_stream_destroy(void* stream);
+int  sda_debug_stream_synchronize(void* stream);
+int  sda_debug_mem_info(size_t* free_bytes, size_t* total_bytes);
 struct sda_sharing_scheme;
 int  sda_debug_select_path(const struct sda_sharing_scheme* scheme, const char* knobs, char* out, size_t cap);
 #ifdef __cplusplus

@@ -76,6 +76,10 @@ SIGNATURES = {
     "sda_debug_reset_knobs": (None, []),
     "sda_debug_env_knobs_compiled_in": (C.c_int, []),
     "sda_debug_last_kernel": (C.c_char_p, []),
+    "sda_debug_stream_create": (C.c_int, [c_voidpp]),
+    "sda_debug_stream_destroy": (C.c_int, [C.c_void_p]),
+    "sda_debug_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "sda_debug_mem_info": (C.c_int, [c_sizep, c_sizep]),
     "sda_debug_select_path": (C.c_int, [_SS, C.c_char_p, C.c_char_p, C.c_size_t]),
     "sda_version": (C.c_char_p, []),
     "sda_build_id": (C.c_char_p, []),

@@ -39,7 +39,8 @@ struct L31Params {
     int32_t  p0;      // p mod 2^31
     int32_t  p1;      // p >> 31
     uint32_t pinvB;   // -p^{-1} mod 2^31
-    uint32_t pad;
+    uint32_t wide;    // 1: the three-digit shapes of 9 .. 12 terms run their dot product as ONE group (admitted by the host on the
+                      // actual constants of both share maps, l31_wide_group_ok); 0 everywhere else
     uint64_t np, np2; // 2^64 - p and 2^64 - 2p: x + np wraps exactly when x >= p (the conditional subtractions)
 };
 

@@ -102,7 +102,7 @@ namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
     "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES",
-    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP", "SDA_NO_NGEMM"};
+    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP", "SDA_NO_NGEMM", "SDA_NO_WIDE_GROUP"};
 std::atomic<long> g_knobs[sda::KNOB_COUNT];
 }  // namespace
 long sda::knob(sda::Knob k) {
@@ -153,6 +153,26 @@ void sda::note_kernel(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sda_debug_last_kernel(void) { return g_last_call_kernels; }
+extern "C" int sda_debug_stream_create(void** stream) {
+    if (!stream) return fail(SDA_ERR_INVALID_ARGUMENT, "stream is NULL");
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return SDA_OK;
+}
+extern "C" int sda_debug_stream_destroy(void* stream) {
+    if (stream) HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    return SDA_OK;
+}
+extern "C" int sda_debug_stream_synchronize(void* stream) {
+    HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    return SDA_OK;
+}
+extern "C" int sda_debug_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(SDA_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return SDA_OK;
+}
 
 // -------------------------------------------------------------------------------------------------
 // device context
@@ -673,6 +693,25 @@ static bool l31_eight_term_group_ok(const std::vector<uint64_t>& Mm, uint32_t kt
     return true;
 }
 
+// The three-digit kernels of 9 .. 12 terms can run a whole dot product as ONE group when no column can leave a signed 64-bit
+// register: |column| <= 2^30 x sum |constant limb| for ANY values (limbs of magnitude <= 2^30), so sum |limb| x 2^30 (+ slack)
+// must stay below 2^63 for the m0 and the m1 limbs of every row.  Checked on the actual constants (R = 2^93).
+static bool l31_wide_group_ok(const std::vector<uint64_t>& Mm, uint32_t kt, uint64_t p) {
+    if (kt < 9 || kt > 12 || Mm.empty()) return false;
+    std::vector<uint64_t> packed;
+    l31_pack_matrix(Mm, p, 93, packed);
+    for (size_t r = 0; r + kt <= Mm.size(); r += kt) {
+        uint64_t s0 = 0, s1 = 0;
+        for (uint32_t i = 0; i < kt; ++i) {
+            const int64_t m0 = (int32_t)(uint32_t)packed[r + i], m1 = (int32_t)(uint32_t)(packed[r + i] >> 32);
+            s0 += (uint64_t)(m0 < 0 ? -m0 : m0);
+            s1 += (uint64_t)(m1 < 0 ? -m1 : m1);
+        }
+        if ((s0 << 30) + (1ull << 33) >= (1ull << 63) || (s1 << 30) + (1ull << 33) >= (1ull << 63)) return false;
+    }
+    return true;
+}
+
 // one matrix in the form the limb-31 kernels take: the kernarg copy (compiled / run-time (k, t) kernels) or device memory
 static int l31_place_matrix(sda_share_generator* g, const std::vector<uint64_t>& Mm, MatArg*& arg, DevBuf& dev) {
     std::vector<uint64_t> packed;
@@ -717,6 +756,8 @@ static int build_n31(sda_share_generator* g) {
 
 static int build_l31(sda_share_generator* g) {
     SDA_TRY(l31_params(g->mod.m, g->lp));
+    if (g->l31 && g->path.l31_r_bits == 93)                              // both maps, or the 7 + rest form serves the handle
+        g->lp.wide = !knob(KNOB_NO_WIDE_GROUP) && l31_wide_group_ok(g->Mmont, g->k + g->t, g->mod.m) && (!g->sys_default || l31_wide_group_ok(g->Msys, g->k + g->t, g->mod.m)) ? 1u : 0u;
     SDA_TRY(l31_place_matrix(g, g->Mmont, g->matarg, g->d_M));
     if (g->sys_default) SDA_TRY(l31_place_matrix(g, g->Msys, g->matarg_sys, g->d_Msys));
     return SDA_OK;
@@ -729,7 +770,7 @@ static int l31_params(uint64_t p, L31Params& lp) {
     if (!h_invmod(p % B, B, inv)) return fail(SDA_ERR_INVALID_ARGUMENT, "modulus not invertible mod 2^31");
     lp.p = p; lp.p2 = 2 * p; lp.h = (p + 1) / 2;
     lp.p0 = (int32_t)(p % B); lp.p1 = (int32_t)(p >> 31);
-    lp.pinvB = (uint32_t)((B - inv) % B); lp.pad = 0;
+    lp.pinvB = (uint32_t)((B - inv) % B); lp.wide = 0;
     lp.np = (uint64_t)0 - p; lp.np2 = (uint64_t)0 - 2 * p;
     return SDA_OK;
 }
@@ -1235,8 +1276,10 @@ extern "C" int sda_share_generator_generate(sda_share_generator_t* g, const int6
     }
     DrbgKey key = d_rand ? DrbgKey{} : g->drbg.call_key();
     const uint64_t stream_id = d_rand ? 0 : g->drbg.host_stream();
+    g_last_gen_kernel[0] = 0;
     int st = generate_batch_impl(g, key, g->d_secrets.as<int64_t>(), 1, len, len, d_rand, want_rand, stream_id,
                                  g->d_out.as<int64_t>(), (size_t)g->n * Bs, Bs, nullptr);
+    snprintf(g_last_call_kernels, sizeof g_last_call_kernels, "%s", g_last_gen_kernel);
     explicit_bzero(&key, sizeof key);
     if (st == SDA_OK) {
         hipError_t e = hipMemcpy2DAsync(out, B * 8, g->d_out.p, Bs * 8, B * 8, g->n, hipMemcpyDeviceToHost, g->ctx.stream);

@@ -464,9 +464,20 @@ __device__ __forceinline__ uint64_t l31_redc3(const L31Cols& c, const L31Params&
     return lifted < (uint64_t)res ? lifted : (uint64_t)res;
 }
 
-template <int KT>
+// WIDE (round 5): the whole dot product of 9 .. 12 terms as ONE group - no normalisation at all (10 terms: 40 multiply-adds + 34
+// instead of 40 + 49).  Ten products of 2^60 pass a signed 64-bit column only if the constant limbs are large all at once;
+// for random constants sum |limb| is ~ KT / 2 x 2^30 against the 8 x 2^30 a column can take, so the host admits the form on
+// the ACTUAL constants of both share maps (l31_wide_group_ok in sda_capi.cpp -> L31Params::wide) and the 7 + rest form
+// serves the handle otherwise.  BASELINE config 4's (8,2,26) over the 62-bit prime: worst row 6.93 x 2^30.
+template <int KT, bool WIDE = false>
 __device__ __forceinline__ uint64_t l31_dot3(const uint64_t* __restrict__ row, const int32_t (&v0)[KT], const int32_t (&v1)[KT],
                                              const L31Params& P) {
+    if constexpr (WIDE) {
+        static_assert(KT >= 9 && KT <= 12, "the wide group is compiled for 9 .. 12 terms");
+        L31Cols c;
+        l31_cols_add<KT, true>(c, row, v0, v1);
+        return l31_redc3<true, false>(c, P);
+    }
     // groups of seven; a remainder of ONE term joins the group before it (15 = 7 + 8: saves a normalisation) - eight products
     // of 2^60 can pass 2^63 only if all eight limbs are -2^30, which the host rules out on the actual constants
     // (l31_eight_term_group_ok in sda_capi.cpp; the shape is served by another kernel otherwise)
@@ -595,6 +606,17 @@ __device__ __forceinline__ void packed_gen_l31_body(const GenLayout& L, uint32_t
     if (direct) {
 #pragma unroll
         for (int i = 0; i < T; ++i) store_pair<VEC>(op + (size_t)i * L.out_stride_clerk, s0[K + i], s1[K + i], in0, in1);
+    }
+    if constexpr (L31UseR93<K, T>::value && KT >= 9 && KT <= 12) {
+        if (lp.wide) {                                                       // uniform: the host admitted the one-group form
+            for (uint32_t j = direct; j < n; ++j) {
+                const uint64_t* row = &M.e[(size_t)(j - direct) * KT];
+                const uint64_t a = l31_dot3<KT, true>(row, a0, a1, lp);
+                const uint64_t b = l31_dot3<KT, true>(row, c0, c1, lp);
+                store_pair<VEC>(op + (size_t)j * L.out_stride_clerk, a, b, in0, in1);
+            }
+            return;
+        }
     }
     for (uint32_t j = direct; j < n; ++j) {
         const uint64_t* row = &M.e[(size_t)(j - direct) * KT];

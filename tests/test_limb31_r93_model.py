@@ -39,9 +39,21 @@ def centre(v, p):
     return v - p if v >= (p + 1) // 2 else v
 
 
-def groups_of(kt):
+def host_admits_wide(cons):
+    """sda_capi.cpp l31_wide_group_ok (round 5): 9 .. 12 terms as ONE group when, for the ACTUAL constants, no column can leave a
+    signed 64-bit register whatever the values (limbs of magnitude <= 2^30): sum |limb| 2^30 + 2^33 < 2^63 for the m0 and the m1
+    limbs of the row"""
+    if not 9 <= len(cons) <= 12:
+        return False
+    return (sum(abs(m0) for m0, _ in cons) << 30) + (1 << 33) < (1 << 63) and (sum(abs(m1) for _, m1 in cons) << 30) + (1 << 33) < (1 << 63)
+
+
+def groups_of(kt, cons=None):
     """l31_dot3: groups of seven, the remainder last; a remainder of ONE term joins the group before it (7 + 8 for 15 terms),
-    which the host admits only after checking the actual constants (host_admits_eight)"""
+    which the host admits only after checking the actual constants (host_admits_eight).  Round 5: 9 .. 12 terms form ONE group
+    where the constants admit it (host_admits_wide; in the library the answer covers every row of both share maps)"""
+    if cons is not None and host_admits_wide(cons):
+        return [kt]
     sizes = [7] * (kt // 7) + ([kt % 7] if kt % 7 else [])
     if len(sizes) >= 2 and sizes[-1] == 1:
         sizes = sizes[:-2] + [8]
@@ -57,7 +69,7 @@ def host_admits_eight(cons, sizes):
     return (sum(abs(m0) for m0, _ in grp) << 30) + (1 << 32) < (1 << 63) and (sum(abs(m1) for _, m1 in grp) << 30) + (1 << 33) < (1 << 63)
 
 
-def dot3(p, row, vals):
+def dot3(p, row, vals, wide=True, seen=None):
     """row: constants m (canonical, NOT yet in Montgomery form); vals: canonical values.  Returns sum m v mod p as the kernel computes it."""
     pinvB = (-pow(p, -1, B)) % B
     p0, p1 = p % B, p >> 31
@@ -65,7 +77,9 @@ def dot3(p, row, vals):
     lim = [bal(centre(v, p)) for v in vals]
     C0 = C1a = C1b = C2 = C3 = 0
     g = 0
-    sizes = groups_of(len(row))
+    sizes = groups_of(len(row), cons if wide else None)
+    if seen is not None:
+        seen.append(tuple(sizes))
     if not host_admits_eight(cons, sizes):
         return sum(m * v for m, v in zip(row, vals)) % p          # the library then serves the shape with another kernel
     for gi, size in enumerate(sizes):
@@ -159,3 +173,43 @@ def test_three_digit_dot_product_exact_and_in_range(p, kt):
             row = [rnd.randrange(p) for _ in range(kt)]
             vals = [rnd.randrange(p) for _ in range(kt)]
         assert dot3(p, row, vals) == sum(m * v for m, v in zip(row, vals)) % p
+        assert dot3(p, row, vals, wide=False) == sum(m * v for m, v in zip(row, vals)) % p
+
+
+@pytest.mark.parametrize("kt", [9, 10, 11, 12])
+def test_wide_group_is_taken_when_the_constants_admit_it_and_never_overflows(kt):
+    """the one-group form of round 5: random constants admit it most of the time for 9 / 10 terms (sum |limb| ~ kt / 2 x 2^30
+    against the 8 x 2^30 a column can take), adversarial ones never - and whenever it is taken every register of the model
+    stays inside 64 bits for the WORST values (all limbs +-2^30, signs aligned with the constants)"""
+    p = 4611686006577364993
+    rnd = random.Random(kt)
+    taken = 0
+    for trial in range(400):
+        row = [rnd.randrange(p) for _ in range(kt)]
+        cons = [bal(centre(m * R93 % p, p)) for m in row]
+        seen = []
+        # worst-case values for THIS row: every limb of magnitude 2^30 (or as close as a residue allows), signs matched to m0
+        worst = []
+        for m0, m1 in cons:
+            s = 1 if m0 >= 0 else -1
+            x = s * ((1 << 30) - 1) * B + s * ((1 << 30) - 1)
+            worst.append(x % p)
+        for vals in (worst, [rnd.randrange(p) for _ in range(kt)]):
+            assert dot3(p, row, vals, seen=seen) == sum(m * v for m, v in zip(row, vals)) % p     # i64() asserts inside
+        taken += seen[0] == (kt,)
+    assert taken > (300 if kt <= 10 else 0), taken
+    # BASELINE config 4's own constants (k=8, t=2, n=26 over the 62-bit prime, roots 5^((p-1)/16), 5^((p-1)/27)): admitted
+    if kt == 10:
+        w2, w3 = 2589100645267092065, 365137883145458390
+        nodes = [pow(w2, e, p) for e in range(11)]
+        for j in range(26):
+            x = pow(w3, j + 1, p)
+            row = []
+            for a, xa in enumerate(nodes):
+                num = den = 1
+                for b, xb in enumerate(nodes):
+                    if a != b:
+                        num = num * (x - xb) % p
+                        den = den * (xa - xb) % p
+                row.append(num * pow(den, p - 2, p) % p)
+            assert host_admits_wide([bal(centre(m * R93 % p, p)) for m in row[1:]]), j

@@ -17,6 +17,35 @@ from conftest import set_knob
 
 pytestmark = pytest.mark.gpu
 
+
+class Stream:
+    """a non-blocking HIP stream from the library's test-only helpers (no second HIP binding in the test process)"""
+
+    def __init__(self):
+        import ctypes as C
+        from sda_amd import capi
+        self._lib, self._h = capi.load(), C.c_void_p()
+        capi.check(self._lib.sda_debug_stream_create(C.byref(self._h)))
+        self.cuda_stream = self._h.value
+
+    def synchronize(self):
+        from sda_amd import capi
+        capi.check(self._lib.sda_debug_stream_synchronize(self._h))
+
+    def __del__(self):
+        try:
+            self._lib.sda_debug_stream_destroy(self._h)
+        except Exception:
+            pass
+
+
+def mem_free():
+    import ctypes as C
+    from sda_amd import capi
+    f, t = C.c_size_t(), C.c_size_t()
+    capi.check(capi.load().sda_debug_mem_info(C.byref(f), C.byref(t)))
+    return f.value
+
 P62 = 4611686006577364993
 W = {8: 631229665360524489, 9: 3451275676410824977, 16: 2589100645267092065, 27: 365137883145458390}
 KEY = bytes((i * 5 + 9) & 0xFF for i in range(32))
@@ -26,12 +55,10 @@ KEY = bytes((i * 5 + 9) & 0xFF for i in range(32))
 def test_combiner_orders_its_accumulators_across_streams(gpu, form):
     """generate_combine_dev on stream A, finish_dev on stream B, 50 times in a row: the oracle's sums every time.  Nothing but
     the library orders B after A (no event, no synchronisation between the two calls on the caller's side)."""
-    import torch
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     from oracle import coracle
-    dev = torch.device("cuda", 0)
-    A, Bst = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    A, Bst = Stream(), Stream()
     if form == "additive":
         sch, n, k, t = crypto.Additive(3, P62), 3, 1, 2
     else:
@@ -41,7 +68,7 @@ def test_combiner_orders_its_accumulators_across_streams(gpu, form):
             set_knob("SDA_FORCE_FFT", 1)
         if form == "two_launches_generic":
             set_knob("SDA_FORCE_GENERIC", 1)
-    P, dim, tiles = 48, k * 40000 + 1, 2
+    P, dim, tiles = 48, k * 40000 + 2, 2        # even: the dual-role kernels read the secrets with 16-byte loads
     gen = crypto.ShareGenerator(sch)
     gen.set_drbg_key(KEY)
     assert gen.path_name() == {"dual_role_l31": "l31", "side_stream_transform": "fft", "two_launches_generic": "generic", "additive": "additive"}[form]
@@ -81,19 +108,17 @@ def test_combiner_orders_its_accumulators_across_streams(gpu, form):
         got = np.empty(n * B, dtype=np.int64)
         capi.check(capi.load().sda_dev_download(got.ctypes.data, d_sums.ptr, n * B * 8))
         assert np.array_equal(got.reshape(n, B), want), (form, rep)
-    torch.cuda.synchronize(dev)
+    capi.check(capi.load().sda_dev_synchronize())
 
 
 def test_update_dev_on_another_stream_after_the_side_stream_sum(gpu):
     """the same for update_dev: tile sums issued by generate_combine_dev (side-stream clerk sum) on stream A, one more tile
     added with update_dev on stream B, finish on the default stream"""
-    import torch
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     from oracle import coracle
     set_knob("SDA_FORCE_FFT", 1)
-    dev = torch.device("cuda", 0)
-    A, Bst = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    A, Bst = Stream(), Stream()
     n, k, t = 8, 3, 4
     sch = crypto.PackedShamir(k, n, t, P62, W[8], W[9])
     P, dim = 32, 3 * 30000
@@ -159,7 +184,6 @@ def test_signed_share_generation_draws_inside_the_kernel(gpu, q):
 def test_signed_share_generation_of_a_bench_sized_tile_needs_no_scratch(gpu):
     """2000 participants x 1 Mi x n = 3 in the reference's representatives: round 4 materialised every draw first (33.5 GB for
     this tile, 117 GB at n = 8); now the device memory in use grows by less than 1 GB across the call"""
-    import torch
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     from oracle import coracle, pyoracle as po
@@ -172,11 +196,11 @@ def test_signed_share_generation_of_a_bench_sized_tile_needs_no_scratch(gpu):
     d_sec = DeviceBuffer(P * dim)
     capi.check(lib.sda_fill_synthetic_dev(d_sec.ptr, P, dim, dim, 0, 0x5DA5, P62, None))
     d_out = DeviceBuffer(n * P * dim)
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
+    capi.check(lib.sda_dev_synchronize())
+    free0 = mem_free()
     gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, dim, P * dim, first_participant=0)      # job-major [n][P][dim]
     capi.check(lib.sda_dev_synchronize())
-    free1, _ = torch.cuda.mem_get_info()
+    free1 = mem_free()
     assert free0 - free1 < (1 << 30), (free0 - free1) / 2**30
     osch = po.AdditiveSecretSharing(n, P62, "rust_signed")
     for p in (0, 1999):
@@ -206,3 +230,55 @@ def test_the_library_reports_the_kernels_it_ran(gpu):
     g.generate(np.arange(10, dtype=np.int64))
     assert g.path_name() == "additive" and last() == "additive_gen_kernel<20, true>", last()
     assert len(lib.sda_build_id()) == 16
+
+
+@pytest.mark.parametrize("wide", [True, False])
+def test_config4_dot_product_as_one_group_and_as_seven_plus_three(gpu, wide):
+    """BASELINE config 4's (8,2,26): the 10-term dot product as ONE three-digit group (default where the host admits it on the
+    constants of both share maps) and in the 7 + 3 grouping (knob SDA_NO_WIDE_GROUP) - both against the oracle, on random and
+    on adversarial operands (every balanced limb +-2^30, alike within a batch), injected randomness and the device CSPRNG,
+    separate and dual-role launches"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    if not wide:
+        set_knob("SDA_NO_WIDE_GROUP", 1)
+    k, t, n = 8, 2, 26
+    sch = crypto.PackedShamir(k, n, t, P62, W[16], W[27])
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    ext = []
+    for a in (-(1 << 30), (1 << 30) - 1):
+        for b in (-(1 << 30) + 1, (1 << 30) - 1, -(1 << 30)):
+            x = b * (1 << 31) + a
+            if abs(x) <= (P62 - 1) // 2:
+                ext.append(x % P62)
+    ext += [0, 1, P62 - 1, (P62 - 1) // 2, (P62 + 1) // 2]
+    Bx = len(ext) * len(ext)
+    secrets = np.array([ext[(b // len(ext))] for b in range(Bx) for _ in range(k)], dtype=np.int64)
+    rand = np.array([ext[(b % len(ext))] for b in range(Bx) for _ in range(t)], dtype=np.int64)
+    assert np.array_equal(gen.generate(secrets, rand), coracle.packed_generate(P62, k, t, n, W[16], W[27], secrets, rand))
+    rng = np.random.default_rng(5)
+    P, dim = 6, k * 777 + 6
+    sec = rng.integers(-(1 << 62), 1 << 62, size=(P, dim), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec)
+    B = gen.batch_count(dim)
+    Bs = (B + 15) // 16 * 16
+    bufs = [DeviceBuffer(n * P * Bs).zero() for _ in range(2)]
+    comb = crypto.ShareCombiner(sch)
+    comb.begin_dev(n, B)
+    for i in range(3):
+        gen.generate_combine_dev(comb, d_sec.ptr, P if i < 2 else 0, dim, dim, bufs[i % 2].ptr, Bs, P * Bs,
+                                 d_prev=bufs[(i - 1) % 2].ptr if i else 0, prev_participants=P if i else 0, first_participant=i * P)
+    from sda_amd import capi
+    assert capi.load().sda_debug_last_kernel().decode() == "fused_packed_l31_kernel<8, 2, 20>"
+    d_sums = DeviceBuffer(n * B)
+    comb.finish_dev(d_sums.ptr)
+    sums = d_sums.to_numpy().reshape(n, B)
+    want = [coracle.packed_generate_csprng(P62, k, t, n, W[16], W[27], sec[q], coracle.drbg_fill(KEY, i * P + q, B, t, P62), gen.csprng_share_map())
+            for i in range(2) for q in range(P)]
+    tile1 = bufs[1].to_numpy().reshape(n, P, Bs)
+    for q in range(P):
+        assert np.array_equal(tile1[:, q, :B], want[P + q]), q
+    for c in range(n):
+        assert np.array_equal(sums[c], coracle.combine(P62, np.stack([w[c] for w in want]))), c
