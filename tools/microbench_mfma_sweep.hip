@@ -1,0 +1,96 @@
+// What does one limb-GEMM "pair" (72 v_mfma_i32_16x16x64_i8 into ten accumulators for one row tile x two batch tiles) cost a wave
+// as its surroundings are added back?  One wave per SIMD (256 threads, one workgroup per CU).
+//   v0  MFMAs only, A and B in registers                         v1  + B fragments from LDS (24 ds_read_b128)
+//   v2  + the epilogue (40 v_mad_i64_i32, 8 reductions)            v3  + 16 non-temporal 8-byte stores per pair
+//   v4  v3 with two waves per SIMD
+//   hipcc --offload-arch=gfx950 -O3 -o tools/microbench_mfma_sweep tools/microbench_mfma_sweep.hip && tools/microbench_mfma_sweep
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int V>
+__global__ void k(const v4i* __restrict__ Ag, long long* out, int iters, int32_t c0, int32_t c1, uint32_t pinv, uint32_t p) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, col = lane & 15u, g = lane >> 4, wave = threadIdx.x >> 6;
+    constexpr int ROW = 272, PLANE = 64 * ROW;
+    for (uint32_t i = threadIdx.x; i < 3 * PLANE / 4; i += blockDim.x) ((uint32_t*)lds)[i] = i * 2654435761u;
+    __syncthreads();
+    v4i A[12];
+    for (int q = 0; q < 12; ++q) A[q] = Ag[q * 64 + lane];
+    const uint8_t* brow = lds + (size_t)col * ROW + 16 * g;
+    v4i b0c = *(const v4i*)(brow), b1c = *(const v4i*)(brow + 16 * ROW);
+    long long* o = out + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    uint32_t sink = 0;
+    for (int it = 0; it < iters; ++it) {
+        v4i acc[2][5];
+        for (int h = 0; h < 2; ++h) for (int c = 0; c < 5; ++c) acc[h][c] = v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int lb = 0; lb < 3; ++lb) {
+                v4i b0v = b0c, b1v = b1c;
+                if (V >= 1) {
+                    b0v = *(const v4i*)(brow + lb * PLANE + 64 * ks + ((it & 1) * 32 * ROW));
+                    b1v = *(const v4i*)(brow + 16 * ROW + lb * PLANE + 64 * ks + ((it & 1) * 32 * ROW));
+                }
+#pragma unroll
+                for (int la = 0; la < 3; ++la) {
+                    acc[0][la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + la], b0v, acc[0][la + lb], 0, 0, 0);
+                    acc[1][la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + la], b1v, acc[1][la + lb], 0, 0, 0);
+                }
+            }
+        if (V >= 2) {
+            uint32_t share[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int64_t S = (int64_t)c0 * acc[h][0][i];
+                    S += (int64_t)c1 * acc[h][1][i]; S += (int64_t)c0 * acc[h][2][i]; S += (int64_t)c1 * acc[h][3][i]; S += (int64_t)c0 * acc[h][4][i];
+                    const int32_t q = (int32_t)((uint32_t)S * pinv);
+                    const uint32_t t = (uint32_t)((int32_t)(S >> 32) - __mulhi(q, (int32_t)p));
+                    const uint32_t u = t + p;
+                    share[h][i] = u < t ? u : t;
+                }
+            if (V >= 3) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) __builtin_nontemporal_store((long long)share[h][i], o + ((h * 4 + i) ^ (it & 7)));
+            } else {
+                for (int h = 0; h < 2; ++h) for (int i = 0; i < 4; ++i) sink ^= share[h][i];
+            }
+        } else {
+            for (int h = 0; h < 2; ++h) for (int c = 0; c < 5; ++c) sink ^= (uint32_t)acc[h][c][0] ^ (uint32_t)acc[h][c][3];
+        }
+    }
+    if (sink == 0x12345678u) o[0] = sink;
+}
+
+template <int V>
+void run(const char* name, const v4i* dA, long long* dout, int threads) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20000, cus = 256;
+    hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    k<V><<<cus, threads, 100 * 1024>>>(dA, dout, 10, 12345, -54321, 0x9E3779B1u, 746497u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<V><<<cus, threads, 100 * 1024>>>(dA, dout, iters, 12345, -54321, 0x9E3779B1u, 746497u);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-58s %8.3f ms   %7.1f ns per pair (72 MFMAs)   %5.2f ns per MFMA-slot per wave\n", name, ms, ms * 1e6 / iters, ms * 1e6 / iters / 72);
+}
+
+int main() {
+    v4i* dA; long long* dout;
+    hipMalloc(&dA, 12 * 64 * 16); hipMemset(dA, 0x11, 12 * 64 * 16);
+    hipMalloc(&dout, (size_t)256 * 512 * 8 * 8);
+    run<0>("v0 MFMAs only (A, B in registers), 1 wave/SIMD", dA, dout, 256);
+    run<1>("v1 + B from LDS", dA, dout, 256);
+    run<2>("v2 + epilogue", dA, dout, 256);
+    run<3>("v3 + 8 nt stores per pair", dA, dout, 256);
+    run<3>("v4 = v3, 2 waves/SIMD", dA, dout, 512);
+    run<0>("v5 = v0, 2 waves/SIMD", dA, dout, 512);
+    return 0;
+}
