@@ -2,7 +2,8 @@
 // as its surroundings are added back?  One wave per SIMD (256 threads, one workgroup per CU).
 //   v0  MFMAs only, A and B in registers                         v1  + B fragments from LDS (24 ds_read_b128)
 //   v2  + the epilogue (40 v_mad_i64_i32, 8 reductions)            v3  + 16 non-temporal 8-byte stores per pair
-//   v4  v3 with two waves per SIMD
+//   v4  v3 with two waves per SIMD                                 v6  v1 + the epilogue in DOUBLE precision (exact: |S| < 2^52):
+//                                                                      5 v_cvt_f64_i32, 4 v_fma_f64, q = rint(S / p), r = fma(-q, p, S)
 //   hipcc --offload-arch=gfx950 -O3 -o tools/microbench_mfma_sweep tools/microbench_mfma_sweep.hip && tools/microbench_mfma_sweep
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -40,7 +41,24 @@ __global__ void k(const v4i* __restrict__ Ag, long long* out, int iters, int32_t
                     acc[1][la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + la], b1v, acc[1][la + lb], 0, 0, 0);
                 }
             }
-        if (V >= 2) {
+        if (V == 6) {
+            const double dp = (double)p, dinv = 1.0 / (double)p;
+            uint32_t share[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double S = __builtin_fma((double)acc[h][1][i], 256.0, (double)acc[h][0][i]);
+                    S = __builtin_fma((double)acc[h][2][i], 65536.0, S);
+                    S = __builtin_fma((double)acc[h][3][i], 16777216.0, S);
+                    S = __builtin_fma((double)acc[h][4][i], 4294967296.0, S);
+                    const double q = __builtin_rint(S * dinv);
+                    const int32_t r = (int32_t)__builtin_fma(-q, dp, S);
+                    const uint32_t t = (uint32_t)r, u = t + p;
+                    share[h][i] = u < t ? u : t;
+                }
+            for (int h = 0; h < 2; ++h) for (int i = 0; i < 4; ++i) sink ^= share[h][i];
+        } else if (V >= 2) {
             uint32_t share[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -92,5 +110,8 @@ int main() {
     run<3>("v3 + 8 nt stores per pair", dA, dout, 256);
     run<3>("v4 = v3, 2 waves/SIMD", dA, dout, 512);
     run<0>("v5 = v0, 2 waves/SIMD", dA, dout, 512);
+    run<6>("v6 v1 + epilogue in double precision, 1 wave/SIMD", dA, dout, 256);
+    run<2>("v7 = v2, 2 waves/SIMD", dA, dout, 512);
+    run<6>("v8 = v6, 2 waves/SIMD", dA, dout, 512);
     return 0;
 }

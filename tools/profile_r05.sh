@@ -1,0 +1,46 @@
+# round-5 evidence: for every bench workload, at ONE tile size per workload and in the DEFAULT schedule (dual-role launch;
+# the transform shape has none and runs serial): kernel stats (rocprofv3 --kernel-trace --stats), HBM traffic (separate
+# --pmc passes FETCH_SIZE / WRITE_SIZE, kernel-trace only) and the SQ counters that say which ceiling is active
+# (tools/pmc_sq.txt, two more passes).   bash tools/profile_r05.sh [workloads...]  ->  gpurun_out/r05_final/<workload>/
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r05_final; mkdir -p $O
+# tiles = the ones bench.py runs in the driver form (its `roofline.traffic` is a measurement of exactly that tile or null)
+declare -A TILE=( [packed]=2500 [additive]=2000 [packed26]=1250 [packed_ref]=1500 [packed26_ref]=1500 [packed_dim16m]=125 [packed_pss728]=500 [narrow_ref]=1500 [narrow26_ref]=1500 [narrow_pss728]=500 [narrow_pss19682]=40 )
+declare -A SCHED=( [packed_pss728]="--schedule serial" [narrow_pss728]="--schedule serial" [narrow_pss19682]="--schedule serial" )
+WLS="${@:-packed additive packed26 packed_dim16m packed_pss728 narrow_ref narrow26_ref narrow_pss728 narrow_pss19682}"
+cd /tmp && export TMPDIR=/tmp
+for W in $WLS; do
+  T=${TILE[$W]}; S=${SCHED[$W]}; D=$O/$W; mkdir -p $D
+  A="--full-line --workload $W --tile $T --no-cpu-baseline --no-verify --no-additional $S"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python $R/bench.py $A --steps 10 --warmup 2 --participants $((10*T)) 2>$D/rocprof_stats.log | tail -1 > $D/bench_under_rocprof.json
+  for c in fetch write sq; do
+    timeout 600 rocprofv3 -i $R/tools/pmc_$c.txt --kernel-trace --output-format csv -d $D/pmc_$c -- python $R/bench.py $A --steps 3 --warmup 1 --participants $((3*T)) > /dev/null 2>$D/rocprof_$c.log
+  done
+  find $D/stats -name '*kernel_stats.csv' -exec cp {} $D/kernel_stats.csv \;
+  python3 - "$D" <<'PY'
+import csv, glob, sys, collections, json
+D = sys.argv[1]
+out = {}
+for c in ('fetch', 'write'):
+    d = collections.defaultdict(list)
+    for f in glob.glob(D + '/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
+        for row in csv.DictReader(open(f)):
+            if 'sda::' in row['Kernel_Name']:
+                d[(row['Kernel_Name'].split('(')[0], row['Counter_Name'], row['Grid_Size'])].append(float(row['Counter_Value']))
+    for k, v in sorted(d.items()):
+        out['%s :: %s :: grid %s' % k] = {'mean_KiB': sum(v) / len(v), 'launches': len(v)}
+json.dump(out, open(D + '/pmc_hbm.json', 'w'), indent=1)
+# SQ counters per (kernel, grid): the mean over the launches of that grid size
+d = collections.defaultdict(list)
+for f in glob.glob(D + '/pmc_sq/**/*counter_collection.csv', recursive=True):
+    for row in csv.DictReader(open(f)):
+        if 'sda::' in row['Kernel_Name']:
+            d[(row['Kernel_Name'].split('(')[0], row['Grid_Size'], row['Counter_Name'])].append(float(row['Counter_Value']))
+sq = collections.defaultdict(dict)
+for (k, g, c), v in sorted(d.items()):
+    sq['%s :: grid %s' % (k, g)][c] = sum(v) / len(v)
+    sq['%s :: grid %s' % (k, g)]['launches'] = len(v)
+json.dump(sq, open(D + '/pmc_sq.json', 'w'), indent=1)
+PY
+  rm -rf $D/stats $D/pmc_fetch $D/pmc_write $D/pmc_sq
+  echo "== $W"; head -3 $D/kernel_stats.csv | cut -c1-200
+done
