@@ -85,6 +85,8 @@ hipError_t launch_packed_generate(const GenLayout& L, uint32_t n, uint32_t k, ui
 // packed Shamir, compiled (k, t) shapes: balanced 31-bit limbs, carry-free v_mad_i64_i32 dot products
 bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n);
 unsigned packed_l31_r_bits(uint32_t k, uint32_t t);     // 62 or 93: the Montgomery radix 2^bits the kernels of this shape expect
+unsigned packed_l31_rt_r_bits(uint32_t kt);             // ... and the run-time (k, t) kernels (the global-matrix form serves compiled shapes too when n is large)
+bool packed_l31_three_digit_compiled(uint32_t k, uint32_t t);   // a COMPILED (k, t) instance in the three-digit form
 hipError_t launch_packed_generate_l31(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,
                                       const ModParams& mod, const L31Params& lp, const MatArg& Ml31,
                                       const DrbgKey& key, int rounds, hipStream_t s);
@@ -111,7 +113,7 @@ hipError_t launch_fused_packed_mfma(const GenLayout& L, uint32_t n, uint32_t k, 
 // the limb-31 kernel with run-time (k, t) and the matrix in global memory: any n, k + t <= 64
 bool packed_l31_global_path_available(uint32_t k, uint32_t t);
 hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
-                                             const L31Params& lp, const uint64_t* d_Ml31 /* n (k+t) entries + 3 zeros */,
+                                             const L31Params& lp, const uint64_t* d_Ml31 /* n (k+t) entries + 7 zeros */,
                                              const DrbgKey& key, int rounds, hipStream_t s);
 
 // packed Shamir, transform form (tss's own radix-2 inverse / radix-3 forward structure) for large tss-valid shapes:

@@ -658,7 +658,7 @@ static int validate_packed(const sda_sharing_scheme_t& s) {
 // (-p/2, p/2] and split into balanced limbs m1 * 2^31 + m0, m0 in [-2^30, 2^30).
 static void l31_pack_matrix(const std::vector<uint64_t>& Mm, uint64_t p, unsigned r_bits, std::vector<uint64_t>& packed) {
     const uint64_t B = 1ull << 31;
-    packed.assign(Mm.size() + 3, 0);                                    // three zero entries past the end (see l31_dot_rt)
+    packed.assign(Mm.size() + 7, 0);                                    // zero entries past the end: the run-time kernels read up to six (l31_dot_rt)
     // Mm holds M * 2^64: bring it to M * 2^r_bits (62: divide by 4; 93: multiply by 2^29)
     const uint64_t adjust = r_bits == 62 ? h_powmod(4 % p, p - 2, p) : h_powmod(2, r_bits - 64, p);
     for (size_t i = 0; i < Mm.size(); ++i) {
@@ -715,8 +715,8 @@ static bool l31_wide_group_ok(const std::vector<uint64_t>& Mm, uint32_t kt, uint
 // one matrix in the form the limb-31 kernels take: the kernarg copy (compiled / run-time (k, t) kernels) or device memory
 static int l31_place_matrix(sda_share_generator* g, const std::vector<uint64_t>& Mm, MatArg*& arg, DevBuf& dev) {
     std::vector<uint64_t> packed;
-    // the global-matrix kernels are run-time (k, t) forms (R = 2^62); a compiled shape may be a three-digit one (R = 2^93)
-    l31_pack_matrix(Mm, g->mod.m, g->l31g ? 62u : packed_l31_r_bits(g->k, g->t), packed);
+    // the radix follows the shape: compiled three-digit instances and every run-time shape of more than eight terms carry R = 2^93
+    l31_pack_matrix(Mm, g->mod.m, g->l31g ? packed_l31_rt_r_bits(g->k + g->t) : packed_l31_r_bits(g->k, g->t), packed);
     if (g->l31g) {                                                      // matrix in global memory
         SDA_TRY(dev.reserve(packed.size() * 8));
         HIP_TRY(hipMemcpy(dev.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
@@ -756,7 +756,7 @@ static int build_n31(sda_share_generator* g) {
 
 static int build_l31(sda_share_generator* g) {
     SDA_TRY(l31_params(g->mod.m, g->lp));
-    if (g->l31 && g->path.l31_r_bits == 93)                              // both maps, or the 7 + rest form serves the handle
+    if (g->l31 && packed_l31_three_digit_compiled(g->k, g->t))          // both maps, or the 7 + rest form serves the handle
         g->lp.wide = !knob(KNOB_NO_WIDE_GROUP) && l31_wide_group_ok(g->Mmont, g->k + g->t, g->mod.m) && (!g->sys_default || l31_wide_group_ok(g->Msys, g->k + g->t, g->mod.m)) ? 1u : 0u;
     SDA_TRY(l31_place_matrix(g, g->Mmont, g->matarg, g->d_M));
     if (g->sys_default) SDA_TRY(l31_place_matrix(g, g->Msys, g->matarg_sys, g->d_Msys));
@@ -948,7 +948,7 @@ static PathFacts path_facts(const sda_share_generator* g, const PathKnobs& kn) {
     PathFacts f;
     uint32_t a = 0, b = 0, G = 0, tw = 0;
     f.transform_shape = fft_shape(g, kn, a, b, G, tw);
-    if (packed_l31_path_available(g->k, g->t, g->n) && packed_l31_r_bits(g->k, g->t) == 93) {
+    if (packed_l31_path_available(g->k, g->t, g->n) && packed_l31_three_digit_compiled(g->k, g->t)) {
         // the 8-term last group of a three-digit shape is admitted on the constants of BOTH share maps
         std::vector<uint64_t> sys_tmp;
         f.eight_term_ok = l31_eight_term_group_ok(g->Mmont, g->k + g->t, g->mod.m);

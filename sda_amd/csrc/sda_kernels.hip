@@ -883,10 +883,39 @@ __global__ __launch_bounds__(kThreads, 3) void packed_gen_mfma_kernel(GenLayout 
 // k and t are kernel arguments, KTMAX (4 / 8 / 12 / 16) bounds k + t.  The value limbs of the terms beyond k + t are
 // zero and every group of four terms is either done in full or skipped by a wave-uniform branch, so a dot product
 // costs what the next multiple of four terms costs; the matrix row may be read up to three entries past its end
-// (MatArg is zero-padded and n (k + t) + 3 <= SDA_MAT_ARG_MAX is required).
+// (MatArg is zero-padded and n (k + t) + 6 <= SDA_MAT_ARG_MAX is required: the three-digit form reads up to six).
+// Round 5: from 17 terms on (the global-matrix kernels for k + t <= 32 / <= 64) the run-time kernels use the THREE-digit form too
+// (R = 2^93: groups of seven terms, a carry normalisation between groups, ONE reduction per dot product) - a 33-term dot product
+// is 5 x 28 multiply-adds + 4 x 15 + 36 instructions instead of 9 x (16 + 21): (20,13,80) 11.9 -> 15.2, (20,11,40) 50.9 -> 62,
+// (10,7,26) 52.8 -> 61.3 Gelem/s (interleaved A/B of two builds, profiles/r05/ab_runtime_three_digit*.txt).  The groups a dot product
+// does not reach are skipped by wave-uniform branches; the last group may read up to six row entries past the end (zero-padded
+// constants, zero value limbs).  Up to 16 terms the two-digit form stays: measured, (9,6,26) ran 18 % SLOWER in the three-digit
+// form (79 -> 65 Gelem/s: at 184 registers the longer live ranges of five columns cost more than two reductions save).
+// packed_l31_r_bits() tells the host which radix a shape's constants carry.  Model: tests/test_limb31_r93_model.py.
+template <int KTMAX, int G>
+__device__ __forceinline__ void l31_rt3_groups(L31Cols& c, const uint64_t* __restrict__ row, const int32_t* v0, const int32_t* v1, uint32_t kt) {
+    if constexpr (G < KTMAX) {
+        if ((uint32_t)G < kt) {                                               // wave-uniform
+            l31_normalize<false>(c);
+            l31_cols_add<(KTMAX - G < 7 ? KTMAX - G : 7), false>(c, row + G, v0 + G, v1 + G);
+        }
+        l31_rt3_groups<KTMAX, G + 7>(c, row, v0, v1, kt);
+    }
+}
+template <int KTMAX>
+__device__ __forceinline__ uint64_t l31_dot_rt3(const uint64_t* __restrict__ row, const int32_t (&v0)[KTMAX],
+                                                const int32_t (&v1)[KTMAX], uint32_t kt, const L31Params& P) {
+    L31Cols c;
+    c.C3 = 0;
+    l31_cols_add<(KTMAX < 7 ? KTMAX : 7), true>(c, row, v0, v1);
+    l31_rt3_groups<KTMAX, 7>(c, row, v0, v1, kt);
+    return l31_redc3<true, true>(c, P);
+}
+
 template <int KTMAX>
 __device__ __forceinline__ uint64_t l31_dot_rt(const uint64_t* __restrict__ row, const int32_t (&v0)[KTMAX],
                                                const int32_t (&v1)[KTMAX], uint32_t kt, const L31Params& P) {
+    if constexpr (KTMAX >= 32) return l31_dot_rt3<KTMAX>(row, v0, v1, kt, P);
     uint64_t r = 0;
 #pragma unroll
     for (int g = 0; g < KTMAX; g += 4) {
@@ -1690,13 +1719,17 @@ unsigned packed_l31_r_bits(uint32_t k, uint32_t t) {
 #define X(K_, T_) if (k == K_ && t == T_) return L31UseR93<K_, T_>::value ? 93u : 62u;
     SDA_PACKED_L31_SHAPES(X)
 #undef X
-    return 62u;
+    return packed_l31_rt_r_bits(k + t);
 }
+// the run-time (k, t) kernels (kernarg or global matrix): three digits from 17 terms on (l31_dot_rt)
+unsigned packed_l31_rt_r_bits(uint32_t kt) { return kt > 16 ? 93u : 62u; }
+// a compiled instance in the three-digit form (the host checks its 8-term / one-group variants on the actual constants)
+bool packed_l31_three_digit_compiled(uint32_t k, uint32_t t) { return packed_l31_compiled(k, t) && packed_l31_r_bits(k, t) == 93u; }
 
 bool packed_l31_path_available(uint32_t k, uint32_t t, uint32_t n) {
     if ((uint64_t)n * (k + t) > SDA_MAT_ARG_MAX) return false;
     if (packed_l31_compiled(k, t)) return true;
-    return k >= 1 && k + t <= 16 && (uint64_t)n * (k + t) + 3 <= SDA_MAT_ARG_MAX;     // run-time (k, t) kernel
+    return k >= 1 && k + t <= 16 && (uint64_t)n * (k + t) + 6 <= SDA_MAT_ARG_MAX;     // run-time (k, t) kernel: a row is read up to 6 entries past its end
 }
 
 template <int K, int T, int ROUNDS>
@@ -1784,7 +1817,7 @@ static hipError_t packed_l31_launch_rtg(const GenLayout& L, uint32_t n, uint32_t
 
 bool packed_l31_global_path_available(uint32_t k, uint32_t t) { return k >= 1 && k + t <= 64; }
 
-// d_M: n (k + t) limb-31 packed entries followed by three zero entries (device memory)
+// d_M: n (k + t) limb-31 packed entries followed by seven zero entries (device memory)
 hipError_t launch_packed_generate_l31_global(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t, const ModParams& mod,
                                              const L31Params& lp, const uint64_t* d_M, const DrbgKey& key, int rounds,
                                              hipStream_t s) {
@@ -2014,7 +2047,7 @@ hipError_t launch_fused_packed_l31(const GenLayout& L, uint32_t n, uint32_t k, u
 #undef X
     // no compiled instance: the run-time (k, t) form, when the shape fits it
     const uint32_t kt = k + t;
-    if (k < 1 || kt > 16 || (uint64_t)n * kt + 3 > SDA_MAT_ARG_MAX) return hipSuccess;
+    if (k < 1 || kt > 16 || (uint64_t)n * kt + 6 > SDA_MAT_ARG_MAX) return hipSuccess;
     *fused = true;
     const dim3 grid((unsigned)F.grid), block(kThreads);
 #define RT(KTMAX_)                                                                                                      \

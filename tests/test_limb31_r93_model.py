@@ -48,6 +48,12 @@ def host_admits_wide(cons):
     return (sum(abs(m0) for m0, _ in cons) << 30) + (1 << 33) < (1 << 63) and (sum(abs(m1) for _, m1 in cons) << 30) + (1 << 33) < (1 << 63)
 
 
+def groups_rt(kt):
+    """l31_dot_rt3 (round 5, the run-time (k, t) kernels from nine terms on): groups of seven, the remainder last, whatever its
+    size - no 8-term joining, no one-group form; C3 starts at zero and every reduction is the SPLIT0 / HAS_C3 one"""
+    return [7] * (kt // 7) + ([kt % 7] if kt % 7 else [])
+
+
 def groups_of(kt, cons=None):
     """l31_dot3: groups of seven, the remainder last; a remainder of ONE term joins the group before it (7 + 8 for 15 terms),
     which the host admits only after checking the actual constants (host_admits_eight).  Round 5: 9 .. 12 terms form ONE group
@@ -69,7 +75,7 @@ def host_admits_eight(cons, sizes):
     return (sum(abs(m0) for m0, _ in grp) << 30) + (1 << 32) < (1 << 63) and (sum(abs(m1) for _, m1 in grp) << 30) + (1 << 33) < (1 << 63)
 
 
-def dot3(p, row, vals, wide=True, seen=None):
+def dot3(p, row, vals, wide=True, seen=None, runtime=False):
     """row: constants m (canonical, NOT yet in Montgomery form); vals: canonical values.  Returns sum m v mod p as the kernel computes it."""
     pinvB = (-pow(p, -1, B)) % B
     p0, p1 = p % B, p >> 31
@@ -77,7 +83,7 @@ def dot3(p, row, vals, wide=True, seen=None):
     lim = [bal(centre(v, p)) for v in vals]
     C0 = C1a = C1b = C2 = C3 = 0
     g = 0
-    sizes = groups_of(len(row), cons if wide else None)
+    sizes = groups_rt(len(row)) if runtime else groups_of(len(row), cons if wide else None)
     if seen is not None:
         seen.append(tuple(sizes))
     if not host_admits_eight(cons, sizes):
@@ -103,7 +109,7 @@ def dot3(p, row, vals, wide=True, seen=None):
     X = C0 + (C1a + C1b) * B + C2 * B * B + C3 * B * B * B
     # ---- l31_redc3
     q0 = sext31((C0 & 0xFFFFFFFF) * pinvB)
-    if sizes[-1] >= 7:
+    if sizes[-1] >= 7 or runtime:
         # a full last group: C0 + q0 p0 can pass 2^63 (7 products of 2^60 + 2^61) - the quotient by B is formed from the floor
         # of C0 and the exact quotient of its low limb plus q0 p0
         low = i64((C0 & MB) + q0 * p0)
@@ -213,3 +219,21 @@ def test_wide_group_is_taken_when_the_constants_admit_it_and_never_overflows(kt)
                         den = den * (xa - xb) % p
                 row.append(num * pow(den, p - 2, p) % p)
             assert host_admits_wide([bal(centre(m * R93 % p, p)) for m in row[1:]]), j
+
+
+@pytest.mark.parametrize("kt", [9, 12, 13, 16, 17, 31, 32, 33, 48, 63, 64])
+def test_run_time_three_digit_form_up_to_64_terms(kt):
+    """the run-time (k, t) kernels' grouping (sevens + remainder, up to ten groups): exact and inside every register for random,
+    extreme and sign-aligned operands over the 62-bit prime, the largest prime below 2^62 and a small one"""
+    for p in (4611686006577364993, largest_prime_below(1 << 62), 746497):
+        rnd = random.Random(kt + p % 1000)
+        inv = pow(R93, -1, p)
+        big = [x % p for x in ((1 << 30) * B + (1 << 30) - 1, -(1 << 30) * B - (1 << 30), ((1 << 30) - 1) * B - (1 << 30)) if abs(x) <= (p - 1) // 2]
+        for trial in range(120):
+            if trial < 30 and big:
+                row = [big[(trial + i) % len(big)] * inv % p for i in range(kt)] if trial & 1 else [big[trial % len(big)] * inv % p] * kt
+                vals = [big[(trial // 2 + i) % len(big)] for i in range(kt)] if trial & 2 else [big[(trial // 3) % len(big)]] * kt
+            else:
+                row = [rnd.randrange(p) for _ in range(kt)]
+                vals = [rnd.randrange(p) for _ in range(kt)]
+            assert dot3(p, row, vals, runtime=True) == sum(m * v for m, v in zip(row, vals)) % p

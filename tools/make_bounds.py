@@ -5,8 +5,9 @@ by bench.py for `roofline.bound`.     python tools/make_bounds.py profiles/r04/f
 
 Rule.  "hbm": the HBM bytes the PMC counters saw per launch / the launch's duration (HIP events of the same command) is
 within 10 % of what tools/microbench_hbm reaches with the SAME access pattern and no arithmetic at all (the floor).
-Otherwise "valu": the launch is limited by vector-ALU instruction issue, and the record carries the numbers to
-recompute that:
+Otherwise "valu" when rocprof's VALUBusy is at least 0.75 - the launch is limited by vector-ALU instruction issue - and
+"neither" below that (round 5: e.g. the narrow limb GEMM, whose vector and matrix instructions take turns on
+the SIMD); the record carries the numbers to recompute either:
   valu_wave_instr_per_element  = SQ_INSTS_VALU / (participants x dim of one launch)
   simd_cycles_per_valu_instr   = (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs / SQ_INSTS_VALU   (SIMD cycles available per issued
                                  VALU wave-instruction; tools/microbench_valu: 2.4-2.8 for add/sub/xor/and/mov, 4.1-5.3
@@ -65,7 +66,10 @@ for w in sorted(os.listdir(root)):
             gbps = pmc_bytes / (ms * 1e-3) / 1e9
             e["hbm"] = {"pmc_bytes_per_launch": pmc_bytes, "launch_ms": ms, "pmc_GBps": gbps, "floor_GBps": FLOOR[role],
                         "frac_of_floor": gbps / FLOOR[role]}
-            e["bound"] = "hbm" if gbps >= 0.9 * FLOOR[role] else "valu"
+            # round 5: a third verdict - neither ceiling is reached (HBM below 0.9 of its floor AND the vector ALUs busy less than
+            # 0.75 of the time): the launch is limited by something else (vector and matrix instructions taking turns on the SIMD in
+            # the narrow limb GEMM; the store stream of its 19682-clerk shape) and saying "valu" would be a claim without evidence
+            e["bound"] = "hbm" if gbps >= 0.9 * FLOOR[role] else "valu" if valu["valu_busy"] >= 0.75 else "neither"
         else:
             e["bound"] = "valu" if valu["valu_busy"] > 0.6 else "hbm"
         e["evidence"] = f"{root.rstrip('/')}/{w}/{{pmc_sq.json,pmc_hbm.json,bench_under_rocprof.json}} (tile {P}, dim {dim}); rule in profiles/bounds.json _note"
