@@ -731,9 +731,43 @@ def _lemire(x, m):
     return (pr & MASK64) >= ((1 << 64) % m), pr >> 64
 
 
+DRBG_PAIRED_MAX = 0x7F7F7F       # moduli up to here (m * m < 2^46): one 64-bit candidate word yields TWO draws
+
+
+def _lemire_pair(x, m):
+    """the PAIRED rule of sda-drbg-v1 for m <= DRBG_PAIRED_MAX: x m m = (ra m + rb) 2^64 + lo - Lemire's method with range m^2
+    (accept iff lo >= 2^64 mod m^2, value hi uniform in [0, m^2)) read off in two steps, x m = ra 2^64 + l1 and l1 m = rb 2^64 + lo
+    ("batched" bounded integers): (ra, rb) is a uniform pair in [0, m)^2"""
+    p1 = x * m
+    ra, l1 = p1 >> 64, p1 & MASK64
+    p2 = l1 * m
+    rb, lo = p2 >> 64, p2 & MASK64
+    return lo >= ((1 << 64) % (m * m)), (ra, rb)
+
+
+def _drbg_value_paired(kw, stream, b, T, i, m, rounds):
+    """draws 2j and 2j + 1 of a batch come from ONE candidate word: block counter (b >> 3) * ceil(T / 2) + j, the same lane / word
+    mapping as the unpaired rule; retry blocks are counted (b * ceil(T / 2) + j)"""
+    T2, j = (T + 1) // 2, i >> 1
+    o = chacha_block(_drbg_state(kw, (b >> 3) * T2 + j, stream, 0), rounds)
+    c, e = (b & 7) >> 1, b & 1
+    ok, pair = _lemire_pair((o[8 * e + c] << 32) | o[8 * e + 4 + c], m)
+    a = 1
+    while not ok and a < 256:
+        o2 = chacha_block(_drbg_state(kw, b * T2 + j, stream, a), rounds)
+        for q in range(8):
+            ok, pair = _lemire_pair((o2[2 * q] << 32) | o2[2 * q + 1], m)
+            if ok:
+                break
+        a += 1
+    return pair[i & 1]
+
+
 def drbg_value(key: bytes, stream: int, b: int, T: int, i: int, m: int, rounds: int = 20) -> int:
     """Draw i (of T) for batch b of stream `stream`, uniform in [0, m)."""
     kw = [int.from_bytes(key[4 * j:4 * j + 4], "little") for j in range(8)]
+    if m <= DRBG_PAIRED_MAX:
+        return _drbg_value_paired(kw, stream, b, T, i, m, rounds)
     o = chacha_block(_drbg_state(kw, (b >> 3) * T + i, stream, 0), rounds)
     c, e = (b & 7) >> 1, b & 1
     ok, val = _lemire((o[8 * e + c] << 32) | o[8 * e + 4 + c], m)

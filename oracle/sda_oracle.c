@@ -375,6 +375,17 @@ static int lemire(uint64_t x, uint64_t m, uint64_t thr, uint64_t* out) {
     return (uint64_t)pr >= thr;
 }
 
+/* the PAIRED rule for m <= 0x7F7F7F (m m < 2^46): one candidate word yields two draws - Lemire's method with range m^2, read off
+ * in two steps (x m = ra 2^64 + l1, l1 m = rb 2^64 + lo; accept iff lo >= 2^64 mod m^2): (ra, rb) uniform in [0, m)^2 */
+#define SDAO_DRBG_PAIRED_MAX 0x7F7F7Full
+static int lemire_pair(uint64_t x, uint64_t m, uint64_t thr2, uint64_t* ra, uint64_t* rb) {
+    u128 p1 = (u128)x * m;
+    *ra = (uint64_t)(p1 >> 64);
+    u128 p2 = (u128)(uint64_t)p1 * m;
+    *rb = (uint64_t)(p2 >> 64);
+    return (uint64_t)p2 >= thr2;
+}
+
 static void drbg_state(const uint32_t key[8], uint64_t I, uint64_t stream, uint32_t attempt, uint32_t st[16]) {
     memcpy(st, CHACHA_CONST, 16);
     memcpy(st + 4, key, 32);
@@ -416,6 +427,35 @@ void sdao_drbg_fill(const uint8_t key_bytes[32], int rounds, uint64_t stream, si
     const uint64_t thr = (uint64_t)((((u128)1) << 64) % m);
     const size_t groups = (batches + 7) / 8;
     uint32_t st[16], o[16];
+    if (m <= SDAO_DRBG_PAIRED_MAX) {
+        /* draws 2j, 2j + 1 of a batch from ONE candidate word: block counter g * ceil(T / 2) + j; retry blocks b * ceil(T / 2) + j */
+        const uint64_t thr2 = (uint64_t)((((u128)1) << 64) % ((u128)m * m));
+        const uint32_t T2 = (T + 1) / 2;
+        for (size_t g = 0; g < groups; ++g)
+            for (uint32_t j = 0; j < T2; ++j) {
+                drbg_state(key, (uint64_t)g * T2 + j, stream, 0, st);
+                sdao_chacha_block(st, rounds, o);
+                for (int c = 0; c < 4; ++c)
+                    for (int e = 0; e < 2; ++e) {
+                        size_t b = g * 8 + (size_t)(2 * c + e);
+                        if (b >= batches) continue;
+                        uint64_t x = ((uint64_t)o[8 * e + c] << 32) | o[8 * e + 4 + c], ra, rb;
+                        if (!lemire_pair(x, m, thr2, &ra, &rb)) {
+                            int done = 0;
+                            for (uint32_t a = 1; a < 256 && !done; ++a) {
+                                uint32_t st2[16], o2[16];
+                                drbg_state(key, (uint64_t)b * T2 + j, stream, a, st2);
+                                sdao_chacha_block(st2, rounds, o2);
+                                for (int q = 0; q < 8 && !done; ++q)
+                                    done = lemire_pair(((uint64_t)o2[2 * q] << 32) | o2[2 * q + 1], m, thr2, &ra, &rb);
+                            }
+                        }
+                        out[b * T + 2 * j] = (int64_t)ra;
+                        if (2 * j + 1 < T) out[b * T + 2 * j + 1] = (int64_t)rb;
+                    }
+            }
+        return;
+    }
     for (size_t g = 0; g < groups; ++g) {
         for (uint32_t i = 0; i < T; ++i) {
             drbg_state(key, (uint64_t)g * T + i, stream, 0, st);

@@ -42,4 +42,27 @@ __device__ __noinline__ uint64_t f_drbg_retry(uint32_t k0, uint32_t k1, uint32_t
     return val;
 }
 
+// the paired rule's retry stream (modarith.hpp): draw pair j of batch b, counter I = b * ceil(T / 2) + j
+template <int ROUNDS>
+__device__ __noinline__ uint64_t f_drbg_retry_pair(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t k4, uint32_t k5, uint32_t k6,
+                                                   uint32_t k7, uint64_t stream, uint64_t I, uint64_t m, uint64_t thr2) {
+    const uint32_t k[8] = {k0, k1, k2, k3, k4, k5, k6, k7};
+    uint32_t ra = 0, rb = 0;
+    for (uint32_t a = 1; a < 256; ++a) {
+        uint32_t o[16];
+        chacha_block_lane<ROUNDS>(k, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream, ((uint32_t)(stream >> 32) & 0xFFFFFFu) | (a << 24), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (lemire_pair(((uint64_t)o[2 * j] << 32) | o[2 * j + 1], (uint32_t)m, thr2, ra, rb)) return ((uint64_t)rb << 32) | ra;
+    }
+    return ((uint64_t)rb << 32) | ra;
+}
+// one candidate word -> the two draws of a pair (retry stream on the rare rejection); returns rb << 32 | ra
+template <int ROUNDS>
+__device__ __forceinline__ uint64_t f_draw_pair(uint64_t xw, const uint32_t (&kk)[8], uint64_t stream, uint64_t retry_I, uint64_t m, uint64_t thr2) {
+    uint32_t ra, rb;
+    if (__builtin_expect(lemire_pair(xw, (uint32_t)m, thr2, ra, rb), 1)) return ((uint64_t)rb << 32) | ra;
+    return f_drbg_retry_pair<ROUNDS>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream, retry_I, m, thr2);
+}
+
 }  // namespace sda

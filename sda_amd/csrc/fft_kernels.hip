@@ -180,6 +180,31 @@ __global__ __launch_bounds__(1024) void packed_gen_fft_kernel(GenLayout L, ModPa
             const uint64_t b = b_first + j;
             X[(size_t)j * m2 + 1 + k + i] = (V)(b < batches ? canon_i64(rp[b * t + i], mod.m, mod.mu) : 0);
         }
+    } else if (drbg_paired(mod.m)) {          // the paired rule (modarith.hpp): one block = draws 2j, 2j + 1 of 8 consecutive batches
+        const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
+        const uint32_t t2 = (t + 1u) >> 1;
+        const uint32_t per = G >= 8 ? 8u : G, off = G >= 8 ? 0u : (uint32_t)(b_first & 7);       // batches of a block group this workgroup holds
+        const uint32_t blocks = G >= 8 ? (G >> 3) : 1u;
+        for (uint32_t u = tid; u < blocks * t2; u += T) {
+            const uint32_t nb = u / t2, j = u - nb * t2;
+            const uint64_t grp = G >= 8 ? (g * (G >> 3) + nb) : (b_first >> 3);
+            const uint64_t I = grp * (uint64_t)t2 + j;
+            uint32_t o[16];
+            chacha_block_lane<ROUNDS>(kk, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream, (uint32_t)(stream >> 32) & 0xFFFFFFu, o);
+            for (uint32_t jj = 0; jj < per; ++jj) {
+                const uint32_t w8 = off + jj, want_hi = 8u * (w8 & 1u) + (w8 >> 1), want_lo = want_hi + 4u;
+                uint32_t hi = 0, lo = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) {                              // o[] lives in registers: select, do not index
+                    if ((uint32_t)w == want_hi) hi = o[w];
+                    if ((uint32_t)w == want_lo) lo = o[w];
+                }
+                const uint64_t bl = 8u * nb + jj;                          // batch inside the workgroup's group
+                const uint64_t pr = f_draw_pair<ROUNDS>(((uint64_t)hi << 32) | lo, kk, stream, (b_first + bl) * (uint64_t)t2 + j, mod.m, mod.lemire_thr);
+                X[(size_t)bl * m2 + 1 + k + 2u * j] = (V)(uint32_t)pr;
+                if (2u * j + 1u < t) X[(size_t)bl * m2 + 2 + k + 2u * j] = (V)(uint32_t)(pr >> 32);
+            }
+        }
     } else if (G >= 8) {                      // one CSPRNG block serves draw i of 8 consecutive batches; G / 8 such blocks of 8
         const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
         for (uint32_t u = tid; u < (G >> 3) * t; u += T) {

@@ -145,6 +145,25 @@ SDA_HD bool lemire_sample(uint64_t x, uint64_t m, uint64_t lemire_thr, uint64_t&
     return pr.lo >= lemire_thr;
 }
 
+// ---- the PAIRED rule of sda-drbg-v1 (round 5) for moduli m <= kDrbgPairedMax (m m < 2^46): ONE 64-bit candidate word yields TWO
+// draws.  x m m = (ra m + rb) 2^64 + lo is Lemire's method with range m^2 - accept iff lo >= 2^64 mod m^2, then ra m + rb is uniform
+// in [0, m^2) - read off in two steps, x m = ra 2^64 + l1 and l1 m = rb 2^64 + lo ("batched" bounded integers): (ra, rb) is a
+// uniform pair in [0, m)^2, with a rejection probability below 2^-18.  Draws 2j and 2j + 1 of a batch are such a pair; the block
+// counter of draw pair j of batch group g is g * ceil(T / 2) + j.  ModParams::lemire_thr holds 2^64 mod m^2 for these moduli.
+// 155 draws per batch of tss's PSS_155_728_100 then cost 78 candidate words instead of 155 (the ChaCha20 blocks are a third of
+// that kernel's vector work).  Spec: DESIGN.md (sda-drbg-v1); vectors: tests/golden/drbg.json.
+static constexpr uint64_t kDrbgPairedMax = 0x7F7F7Full;
+SDA_HD bool drbg_paired(uint64_t m) { return m <= kDrbgPairedMax; }
+SDA_HD bool lemire_pair(uint64_t x, uint32_t m, uint64_t thr2, uint32_t& ra, uint32_t& rb) {
+    const uint64_t t0 = (uint64_t)(uint32_t)x * m;
+    const uint64_t t1 = (uint64_t)(uint32_t)(x >> 32) * m + (t0 >> 32);                 // x m = t1 2^32 + lo32(t0), t1 < 2^55
+    ra = (uint32_t)(t1 >> 32);
+    const uint64_t u0 = (uint64_t)(uint32_t)t0 * m;                                     // l1 = lo32(t1) 2^32 + lo32(t0)
+    const uint64_t u1 = (uint64_t)(uint32_t)t1 * m + (u0 >> 32);
+    rb = (uint32_t)(u1 >> 32);
+    return ((u1 << 32) | (uint32_t)u0) >= thr2;
+}
+
 // ---- host-only helpers (plain host functions: parsed but never emitted in the device pass) ------
 inline uint64_t h_mulmod(uint64_t a, uint64_t b, uint64_t m) { return (uint64_t)(((u128)a * b) % m); }
 
@@ -183,7 +202,8 @@ inline uint64_t h_barrett_mu(uint64_t m) {           // floor(2^64 / m), m >= 2
     return (uint64_t)((((u128)1) << 64) / m);
 }
 
-inline uint64_t h_lemire_thr(uint64_t m) {           // 2^64 mod m
+inline uint64_t h_lemire_thr(uint64_t m) {           // 2^64 mod m; for the paired rule's moduli 2^64 mod m^2
+    if (drbg_paired(m)) return (uint64_t)((((u128)1) << 64) % ((u128)m * m));
     return (uint64_t)((((u128)1) << 64) % m);
 }
 

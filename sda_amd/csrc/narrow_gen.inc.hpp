@@ -29,6 +29,10 @@ __device__ __forceinline__ bool lemire_sample_m32(uint64_t x, uint32_t m, uint64
 template <int ROUNDS>
 __device__ __forceinline__ void drbg_pair_m32(const DrbgKey& key, const QuadCol& qc, uint64_t stream, uint64_t pair, uint32_t T,
                                               uint32_t i, const ModParams& mod, uint64_t& r0, uint64_t& r1) {
+    if (drbg_paired(mod.m)) {                               // uniform: the paired rule (modarith.hpp) lives in drbg_pair
+        drbg_pair<ROUNDS>(key, qc, stream, pair, T, i, mod, r0, r1);
+        return;
+    }
     const uint32_t c = threadIdx.x & 3;
     const uint64_t I = (pair >> 2) * (uint64_t)T + i;
     const uint32_t ctr = c == 0 ? (uint32_t)I : c == 1 ? (uint32_t)(I >> 32) : c == 2 ? (uint32_t)stream

@@ -19,10 +19,14 @@
 // laid out fragment by fragment ([row tile][64-term step][digit][lane] 16 bytes).  The LOADER wave streams those tiles
 // global -> LDS with global_load_lds_dwordx4 into a ring of slots, two tiles ahead, with counted s_waitcnt vmcnt - it has no
 // stores in its in-order counter, so no tile ever waits for share stores to be acknowledged; the compute waves read the
-// fragments back with conflict-free 16-byte LDS loads.  Shares leave as 128-byte row segments (16 batches x 8 bytes),
-// non-temporal.  Values reach the B-operand layout through an LDS tile [digit][batch][64 terms], one 64-term step at a time;
-// the draws are the per-lane sda-drbg-v1 blocks of the transform kernel (one block = draw i of 8 consecutive batches), so
-// both kernels produce identical shares from identical inputs and keys.  With the library's own randomness the draws ARE
+// fragments back with conflict-free 16-byte LDS loads.  A wave multiplies, reduces and stores ONE of its NT batch tiles at a
+// time (five accumulators, not 5 NT: the loop must fit the 168 registers that three waves per SIMD leave, see the row loop);
+// column c of batch tile nt is batch NT c + nt of the wave, so a lane owns adjacent batch columns and shares leave as 16-byte
+// non-temporal buffer stores (row pointer in a scalar descriptor, one 32-bit lane offset), 256-byte row segments.
+// Values reach the B-operand layout through an LDS tile [digit][batch][64 terms], one 64-term step at a time; the draws are
+// sda-drbg-v1's PAIRED rule (every prime of this kernel is in its domain): one lane = one ChaCha20 block = draws 2j and 2j + 1
+// of 8 consecutive batches, the same words the transform kernel reads, so both produce identical shares from
+// identical inputs and keys.  With the library's own randomness the draws ARE
 // shares 0..t-1 (systematic share map, include/sda_hip.h) and the matrix has only the other n - t rows.
 // Measurements behind these choices (MFMA / vector co-issue, the vmcnt trap, the half-period offset of the wave pairs):
 // DESIGN.md 4 "Narrow limb GEMM".
@@ -30,6 +34,8 @@
 // Exactness and every bound (digits, columns, the reduction's operand): tests/test_ngemm_model.py.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "capi_internal.hpp"
 #include "chacha.hpp"
@@ -41,6 +47,8 @@
 namespace sda {
 
 typedef int ng_v4i __attribute__((ext_vector_type(4)));
+typedef unsigned int ng_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int ng_v2u __attribute__((ext_vector_type(2)));
 
 static constexpr int kNgCompute = 8;                // compute waves per workgroup (two per SIMD), one workgroup per CU
 static constexpr int kNgWorkers = 64 * kNgCompute;
@@ -155,27 +163,31 @@ __device__ __noinline__ void ng_load_pass(uint8_t* Bt, const int64_t* sp, const 
     }
 }
 
-// the CSPRNG draws d_lo .. d_lo + cd - 1 of the workgroup's batches -> digit tile (sda-drbg-v1, one block = draw i of 8 batches)
+// the CSPRNG draws d_lo .. d_lo + cd - 1 of the workgroup's batches -> digit tile.  Every prime this kernel takes (p <= 0x7F7F7F) is
+// in the domain of sda-drbg-v1's PAIRED rule (modarith.hpp): one lane = one block = draws 2j AND 2j + 1 of 8 batches - 78 blocks per
+// 8 batches of PSS_155_728_100 instead of 155.  A pair that straddles two 64-term steps is computed in both (each step writes the
+// element that falls into its term range).
 template <int WGB>
 __device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t stream, uint64_t b0, uint32_t k, uint32_t t, uint32_t t_lo,
                                           uint32_t d_lo, uint32_t cd, uint64_t m, uint64_t lemire_thr) {
     ng_lptr B = (ng_lptr)Bt;
     const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
+    const uint32_t d_hi = d_lo + cd, t2 = (t + 1u) >> 1, j_lo = d_lo >> 1, cp = ((d_hi - 1u) >> 1) - j_lo + 1u;   // cd >= 1
 #pragma unroll 1
-    for (uint32_t u = threadIdx.x; u < (uint32_t)(WGB / 8) * cd; u += kNgWorkers) {
-        const uint32_t nb = u / cd, i = d_lo + (u - nb * cd);
-        const uint64_t I = ((b0 >> 3) + nb) * (uint64_t)t + i;
+    for (uint32_t u = threadIdx.x; u < (uint32_t)(WGB / 8) * cp; u += kNgWorkers) {
+        const uint32_t nb = u / cp, j = j_lo + (u - nb * cp);
+        const uint64_t I = ((b0 >> 3) + nb) * (uint64_t)t2 + j;
         uint32_t o[16];
         chacha_block_lane<20>(kk, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream, (uint32_t)(stream >> 32) & 0xFFFFFFu, o);
+        const uint32_t i0 = 2u * j, i1 = i0 + 1u;
+        const bool w0 = i0 >= d_lo, w1 = i1 < d_hi;                            // (i0 < d_hi and i1 >= d_lo hold by construction)
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int cc = jj >> 1, e = jj & 1;
             const uint64_t xw = ((uint64_t)o[8 * e + cc] << 32) | o[8 * e + 4 + cc];
-            uint64_t val;
-            if (!f_lemire32(xw, (uint32_t)m, lemire_thr, val))
-                val = f_drbg_retry<20>(kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], kk[6], kk[7], stream,
-                                       (b0 + 8u * nb + jj) * (uint64_t)t + i, m, lemire_thr);
-            ng_put(B, WGB, 8u * nb + jj, k + i - t_lo, ng_digits((uint32_t)val));
+            const uint64_t pr = f_draw_pair<20>(xw, kk, stream, (b0 + 8u * nb + jj) * (uint64_t)t2 + j, m, lemire_thr);
+            if (w0) ng_put(B, WGB, 8u * nb + jj, k + i0 - t_lo, ng_digits((uint32_t)pr));
+            if (w1) ng_put(B, WGB, 8u * nb + jj, k + i1 - t_lo, ng_digits((uint32_t)(pr >> 32)));
         }
     }
 }
@@ -254,7 +266,7 @@ __device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS][3], uint8_t* Bt
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int lb = 0; lb < 3; ++lb)
-                bfrag[nt][STEP][lb] = *reinterpret_cast<const ng_v4i*>(Bt + ((size_t)lb * WGB + wave * WB + 16 * nt + col) * kNgRow + 16 * g);
+                bfrag[nt][STEP][lb] = *reinterpret_cast<const ng_v4i*>(Bt + ((size_t)lb * WGB + wave * WB + NT * col + nt) * kNgRow + 16 * g);   // column col of batch tile nt = batch NT col + nt of the wave (see the row tiles' stores)
     }
     __syncthreads();
 #ifdef NG_TIMING
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     // ---- values -> B fragments, one 64-term step at a time -------------------------------------------------------------------
 #ifdef NG_TIMING
     const uint64_t ng_t0 = __builtin_readcyclecounter();
+    const uint64_t ng_w0 = wall_clock64();
 #endif
     ng_v4i bfrag[NT][KS][3];
     int64_t* op = L.out + p * L.out_stride_participant;
@@ -361,78 +374,148 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         }
         return;
     }
-    // this lane's output rows: 4 g + i of every tile, batch column bw (+ 16 per batch tile)
-    const uint64_t bw = b0 + wave * WB + col;
+    // this lane's output rows: 4 g + i of every tile; its batch columns: bw + nt, ADJACENT (column col of batch tile nt is batch
+    // NT col + nt of the wave), so that a lane stores two shares of a row with one 16-byte instruction: the CU's address path
+    // takes a wave's store lane by lane, and 4 NT instructions of 8 bytes per lane and tile kept it busy for a fifth of the
+    // row-tile phase (measured with the stores compiled out: 189k -> 147k cycles per workgroup of PSS_155_728_100)
+    const uint32_t bl = wave * WB + (uint32_t)NT * col;            // first of this lane's batch columns, inside the workgroup
     // (systematic share map: the matrix has the rows direct_rows .. n - 1, rows 0 .. direct_rows - 1 were the draws)
-    int64_t* orow = op + bw + (size_t)((rp ? 0u : L.direct_rows) + 4u * g) * L.out_stride_clerk;
-    const size_t tile_step = 16 * L.out_stride_clerk;
+    // Addresses: a UNIFORM row pointer (scalar registers, stepped by 16 rows per tile) plus ONE 32-bit lane offset (column and
+    // row 4 g) - row pointers per lane were 10 vector registers of a loop that has none to spare (see finish()).
+    const char* obase = reinterpret_cast<const char*>(op + b0 + (size_t)(rp ? 0u : L.direct_rows) * L.out_stride_clerk);
+    const size_t row_bytes = L.out_stride_clerk * sizeof(int64_t);
+    const uint32_t loff = bl * 8u + 4u * g * (uint32_t)row_bytes;  // (the fast path asks for 16 rows below 4 GiB)
     const int32_t c0 = ng_pin_vgpr(P.c[0]), c1 = ng_pin_vgpr(P.c[1]), c2 = ng_pin_vgpr(P.c[2]), c3 = ng_pin_vgpr(P.c[3]), c4 = ng_pin_vgpr(P.c[4]);
-    // The two compute waves of a SIMD run half a period apart: waves 0-3 multiply tile r and THEN reduce and store it, waves 4-7
-    // first reduce and store tile r - 1 and then multiply tile r - so one wave's products run beside the other's vector work.
-    // (With every wave in the same order the per-tile barrier keeps all of them in lockstep: all on the matrix cores, then all on
-    // the vector ALUs - 3700 cycles per tile where 2300 are matrix-core time, measured.)
+    // One batch tile (16 batches) at a time: multiply it (9 KS matrix instructions into five 32-bit column sums), reduce and store
+    // it, then the wave's next batch tile of the same row tile.  With all NT batch tiles in flight at once (as in rounds 4 and 5)
+    // the loop needed every register the wave has and the compiler kept B fragments in scratch memory, reloaded each tile behind
+    // an s_waitcnt vmcnt(0) that ALSO waited for every share store in flight - a quarter of the row-tile phase, and a kernel
+    // whose speed followed the register allocator's mood (+- 15 % between builds that differed in unrelated code).  The price:
+    // each A fragment is read from LDS NT times (NT 12 KS KiB per wave and tile; the LDS has the bandwidth).
+    // The two compute waves of a SIMD run one PHASE apart: waves 0-3 multiply a batch tile and then reduce it, waves 4-7 reduce
+    // their previous batch tile first and multiply then - so one wave's products run beside the other's vector work.  (With every
+    // wave in the same order the per-tile barrier keeps all of them in lockstep: all on the matrix cores, then all on the vector
+    // ALUs - 3700 cycles per tile where 2300 are matrix-core time, measured.)
     const bool late = wave >= (uint32_t)(kNgCompute / 2);
-    ng_v4i acc[NT][5];
-    auto products = [&](uint32_t slot_) {
+    // every B fragment in a register HERE: the staging steps park fragments in scratch memory around their calls, and left to itself
+    // the register allocator reloads some of them where they are used first - inside the loop, every tile, behind an
+    // s_waitcnt vmcnt(0) that also waits for the wave's share stores
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int lb = 0; lb < 3; ++lb) asm volatile("" : "+v"(bfrag[nt][ks][lb]));
+    ng_v4i acc[5];
+    auto products = [&](uint32_t slot_, auto ntc) {
+        constexpr int nt = decltype(ntc)::value;
         const uint8_t* Acur = Abuf + slot_ * ATILE;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) acc[nt][c] = ng_v4i{0, 0, 0, 0};
+        for (int c = 0; c < 5; ++c) acc[c] = ng_v4i{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int la = 0; la < 3; ++la) {
                 const ng_v4i a = *reinterpret_cast<const ng_v4i*>(Acur + ((size_t)(ks * 3 + la) * 64 + lane) * 16);
 #pragma unroll
-                for (int lb = 0; lb < 3; ++lb)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt][la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bfrag[nt][ks][lb], acc[nt][la + lb], 0, 0, 0);
+                for (int lb = 0; lb < 3; ++lb) acc[la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bfrag[nt][ks][lb], acc[la + lb], 0, 0, 0);
             }
     };
-    // shares = rows 16 rt + 4 g + i of tile rt, canonical, clerk-major (batched.rs:46-48): all of them first (straight-line
-    // code), then the stores under their masks
-    auto finish = [&](uint32_t rt) {
-        uint32_t share[NT][4];
+    // uniform: every batch column of the workgroup exists, 16-byte stores are aligned, a tile's 16 rows span less than 4 GiB
+    const bool near = row_bytes < (1ull << 28);                     // 16 rows of a tile within the 4 GiB a buffer descriptor spans
+    const bool whole = near && b0 + WGB <= batches && ((reinterpret_cast<uintptr_t>(op) | row_bytes) & 15u) == 0;
+    auto reduce1 = [&](int i) {
+        int64_t S = ng_mad(c0, acc[0][i], 0);
+        S = ng_mad(c1, acc[1][i], S);
+        S = ng_mad(c2, acc[2][i], S);
+        S = ng_mad(c3, acc[3][i], S);
+        S = ng_mad(c4, acc[4][i], S);
+        return ng_redc(S, P.np);
+    };
+    // shares = rows 16 rt + 4 g + i of tile rt, canonical, clerk-major (batched.rs:46-48).
+    // A WHOLE tile (all but a participant's last chunk / the last row tile): no masks.  The shares of an even batch tile wait
+    // (four registers) for those of the next one, a lane's two adjacent columns leave as one 16-byte store.  Buffer stores: the
+    // tile's row pointer in a scalar descriptor, row i as the scalar offset, the lane offset in ONE vector register.
+    uint32_t held[4] = {0, 0, 0, 0};
+    auto finish_whole = [&](uint32_t rt, auto ntc) {
+        constexpr int nt = decltype(ntc)::value;
+        if constexpr (NT > 1 && nt % 2 == 0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int i = 0; i < 4; ++i) held[i] = reduce1(i);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(obase) + (size_t)rt * 16u * row_bytes, 0, 0xFFFFFFFFu, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int64_t S = ng_mad(c0, acc[nt][0][i], 0);
-                S = ng_mad(c1, acc[nt][1][i], S);
-                S = ng_mad(c2, acc[nt][2][i], S);
-                S = ng_mad(c3, acc[nt][3][i], S);
-                S = ng_mad(c4, acc[nt][4][i], S);
-                share[nt][i] = ng_redc(S, P.np);
-                asm volatile("" : "+v"(share[nt][i]));
+                const uint32_t soff = (uint32_t)i * (uint32_t)row_bytes;
+                if constexpr (NT == 1) {
+                    const ng_v2u v = {reduce1(i), 0u};
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff, soff, 2);                    // aux 2: non-temporal
+                } else {
+                    const ng_v4u v = {held[i], 0u, reduce1(i), 0u};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, loff + 8 * (nt - 1), soff, 2);
+                }
             }
+        }
+    };
+    // any tile: one share at a time under its mask - the same addressing, so that this path keeps two registers (lim, 4 g) alive
+    // through the loop and not a set of row pointers
+    const uint32_t lim = b0 + bl >= batches ? 0u : (batches - b0 - bl > (uint64_t)NT ? (uint32_t)NT : (uint32_t)(batches - b0 - bl));   // this lane's batch columns that exist
+    auto finish_masked = [&](uint32_t rt, auto ntc) {
+        constexpr int nt = decltype(ntc)::value;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(obase) + (size_t)rt * 16u * row_bytes, 0, 0xFFFFFFFFu, 0x00020000);
         const uint32_t row0 = 16u * rt + 4u * g;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            if (bw + 16u * nt < batches) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (row0 + (uint32_t)i < P.n)
-                        __builtin_nontemporal_store((long long)share[nt][i], reinterpret_cast<long long*>(orow + (size_t)i * L.out_stride_clerk + 16 * nt));
-            }
-        orow += tile_step;
+        for (int i = 0; i < 4; ++i) {
+            const ng_v2u v = {reduce1(i), 0u};
+            if ((uint32_t)nt < lim && row0 + (uint32_t)i < P.n) __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff + 8 * nt, (uint32_t)i * (uint32_t)row_bytes, 2);
+        }
     };
+    // clerk rows 256 MiB or more apart (33 M batches of one tile): plain 64-bit addresses, computed here and now (the inputs pass
+    // through an empty asm so that nothing of this is kept in registers through the loop)
+    auto finish_far = [&](uint32_t rt, auto ntc) {
+        constexpr int nt = decltype(ntc)::value;
+        uint32_t gg = g, bb = bl;
+        asm volatile("" : "+v"(gg), "+v"(bb));
+        const uint32_t row0 = 16u * rt + 4u * gg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t v = reduce1(i);
+            if ((uint32_t)nt < lim && row0 + (uint32_t)i < P.n)
+                __builtin_nontemporal_store((long long)v, reinterpret_cast<long long*>(const_cast<char*>(obase) + (size_t)(row0 + (uint32_t)i) * row_bytes) + bb + nt);
+        }
+    };
+    // whole_tiles: the row tiles this workgroup stores without masks
+    const uint32_t whole_tiles = whole ? (P.n / 16u < tiles ? P.n / 16u : tiles) : 0u;
+    typedef std::integral_constant<int, NT - 1> NtLast;
     uint32_t slot = 0;
+    auto finish = [&](uint32_t rt, auto ntc) {
+        if (rt < whole_tiles) finish_whole(rt, ntc); else if (near) finish_masked(rt, ntc); else finish_far(rt, ntc);
+        __builtin_amdgcn_sched_barrier(0);                          // the next batch tile's matrix instructions stay behind this reduction
+    };
     for (uint32_t rt = 0; rt < tiles; ++rt) {
-        if (late && rt) finish(rt - 1);
-        products(slot);
+        if (late && rt) finish(rt - 1, NtLast{});                   // (a late wave's last batch tile is reduced in front of its next products)
+        auto phase = [&](auto ntc) {                                // one batch tile of the row tile
+            products(slot, ntc);
+            if (!late || decltype(ntc)::value + 1 < NT) finish(rt, ntc);
+        };
+        phase(std::integral_constant<int, 0>{});
+        if constexpr (NT > 1) phase(std::integral_constant<int, 1>{});
+        if constexpr (NT > 2) { phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{}); }
         slot = slot + 1 == (uint32_t)DEPTH ? 0u : slot + 1;
-        if (!late) finish(rt);
         __syncthreads();                                            // tile rt + 1 is in LDS (the loader waited for it); slot of tile rt is free
     }
-    if (late && tiles) finish(tiles - 1);                           // (a systematic plan with n == t has no matrix rows at all)
+    if (late && tiles) finish(tiles - 1, NtLast{});                 // (a systematic plan with n == t has no matrix rows at all)
 #ifdef NG_TIMING
     if (tid == 0) {                                                 // timing build only: overwrites two shares with cycle counts
         int64_t* o = L.out + p * L.out_stride_participant + b0;
         o[0] = (int64_t)(ng_t1 - ng_t0);
         o[1] = (int64_t)(__builtin_readcyclecounter() - ng_t1);
         o[2] = (int64_t)ng_tm[0]; o[3] = (int64_t)ng_tm[1]; o[4] = (int64_t)ng_tm[2]; o[5] = (int64_t)ng_tm[3];
+        o[6] = (int64_t)ng_w0; o[7] = (int64_t)wall_clock64();        // 100 MHz: the workgroup's start and end on the device's constant clock
+    }
+    if (lane == 0) {                                                // every compute wave's own staging passes
+        int64_t* o = L.out + p * L.out_stride_participant + b0 + 8 + 4 * wave;
+        o[0] = (int64_t)ng_tm[0]; o[1] = (int64_t)ng_tm[1]; o[2] = (int64_t)ng_tm[2]; o[3] = (int64_t)ng_tm[3];
     }
 #endif
 }

@@ -40,6 +40,9 @@ typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 //     acceptance     : Lemire: accept iff lo64(x * m) >= 2^64 mod m; value = hi64(x * m).
 //     retry (rare)   : attempt a = 1, 2, ...: block with words 12,13 = b * T + i, word 15 |= a << 24;
 //                      candidates x_j = (out[2j] << 32) | out[2j+1], j = 0..7, first accepted wins.
+//   moduli m <= 0x7F7F7F (round 5, the PAIRED rule - modarith.hpp): draws 2j, 2j + 1 of a batch come from ONE candidate word
+//                      (Lemire with range m^2); main block counter I = (b >> 3) * ceil(T / 2) + j, retry counter
+//                      b * ceil(T / 2) + j, same lanes and words.
 // =================================================================================================
 // Everything by value: a by-reference key would force a scratch copy of it at kernel entry
 // (measured: +11 GB of HBM writes per 2000-participant launch).
@@ -60,6 +63,23 @@ __device__ __noinline__ uint64_t drbg_retry(uint32_t k0, uint32_t k1, uint32_t k
         }
     }
     return val;
+}
+// the paired rule's retry stream: draw pair j of batch b (counter I = b * ceil(T / 2) + j); returns element `which` of the pair
+template <int ROUNDS>
+__device__ __noinline__ uint64_t drbg_retry_pair(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t k4, uint32_t k5,
+                                                 uint32_t k6, uint32_t k7, uint64_t stream, uint64_t I, uint64_t m, uint64_t thr2,
+                                                 uint32_t which) {
+    const uint32_t k[8] = {k0, k1, k2, k3, k4, k5, k6, k7};
+    uint32_t ra = 0, rb = 0;
+    for (uint32_t a = 1; a < 256; ++a) {
+        uint32_t o[16];
+        chacha_block_lane<ROUNDS>(k, (uint32_t)I, (uint32_t)(I >> 32), (uint32_t)stream,
+                                  ((uint32_t)(stream >> 32) & 0xFFFFFFu) | (a << 24), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (lemire_pair(((uint64_t)o[2 * j] << 32) | o[2 * j + 1], (uint32_t)m, thr2, ra, rb)) return which ? rb : ra;
+    }
+    return which ? rb : ra;
 }
 
 // this lane's column of the ChaCha input state (lane c = lane id & 3 of a DPP quad): constant, key
@@ -84,13 +104,31 @@ __device__ __forceinline__ void drbg_pair(const DrbgKey& key, const QuadCol& qc,
                                           uint32_t T, uint32_t i, const ModParams& mod, uint64_t& r0, uint64_t& r1) {
     const uint32_t c = threadIdx.x & 3;
     const uint64_t g = pair >> 2;                       // batch group of 8 = one quad
-    const uint64_t I = g * (uint64_t)T + i;
+    const bool paired = drbg_paired(mod.m);             // uniform: draw i is element i & 1 of draw pair i >> 1 (this form computes the
+                                                        // pair's block for each of its elements; the lane forms of the large-shape
+                                                        // kernels, where the draws dominate, take both from one block)
+    const uint32_t T2 = (T + 1) >> 1, j = i >> 1;
+    const uint64_t I = paired ? g * (uint64_t)T2 + j : g * (uint64_t)T + i;
     const uint32_t ctr = c == 0 ? (uint32_t)I : c == 1 ? (uint32_t)(I >> 32) : c == 2 ? (uint32_t)stream
                                                                               : ((uint32_t)(stream >> 32) & 0xFFFFFFu);
     uint32_t o0, o1, o2, o3;
     chacha_block_quad<ROUNDS>(qc.cst, qc.kb, qc.kc, ctr, o0, o1, o2, o3);
     const uint64_t x0 = ((uint64_t)o0 << 32) | o1;
     const uint64_t x1 = ((uint64_t)o2 << 32) | o3;
+    if (paired) {
+        uint32_t a0, b0, a1, b1;
+        const bool ok0 = lemire_pair(x0, (uint32_t)mod.m, mod.lemire_thr, a0, b0);
+        const bool ok1 = lemire_pair(x1, (uint32_t)mod.m, mod.lemire_thr, a1, b1);
+        r0 = (i & 1u) ? b0 : a0;
+        r1 = (i & 1u) ? b1 : a1;
+        if (__builtin_expect(!ok0, 0))
+            r0 = drbg_retry_pair<ROUNDS>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
+                                         (2 * pair) * (uint64_t)T2 + j, mod.m, mod.lemire_thr, i & 1u);
+        if (__builtin_expect(!ok1, 0))
+            r1 = drbg_retry_pair<ROUNDS>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
+                                         (2 * pair + 1) * (uint64_t)T2 + j, mod.m, mod.lemire_thr, i & 1u);
+        return;
+    }
     const bool ok0 = lemire_sample(x0, mod.m, mod.lemire_thr, r0);
     const bool ok1 = lemire_sample(x1, mod.m, mod.lemire_thr, r1);
     if (__builtin_expect(!ok0, 0))

@@ -181,7 +181,11 @@ def main():
     key = bytes(range(32))
     drbg = {"key_hex": key.hex(), "cases": []}
     for (stream, batches, T, m, rounds) in [(0, 19, 1, P, 20), (5, 9, 4, P, 20), (2 ** 40 + 3, 17, 2, 433, 20),
-                                            (7, 16, 2, (1 << 61) + 1, 20), (1, 10, 3, P, 12), (1, 10, 3, P, 8)]:
+                                            (7, 16, 2, (1 << 61) + 1, 20), (1, 10, 3, P, 12), (1, 10, 3, P, 8),
+                                            # the PAIRED rule (moduli <= 0x7F7F7F: one candidate word -> two draws), odd and even T,
+                                            # its upper edge and the first modulus above it
+                                            (3, 17, 3, 433, 20), (11, 9, 5, 746497, 20), (4, 16, 2, 0x7F7F7F, 20),
+                                            (4, 16, 2, 0x7F7F80, 20), (9, 10, 3, 433, 12), (6, 24, 1, 5038849, 8)]:
         drbg["cases"].append({"stream": stream, "batches": batches, "T": T, "modulus": m, "rounds": rounds,
                               "values": po.drbg_fill(key, stream, batches, T, m, rounds)})
     drbg["call_keys"] = [{"call_index": i, "key_hex": po.drbg_call_key(key, i).hex()} for i in (0, 1, 2, (1 << 32) + 5)]

@@ -113,6 +113,42 @@ def test_narrow_limb_gemm_odd_strides_and_clerk_major_layout(gpu):
     assert not out[:, :, B:].any()
 
 
+@pytest.mark.parametrize("form", ["far", "unaligned", "aligned"])
+def test_narrow_limb_gemm_store_paths(gpu, form):
+    """the three ways a share leaves the limb GEMM (ngemm_kernels.hip, finish_whole / finish_masked / finish_far), each with whole
+    workgroups (256 batches) AND a ragged last one, a ragged last row tile (n - t = 13) and two participants:
+    aligned - 16-byte buffer stores, two adjacent batch columns per lane; unaligned (base + 8 bytes, odd strides) - 8-byte buffer
+    stores under masks; far - clerk rows 256 MiB apart (more than a buffer descriptor's 32-bit offsets reach in 16 rows): plain
+    64-bit addresses.  Nothing may be written outside the rows' first B columns."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    p, k, t, n = TSS_P1, 10, 7, 20
+    w2, w3 = _root(p, 32), _root(p, 27)
+    dim, P, first = 10 * 600 + 3, 2, 9
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    B = gen.batch_count(dim)
+    assert B == 601
+    Bs = B + 7 if form != "unaligned" else B + 6                    # 608 (even) / 607 (odd)
+    stride_clerk = {"far": (1 << 25) + 2, "unaligned": P * Bs + 1, "aligned": P * Bs}[form]
+    shift = 1 if form == "unaligned" else 0
+    rng = np.random.default_rng(17)
+    sec = rng.integers(-(1 << 62), 1 << 62, size=(P, dim), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec)
+    d_out = DeviceBuffer(n * stride_clerk + shift).zero()
+    gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr + 8 * shift, Bs, stride_clerk, first_participant=first)
+    assert capi_last_kernel().startswith("packed_gen_ngemm_kernel")
+    rows = np.stack([d_out.to_numpy(P * Bs, shift + j * stride_clerk) for j in range(n)]).reshape(n, P, Bs)
+    for q in range(P):
+        want = coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[q], coracle.drbg_fill(KEY, first + q, B, t, p), gen.csprng_share_map())
+        assert np.array_equal(rows[:, q, :B], want), q
+    assert not rows[:, :, B:].any()
+    if form == "unaligned":                                         # the element between two clerk rows, and the one in front of the base
+        assert not any(d_out.to_numpy(1, shift + j * stride_clerk + P * Bs)[0] for j in range(n - 1)) and d_out.to_numpy(1)[0] == 0
+
+
 def test_narrow_limb_gemm_share_combine_reveal_roundtrip(gpu):
     """tss's PSS_155_728_100 over tss's prime through the pipelined step (the dual-role launch: share generation of tile i and the
     clerk sum of tile i - 1 in one grid), clerk sums against the oracle, then the reveal from an arbitrary t + k clerks = the sum

@@ -223,6 +223,57 @@ def test_drbg_spec_c_equals_python_and_golden():
     assert coracle.drbg_fill(key, 3, 300, 2, m).tolist() == po.drbg_fill(key, 3, 300, 2, m)
 
 
+def _np_chacha20_words(key_words, counters, stream):
+    """ChaCha20 blocks of sda-drbg-v1's attempt-0 layout for an array of block counters, vectorised (test-local; the block
+    function itself is pinned by the RFC 7539 vectors above): returns a (16, len) uint32 array"""
+    n = len(counters)
+    st = [np.full(n, c, dtype=np.uint32) for c in po.CHACHA_CONST] + [np.full(n, w, dtype=np.uint32) for w in key_words]
+    st += [(counters & 0xFFFFFFFF).astype(np.uint32), (counters >> 32).astype(np.uint32),
+           np.full(n, stream & 0xFFFFFFFF, dtype=np.uint32), np.full(n, (stream >> 32) & 0xFFFFFF, dtype=np.uint32)]
+    x = [v.copy() for v in st]
+
+    def rot(v, r):
+        return (v << np.uint32(r)) | (v >> np.uint32(32 - r))
+
+    def qr(a, b, c, d):
+        x[a] += x[b]; x[d] = rot(x[d] ^ x[a], 16)
+        x[c] += x[d]; x[b] = rot(x[b] ^ x[c], 12)
+        x[a] += x[b]; x[d] = rot(x[d] ^ x[a], 8)
+        x[c] += x[d]; x[b] = rot(x[b] ^ x[c], 7)
+
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return np.stack([x[i] + st[i] for i in range(16)])
+
+
+def test_drbg_paired_rule_retry_stream():
+    """the PAIRED rule (moduli <= 0x7F7F7F) rejects a candidate word with probability below 2^-18, so the retry stream is found,
+    not forced: every candidate word of 6 Mi pairs is scanned (vectorised), the rejected pairs located, and there the C
+    restatement must equal the big-int one (which also ties the scan's word mapping to the spec: accepted neighbours compared)"""
+    key = bytes(range(32))
+    kw = [int.from_bytes(key[4 * j:4 * j + 4], "little") for j in range(8)]
+    m, stream, B = 8355709, 12, 6 << 20                  # T = 2: one pair per batch, block counter = b >> 3
+    with np.errstate(over="ignore"):
+        o = _np_chacha20_words(kw, np.arange(B >> 3, dtype=np.uint64), stream)
+    b = np.arange(B)
+    c, e = (b & 7) >> 1, b & 1
+    x = (o[8 * e + c, b >> 3].astype(np.uint64) << np.uint64(32)) | o[8 * e + 4 + c, b >> 3].astype(np.uint64)
+    thr2 = (1 << 64) % (m * m)
+    with np.errstate(over="ignore"):
+        lo = (x * np.uint64(m)) * np.uint64(m)           # lo64(x m m) = lo64(lo64(x m) m)
+    rejected = np.nonzero(lo < np.uint64(thr2))[0]
+    assert 1 <= len(rejected) <= 40, len(rejected)
+    got = coracle.drbg_fill(key, stream, B, 2, m).reshape(B, 2)
+    for bb in rejected.tolist() + [0, 1, 7, 8, B - 1]:
+        assert got[bb].tolist() == [po.drbg_value(key, stream, bb, 2, 0, m), po.drbg_value(key, stream, bb, 2, 1, m)], bb
+    assert got.min() >= 0 and got.max() < m
+    # and the first-attempt values of the accepted pairs are the scan's own
+    acc = np.ones(B, dtype=bool); acc[rejected] = False
+    ra = np.array([(int(v) * m) >> 64 for v in x[:4096]])
+    assert np.array_equal(got[:4096, 0][acc[:4096]], ra[acc[:4096]])
+
+
 def test_csprng_share_map_c_equals_python_and_golden():
     """the library's systematic CSPRNG share map (include/sda_hip.h): the C restatement and the big-int one against the
     committed cases, draws = shares 0..t-1, and the tie to tss's own map - share(secrets, implied randomness) is the same

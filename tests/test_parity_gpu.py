@@ -416,7 +416,7 @@ def test_small_prime_packed_matches_tss_fft_path(gpu):
 
 
 # ---- device CSPRNG (sda-drbg-v1) ----------------------------------------------------------------------
-@pytest.mark.parametrize("case", range(6))
+@pytest.mark.parametrize("case", range(12))
 def test_drbg_matches_spec(gpu, case):
     """Additive shares 0..n-2 ARE the raw draws, so generate(rand=NULL) exposes the CSPRNG stream."""
     from sda_amd import crypto
@@ -485,6 +485,21 @@ def test_drbg_rejection_path(gpu):
     got2 = gen.generate(np.zeros(dim, dtype=np.int64))       # stream 1: fresh randomness per call
     assert np.array_equal(got2[:2], coracle.drbg_fill(KEY, 1, dim, 2, m).reshape(dim, 2).T)
     assert not np.array_equal(got, got2)
+
+
+@pytest.mark.parametrize("m,T", [(8355709, 2), (0x7F7F7F, 3), (5038849, 5)])
+def test_drbg_paired_rule_at_volume(gpu, m, T):
+    """the PAIRED rule (moduli <= 0x7F7F7F, one candidate word -> two draws): millions of pairs, so the rare rejections
+    (below 2^-18 per pair; tests/test_oracle.py locates them) and the retry stream happen on the device too; odd T = a last
+    pair whose second element is discarded"""
+    from sda_amd import crypto
+    from oracle import coracle
+    gen = crypto.ShareGenerator(crypto.Additive(T + 1, m))
+    gen.set_drbg_key(KEY)
+    dim = (6 << 20) // ((T + 1) // 2)
+    got = gen.generate(np.zeros(dim, dtype=np.int64))        # stream 0
+    want = coracle.drbg_fill(KEY, 0, dim, T, m).reshape(dim, T).T
+    assert np.array_equal(got[:T], want)
 
 
 def test_call_key_derivation_and_stream_hygiene(gpu):
