@@ -19,10 +19,12 @@
 // laid out fragment by fragment ([row tile][64-term step][digit][lane] 16 bytes).  The LOADER wave streams those tiles
 // global -> LDS with global_load_lds_dwordx4 into a ring of slots, two tiles ahead, with counted s_waitcnt vmcnt - it has no
 // stores in its in-order counter, so no tile ever waits for share stores to be acknowledged; the compute waves read the
-// fragments back with conflict-free 16-byte LDS loads.  A wave multiplies, reduces and stores ONE of its NT batch tiles at a
-// time (five accumulators, not 5 NT: the loop must fit the 168 registers that three waves per SIMD leave, see the row loop);
-// column c of batch tile nt is batch NT c + nt of the wave, so a lane owns adjacent batch columns and shares leave as 16-byte
-// non-temporal buffer stores (row pointer in a scalar descriptor, one 32-bit lane offset), 256-byte row segments.
+// fragments back with conflict-free 16-byte LDS loads.  Column c of batch tile nt is batch NT c + nt of the wave, so a lane owns
+// adjacent batch columns and shares leave as 16-byte non-temporal buffer stores (row pointer in a scalar descriptor, one 32-bit
+// lane offset), 256-byte row segments.  The B fragments of the last two steps are read from LDS during the row tiles (the last
+// step's digit tile and a per-wave stash, NgBSource): the row loop must fit the 168 registers three waves per SIMD leave WITHOUT
+// scratch memory - a reload there waits for every share store in flight (tests/test_ngemm_isa.py reads the assembly).  Ten tiles
+// before it ends a workgroup touches the secrets of the workgroup that runs next on its XCD (L2 prefetch, see the row loop).
 // Values reach the B-operand layout through an LDS tile [digit][batch][64 terms], one 64-term step at a time; the draws are
 // sda-drbg-v1's PAIRED rule (every prime of this kernel is in its domain): one lane = one ChaCha20 block = draws 2j and 2j + 1
 // of 8 consecutive batches, the same words the transform kernel reads, so both produce identical shares from
@@ -163,6 +165,23 @@ __device__ __noinline__ void ng_load_pass(uint8_t* Bt, const int64_t* sp, const 
     }
 }
 
+// Where the B fragments of a step live during the row tiles.  Fragments in registers have to survive the staging calls of every
+// later step: the calling convention preserves 64 vector registers, and once more fragments than that crossed a call the compiler
+// parked some in scratch memory and kept reloading them INSIDE the row loop, every tile, behind an s_waitcnt vmcnt(0) that also
+// waits for the wave's share stores (124 k or 180 k cycles in the row-tile phase, depending on unrelated code).  So: the LAST
+// step's fragments are read from the digit tile, which stays in LDS through the row tiles; the step before it (KS >= 4) from a
+// stash the wave copies them to - fragment by fragment, 1 KiB each, in the side tile's memory, which is free by then; only the
+// steps before those are registers (KS = 4, NT = 2: 48 of them, all within the preserved set).
+// (Fetching two steps' values with one pass - one memory latency instead of two - was tried with a side tile in that memory and
+// made the pass slower, 35 k against 29 k cycles: it is the bytes in flight per CU that bound it, see the prefetch in the row loop.)
+template <int KS> struct NgBSource {
+    static constexpr bool last_in_tile = KS >= 2, stash = KS >= 4;
+    static constexpr int in_regs = stash ? KS - 2 : last_in_tile ? KS - 1 : KS;      // steps 0 .. in_regs - 1 are registers
+};
+template <int KS, int NT> constexpr size_t ngemm_lds_bytes() {      // A ring + digit tile + stash + 256 bytes nobody reads (prefetch target)
+    return (size_t)(KS == 8 ? 2 : 4) * (size_t)KS * 3 * 1024 + 3 * (size_t)(16 * kNgCompute * NT) * kNgRow +
+           (NgBSource<KS>::stash ? (size_t)kNgCompute * NT * 3 * 1024 : 0) + 256;
+}
 // the CSPRNG draws d_lo .. d_lo + cd - 1 of the workgroup's batches -> digit tile.  Every prime this kernel takes (p <= 0x7F7F7F) is
 // in the domain of sda-drbg-v1's PAIRED rule (modarith.hpp): one lane = one block = draws 2j AND 2j + 1 of 8 batches - 78 blocks per
 // 8 batches of PSS_155_728_100 instead of 155.  A pair that straddles two 64-term steps is computed in both (each step writes the
@@ -225,7 +244,7 @@ __device__ __noinline__ void ng_direct_pass(const uint8_t* Bt, int64_t* op, size
 // step STEP: the three passes, then the B fragments of the step (a template recursion: the fragment array must be indexed by
 // constants to stay in registers)
 template <int KS, int NT, int STEP>
-__device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS][3], uint8_t* Bt, const GenLayout& L, const ModParams& mod, const DrbgKey& key,
+__device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS > 1 ? NgBSource<KS>::in_regs : 1][3], uint8_t* Bt, uint8_t* Side, const GenLayout& L, const ModParams& mod, const DrbgKey& key,
                                          const NGemmPlan& P, const int64_t* sp, const int64_t* rp, int64_t* op, uint64_t stream, uint64_t b0,
                                          uint64_t batches
 #ifdef NG_TIMING
@@ -262,17 +281,23 @@ __device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS][3], uint8_t* Bt
 #ifdef NG_TIMING
         ng_tm[3] += __builtin_readcyclecounter() - tq2;
 #endif
+        // column col of batch tile nt = batch NT col + nt of the wave (see the row tiles' stores)
+        if constexpr (STEP < NgBSource<KS>::in_regs || (NgBSource<KS>::stash && STEP == KS - 2)) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int lb = 0; lb < 3; ++lb)
-                bfrag[nt][STEP][lb] = *reinterpret_cast<const ng_v4i*>(Bt + ((size_t)lb * WGB + wave * WB + NT * col + nt) * kNgRow + 16 * g);   // column col of batch tile nt = batch NT col + nt of the wave (see the row tiles' stores)
+                for (int lb = 0; lb < 3; ++lb) {
+                    const ng_v4i f = *reinterpret_cast<const ng_v4i*>(Bt + ((size_t)lb * WGB + wave * WB + NT * col + nt) * kNgRow + 16 * g);
+                    if constexpr (STEP < NgBSource<KS>::in_regs) bfrag[nt][STEP][lb] = f;
+                    else *reinterpret_cast<ng_v4i*>(Side + ((size_t)(wave * NT + nt) * 3 + lb) * 1024 + lane * 16) = f;     // the wave's stash
+                }
+        }
     }
     __syncthreads();
 #ifdef NG_TIMING
-    if constexpr (STEP + 1 < KS) ng_stage<KS, NT, STEP + 1>(bfrag, Bt, L, mod, key, P, sp, rp, op, stream, b0, batches, ng_tm);
+    if constexpr (STEP + 1 < KS) ng_stage<KS, NT, STEP + 1>(bfrag, Bt, Side, L, mod, key, P, sp, rp, op, stream, b0, batches, ng_tm);
 #else
-    if constexpr (STEP + 1 < KS) ng_stage<KS, NT, STEP + 1>(bfrag, Bt, L, mod, key, P, sp, rp, op, stream, b0, batches);
+    if constexpr (STEP + 1 < KS) ng_stage<KS, NT, STEP + 1>(bfrag, Bt, Side, L, mod, key, P, sp, rp, op, stream, b0, batches);
 #endif
 }
 
@@ -302,6 +327,8 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     extern __shared__ __align__(16) uint8_t ng_lds[];
     uint8_t* Abuf = ng_lds;                                          // [DEPTH][ATILE]
     uint8_t* Bt = ng_lds + DEPTH * ATILE;                            // [3][WGB][kNgRow]
+    uint8_t* Side = Bt + 3 * WGB * kNgRow;                           // [wave][NT][3][1 KiB]: the stash of step KS - 2's B fragments (KS >= 4)
+    uint8_t* Junk = Side + (NgBSource<KS>::stash ? kNgCompute * NT * 3 * 1024 : 0);   // 256 bytes nobody reads: where the prefetch loads land
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, col = lane & 15u, g = lane >> 4;
     uint64_t item = blockIdx.x;
     if (F.n_comb_wg) {                                               // dual-role grid: which role is this workgroup's?
@@ -344,18 +371,21 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     }
 
     // ---- values -> B fragments, one 64-term step at a time -------------------------------------------------------------------
-#ifdef NG_TIMING
+#if defined(NG_TIMING) || defined(NG_PHASES)
     const uint64_t ng_t0 = __builtin_readcyclecounter();
     const uint64_t ng_w0 = wall_clock64();
 #endif
-    ng_v4i bfrag[NT][KS][3];
+    ng_v4i bfrag[NT][KS > 1 ? NgBSource<KS>::in_regs : 1][3];
     int64_t* op = L.out + p * L.out_stride_participant;
 #ifdef NG_TIMING
     uint64_t ng_tm[4] = {0, 0, 0, 0};
-    ng_stage<KS, NT, 0>(bfrag, Bt, L, mod, key, P, sp, rp, op, stream, b0, batches, ng_tm);
+    ng_stage<KS, NT, 0>(bfrag, Bt, Side, L, mod, key, P, sp, rp, op, stream, b0, batches, ng_tm);
     const uint64_t ng_t1 = __builtin_readcyclecounter();
 #else
-    ng_stage<KS, NT, 0>(bfrag, Bt, L, mod, key, P, sp, rp, op, stream, b0, batches);
+    ng_stage<KS, NT, 0>(bfrag, Bt, Side, L, mod, key, P, sp, rp, op, stream, b0, batches);
+#endif
+#ifdef NG_PHASES
+    const uint64_t ng_t1 = __builtin_readcyclecounter();            // (the two phases only: the per-pass timers of NG_TIMING cost registers)
 #endif
 
     // ---- the row tiles ---------------------------------------------------------------------------------------------------
@@ -385,74 +415,97 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     const char* obase = reinterpret_cast<const char*>(op + b0 + (size_t)(rp ? 0u : L.direct_rows) * L.out_stride_clerk);
     const size_t row_bytes = L.out_stride_clerk * sizeof(int64_t);
     const uint32_t loff = bl * 8u + 4u * g * (uint32_t)row_bytes;  // (the fast path asks for 16 rows below 4 GiB)
-    const int32_t c0 = ng_pin_vgpr(P.c[0]), c1 = ng_pin_vgpr(P.c[1]), c2 = ng_pin_vgpr(P.c[2]), c3 = ng_pin_vgpr(P.c[3]), c4 = ng_pin_vgpr(P.c[4]);
-    // One batch tile (16 batches) at a time: multiply it (9 KS matrix instructions into five 32-bit column sums), reduce and store
-    // it, then the wave's next batch tile of the same row tile.  With all NT batch tiles in flight at once (as in rounds 4 and 5)
-    // the loop needed every register the wave has and the compiler kept B fragments in scratch memory, reloaded each tile behind
-    // an s_waitcnt vmcnt(0) that ALSO waited for every share store in flight - a quarter of the row-tile phase, and a kernel
-    // whose speed followed the register allocator's mood (+- 15 % between builds that differed in unrelated code).  The price:
-    // each A fragment is read from LDS NT times (NT 12 KS KiB per wave and tile; the LDS has the bandwidth).
-    // The two compute waves of a SIMD run one PHASE apart: waves 0-3 multiply a batch tile and then reduce it, waves 4-7 reduce
-    // their previous batch tile first and multiply then - so one wave's products run beside the other's vector work.  (With every
-    // wave in the same order the per-tile barrier keeps all of them in lockstep: all on the matrix cores, then all on the vector
-    // ALUs - 3700 cycles per tile where 2300 are matrix-core time, measured.)
     const bool late = wave >= (uint32_t)(kNgCompute / 2);
-    // every B fragment in a register HERE: the staging steps park fragments in scratch memory around their calls, and left to itself
-    // the register allocator reloads some of them where they are used first - inside the loop, every tile, behind an
-    // s_waitcnt vmcnt(0) that also waits for the wave's share stores
+    constexpr int KREG = NgBSource<KS>::in_regs, NLDS = KS - KREG;  // steps in registers / in LDS (0, 1 or 2)
+    // The order in which a row tile's matrix instructions take the steps: the LDS steps BETWEEN register steps (0, KS - 2, 1,
+    // KS - 1, 2, ...), so that ONE buffer of 3 NT fragments serves both - the second LDS step is fetched into it while a register
+    // step multiplies.  All NT batch tiles of the wave are in flight (each A fragment is read from LDS once per row tile).
+    auto step_at = [](int pos) constexpr {
+        if (NLDS == 2) return pos == 0 ? 0 : pos == 1 ? KS - 2 : pos == 2 ? 1 : pos == 3 ? KS - 1 : pos - 2;
+        return pos;                                                 // (NLDS == 1: the last step is the LDS one and comes last)
+    };
+    ng_v4i acc[NT][5];
+    // (tests/test_ngemm_isa.py fails a build whose row loop touches scratch memory.)
+    auto products = [&](uint32_t slot_) {
+        constexpr int GROUPS = KS * 3;
+        const uint8_t* Acur = Abuf + slot_ * ATILE + (size_t)lane * 16;
+        uint32_t bt_off = (wave * WB + NT * col) * kNgRow + 16u * g;           // this lane's rows of the digit tile (plane 0, batch tile 0)
+        uint32_t st_off = wave * NT * 3u * 1024u + lane * 16u;                 // the wave's stash
+        asm volatile("" : "+v"(bt_off), "+v"(st_off));              // (opaque: the reads stay in the loop, they are not hoisted into registers)
+        ng_v4i bl[NT][3];                                           // the fragments of the LDS step at hand
+        auto fetch_b = [&](int ks) {                                // ks >= KREG, a constant after unrolling
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+                for (int lb = 0; lb < 3; ++lb)
+                    bl[nt][lb] = ks == KS - 1 ? *reinterpret_cast<const ng_v4i*>(Bt + ((size_t)lb * WGB + nt) * kNgRow + bt_off)
+                                              : *reinterpret_cast<const ng_v4i*>(Side + (size_t)(nt * 3 + lb) * 1024 + st_off);
+        };
+        auto fetch_a = [&](int gi) { return *reinterpret_cast<const ng_v4i*>(Acur + (size_t)(step_at(gi / 3) * 3 + gi % 3) * 1024); };
 #pragma unroll
-            for (int lb = 0; lb < 3; ++lb) asm volatile("" : "+v"(bfrag[nt][ks][lb]));
-    ng_v4i acc[5];
-    auto products = [&](uint32_t slot_, auto ntc) {
-        constexpr int nt = decltype(ntc)::value;
-        const uint8_t* Acur = Abuf + slot_ * ATILE;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int c = 0; c < 5; ++c) acc[c] = ng_v4i{0, 0, 0, 0};
+            for (int c = 0; c < 5; ++c) acc[nt][c] = ng_v4i{0, 0, 0, 0};
+        // A fragments three groups ahead of their use; the first LDS step's B fragments at the start, the second one's when the
+        // first has been multiplied (position 2 of the order, three groups ahead of position 3)
+        ng_v4i a0 = fetch_a(0), a1 = GROUPS > 1 ? fetch_a(1) : a0, a2 = GROUPS > 2 ? fetch_a(2) : a0;
+        if constexpr (NLDS >= 1) fetch_b(NLDS == 2 ? KS - 2 : KS - 1);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int gi = 0; gi < GROUPS; ++gi) {
+            const int ks = step_at(gi / 3), la = gi % 3;
+            ng_v4i a3 = a2;
+            if (gi + 3 < GROUPS) a3 = fetch_a(gi + 3);
+            if (NLDS == 2 && gi == 6) fetch_b(KS - 1);
 #pragma unroll
-            for (int la = 0; la < 3; ++la) {
-                const ng_v4i a = *reinterpret_cast<const ng_v4i*>(Acur + ((size_t)(ks * 3 + la) * 64 + lane) * 16);
+            for (int lb = 0; lb < 3; ++lb)
 #pragma unroll
-                for (int lb = 0; lb < 3; ++lb) acc[la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bfrag[nt][ks][lb], acc[la + lb], 0, 0, 0);
-            }
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, ks >= KREG ? bl[nt][lb] : bfrag[nt][ks < KREG ? ks : 0][lb], acc[nt][la + lb], 0, 0, 0);
+            a0 = a1; a1 = a2; a2 = a3;
+        }
     };
     // uniform: every batch column of the workgroup exists, 16-byte stores are aligned, a tile's 16 rows span less than 4 GiB
     const bool near = row_bytes < (1ull << 28);                     // 16 rows of a tile within the 4 GiB a buffer descriptor spans
     const bool whole = near && b0 + WGB <= batches && ((reinterpret_cast<uintptr_t>(op) | row_bytes) & 15u) == 0;
-    auto reduce1 = [&](int i) {
-        int64_t S = ng_mad(c0, acc[0][i], 0);
-        S = ng_mad(c1, acc[1][i], S);
-        S = ng_mad(c2, acc[2][i], S);
-        S = ng_mad(c3, acc[3][i], S);
-        S = ng_mad(c4, acc[4][i], S);
+    // (the five constants live in vector registers only while a tile is reduced: moved there by finish(), instead of occupying
+    // five of the loop's registers through the matrix instructions)
+    int32_t c0, c1, c2, c3, c4;
+    auto reduce1 = [&](int nt, int i) {
+        int64_t S = ng_mad(c0, acc[nt][0][i], 0);
+        S = ng_mad(c1, acc[nt][1][i], S);
+        S = ng_mad(c2, acc[nt][2][i], S);
+        S = ng_mad(c3, acc[nt][3][i], S);
+        S = ng_mad(c4, acc[nt][4][i], S);
         return ng_redc(S, P.np);
     };
     // shares = rows 16 rt + 4 g + i of tile rt, canonical, clerk-major (batched.rs:46-48).
-    // A WHOLE tile (all but a participant's last chunk / the last row tile): no masks.  The shares of an even batch tile wait
-    // (four registers) for those of the next one, a lane's two adjacent columns leave as one 16-byte store.  Buffer stores: the
-    // tile's row pointer in a scalar descriptor, row i as the scalar offset, the lane offset in ONE vector register.
-    uint32_t held[4] = {0, 0, 0, 0};
-    auto finish_whole = [&](uint32_t rt, auto ntc) {
-        constexpr int nt = decltype(ntc)::value;
-        if constexpr (NT > 1 && nt % 2 == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) held[i] = reduce1(i);
-        } else {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(obase) + (size_t)rt * 16u * row_bytes, 0, 0xFFFFFFFFu, 0x00020000);
+    // A WHOLE tile (all but a participant's last chunk / the last row tile): no masks, a lane's two adjacent batch columns leave as
+    // one 16-byte store as soon as they are reduced.  Buffer stores: the tile's row pointer in a scalar descriptor, row i as the
+    // scalar offset, the lane offset in ONE vector register.
+    // The FIRST dword of a 16-byte store's data is written long before the store and not again until the next tile (all the even
+    // batch tiles' shares are reduced first, into registers of their own).  With {reduce1(nt, i), 0, reduce1(nt + 1, i), 0} built
+    // afresh for every row i in the same four registers, the store of row i now and then left with row i + 1's first share in lanes
+    // 12-15 of every row of 16 - in the waves that go from the reduction straight into the next products, one launch in ten, and
+    // neither wait states nor an s_waitcnt behind the stores changed it (the documented rule asks for 2 wait states; there were 11
+    // instructions).  This arrangement is the one rounds 4 and 5 shipped; tests/test_ngemm_gpu.py stresses it.
+    auto finish_whole = [&](uint32_t rt) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(obase) + (size_t)rt * 16u * row_bytes, 0, 0xFFFFFFFFu, 0x00020000);
+        if constexpr (NT == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t soff = (uint32_t)i * (uint32_t)row_bytes;
-                if constexpr (NT == 1) {
-                    const ng_v2u v = {reduce1(i), 0u};
-                    __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff, soff, 2);                    // aux 2: non-temporal
-                } else {
-                    const ng_v4u v = {held[i], 0u, reduce1(i), 0u};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, loff + 8 * (nt - 1), soff, 2);
+                const ng_v2u v = {reduce1(0, i), 0u};
+                __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff, (uint32_t)i * (uint32_t)row_bytes, 2);       // aux 2: non-temporal
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt += 2) {                    // a lane's columns nt, nt + 1
+                uint32_t even[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) even[i] = reduce1(nt, i);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const ng_v4u v = {even[i], 0u, reduce1(nt + 1, i), 0u};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, loff + 8 * nt, (uint32_t)i * (uint32_t)row_bytes, 2);
                 }
             }
         }
@@ -460,51 +513,80 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     // any tile: one share at a time under its mask - the same addressing, so that this path keeps two registers (lim, 4 g) alive
     // through the loop and not a set of row pointers
     const uint32_t lim = b0 + bl >= batches ? 0u : (batches - b0 - bl > (uint64_t)NT ? (uint32_t)NT : (uint32_t)(batches - b0 - bl));   // this lane's batch columns that exist
-    auto finish_masked = [&](uint32_t rt, auto ntc) {
-        constexpr int nt = decltype(ntc)::value;
+    auto finish_masked = [&](uint32_t rt) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(obase) + (size_t)rt * 16u * row_bytes, 0, 0xFFFFFFFFu, 0x00020000);
         const uint32_t row0 = 16u * rt + 4u * g;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const ng_v2u v = {reduce1(i), 0u};
-            if ((uint32_t)nt < lim && row0 + (uint32_t)i < P.n) __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff + 8 * nt, (uint32_t)i * (uint32_t)row_bytes, 2);
-        }
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const ng_v2u v = {reduce1(nt, i), 0u};
+                if ((uint32_t)nt < lim && row0 + (uint32_t)i < P.n) __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff + 8 * nt, (uint32_t)i * (uint32_t)row_bytes, 2);
+            }
     };
     // clerk rows 256 MiB or more apart (33 M batches of one tile): plain 64-bit addresses, computed here and now (the inputs pass
     // through an empty asm so that nothing of this is kept in registers through the loop)
-    auto finish_far = [&](uint32_t rt, auto ntc) {
-        constexpr int nt = decltype(ntc)::value;
+    auto finish_far = [&](uint32_t rt) {
         uint32_t gg = g, bb = bl;
         asm volatile("" : "+v"(gg), "+v"(bb));
         const uint32_t row0 = 16u * rt + 4u * gg;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t v = reduce1(i);
-            if ((uint32_t)nt < lim && row0 + (uint32_t)i < P.n)
-                __builtin_nontemporal_store((long long)v, reinterpret_cast<long long*>(const_cast<char*>(obase) + (size_t)(row0 + (uint32_t)i) * row_bytes) + bb + nt);
-        }
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t v = reduce1(nt, i);
+                if ((uint32_t)nt < lim && row0 + (uint32_t)i < P.n)
+                    __builtin_nontemporal_store((long long)v, reinterpret_cast<long long*>(const_cast<char*>(obase) + (size_t)(row0 + (uint32_t)i) * row_bytes) + bb + nt);
+            }
     };
     // whole_tiles: the row tiles this workgroup stores without masks
     const uint32_t whole_tiles = whole ? (P.n / 16u < tiles ? P.n / 16u : tiles) : 0u;
-    typedef std::integral_constant<int, NT - 1> NtLast;
-    uint32_t slot = 0;
-    auto finish = [&](uint32_t rt, auto ntc) {
-        if (rt < whole_tiles) finish_whole(rt, ntc); else if (near) finish_masked(rt, ntc); else finish_far(rt, ntc);
-        __builtin_amdgcn_sched_barrier(0);                          // the next batch tile's matrix instructions stay behind this reduction
+    auto finish = [&](uint32_t rt) {
+        c0 = ng_pin_vgpr(P.c[0]); c1 = ng_pin_vgpr(P.c[1]); c2 = ng_pin_vgpr(P.c[2]); c3 = ng_pin_vgpr(P.c[3]); c4 = ng_pin_vgpr(P.c[4]);
+        if (rt < whole_tiles) finish_whole(rt); else if (near) finish_masked(rt); else finish_far(rt);
+        __builtin_amdgcn_sched_barrier(0);                          // the next tile's matrix instructions stay behind this reduction
     };
+    // The secrets of the workgroup that runs next on this XCD (one workgroup per CU: the one 256 items on), touched a few tiles
+    // before this one ends: its load passes then find them in L2.  A pass is bound by the bytes a CU keeps in flight times the
+    // latency of memory that every other CU is writing shares to (35 k cycles per workgroup; 23 k with every workgroup reading
+    // the same, cache-resident secrets).  global_load_lds: no destination register, nothing to wait for - the four bytes per lane
+    // land in LDS nobody reads; compute waves never wait for vmcnt in this loop.
+    const uint32_t pf_tile = tiles > 12u ? tiles - 10u : 0u;
+    const uint64_t n_items = F.n_comb_wg ? F.n_gen : (uint64_t)gridDim.x;
+    auto prefetch_next = [&]() {
+        const uint64_t nitem = item + 256u;
+        if (nitem >= n_items) return;
+        const uint64_t p2 = nitem / chunks, first = (nitem - p2 * chunks) * WGB * (uint64_t)P.k;     // first secret of that workgroup
+        if (first >= L.len) return;
+        const uint64_t count = L.len - first < (uint64_t)WGB * P.k ? L.len - first : (uint64_t)WGB * P.k;
+        const char* base = reinterpret_cast<const char*>(L.secrets + p2 * L.secrets_stride + first);
+#pragma unroll 1
+        for (uint64_t off = (uint64_t)tid * 128u; off < count * 8u; off += (uint64_t)kNgWorkers * 128u)    // one lane, one 128-byte line
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                             (__attribute__((address_space(3))) void*)Junk, 4, 0, 0);
+    };
+    // The two compute waves of a SIMD run half a period apart: waves 0-3 multiply tile r and THEN reduce and store it, waves 4-7
+    // first reduce and store tile r - 1 and then multiply tile r - so one wave's products run beside the other's vector work.
+    // (With every wave in the same order the per-tile barrier keeps all of them in lockstep: all on the matrix cores, then all on
+    // the vector ALUs - 3700 cycles per tile where 2300 are matrix-core time, measured.)
+    uint32_t slot = 0;
     for (uint32_t rt = 0; rt < tiles; ++rt) {
-        if (late && rt) finish(rt - 1, NtLast{});                   // (a late wave's last batch tile is reduced in front of its next products)
-        auto phase = [&](auto ntc) {                                // one batch tile of the row tile
-            products(slot, ntc);
-            if (!late || decltype(ntc)::value + 1 < NT) finish(rt, ntc);
-        };
-        phase(std::integral_constant<int, 0>{});
-        if constexpr (NT > 1) phase(std::integral_constant<int, 1>{});
-        if constexpr (NT > 2) { phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{}); }
+        if (rt == pf_tile && !rp) prefetch_next();
+        if (late && rt) finish(rt - 1);
+        products(slot);
         slot = slot + 1 == (uint32_t)DEPTH ? 0u : slot + 1;
+        if (!late) finish(rt);
         __syncthreads();                                            // tile rt + 1 is in LDS (the loader waited for it); slot of tile rt is free
     }
-    if (late && tiles) finish(tiles - 1, NtLast{});                 // (a systematic plan with n == t has no matrix rows at all)
+    if (late && tiles) finish(tiles - 1);                           // (a systematic plan with n == t has no matrix rows at all)
+#ifdef NG_PHASES
+    if (tid == 0) {
+        int64_t* o = L.out + p * L.out_stride_participant + b0;
+        o[0] = (int64_t)(ng_t1 - ng_t0);
+        o[1] = (int64_t)(__builtin_readcyclecounter() - ng_t1);
+        o[6] = (int64_t)ng_w0; o[7] = (int64_t)wall_clock64();
+    }
+#endif
 #ifdef NG_TIMING
     if (tid == 0) {                                                 // timing build only: overwrites two shares with cycle counts
         int64_t* o = L.out + p * L.out_stride_participant + b0;
@@ -536,7 +618,7 @@ static hipError_t ngemm_launch(const GenLayout& L, const ModParams& mod, const D
     const uint64_t batches = (L.len + P.k - 1) / P.k;
     const uint64_t chunks = (batches + WGB - 1) / WGB;
     if (chunks * L.participants == 0) return hipSuccess;
-    const size_t lds = NgRing<KS>::depth * ngemm_tile_bytes(KS) + 3 * (size_t)WGB * kNgRow;
+    const size_t lds = ngemm_lds_bytes<KS, NT>();
     auto kern = packed_gen_ngemm_kernel<KS, NT>;
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
@@ -594,7 +676,7 @@ static hipError_t ngemm_launch_fused(const GenLayout& L, const ModParams& mod, c
     if (grid == 0) { *fused = true; return hipSuccess; }
     if (grid > 0x7FFFFFFFull) return hipSuccess;                                  // not fused: the caller issues the two launches
     if (F.n_comb_wg == 0) { *fused = true; return ngemm_launch<KS, NT>(L, mod, key, P, s); }
-    const size_t lds = NgRing<KS>::depth * ngemm_tile_bytes(KS) + 3 * (size_t)WGB * kNgRow;
+    const size_t lds = ngemm_lds_bytes<KS, NT>();
     auto kern = packed_gen_ngemm_kernel<KS, NT>;
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;

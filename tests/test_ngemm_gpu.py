@@ -149,6 +149,35 @@ def test_narrow_limb_gemm_store_paths(gpu, form):
         assert not any(d_out.to_numpy(1, shift + j * stride_clerk + P * Bs)[0] for j in range(n - 1)) and d_out.to_numpy(1)[0] == 0
 
 
+@pytest.mark.parametrize("k,t,n,dim", [(70, 57, 242, 70 * 260), (40, 23, 242, 52001), (100, 155, 728, 26001)])
+def test_narrow_limb_gemm_repeated_launches(gpu, k, t, n, dim):
+    """the same shares 40 times over (KS = 2, 1 and 4; whole workgroups and a ragged one; three participants).  Round 5 met a store
+    that now and then left with the NEXT row's value in 16 of its lanes - one launch in ten, only in the waves that go from the
+    reduction straight into the next row tile's products (ngemm_kernels.hip, finish_whole): a single comparison per shape passes
+    nine times out of ten"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    p, P, first = TSS_P1, 3, (1 << 33) + 9
+    w2, w3 = _root(p, {127: 128, 63: 64, 255: 256}[k + t]), _root(p, {242: 243, 728: 729}[n])
+    gen = crypto.ShareGenerator(crypto.PackedShamir(k, n, t, p, w2, w3))
+    gen.set_drbg_key(KEY)
+    B = gen.batch_count(dim)
+    Bs = (B + 15) // 16 * 16 + 16
+    sec = np.random.default_rng(k + n).integers(0, p, size=(P, dim), dtype=np.int64)
+    d_sec = DeviceBuffer.from_numpy(sec)
+    want = np.stack([coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[q], coracle.drbg_fill(KEY, first + q, B, t, p), gen.csprng_share_map())
+                     for q in range(P)])
+    d_out = DeviceBuffer(P * n * Bs)
+    for rep in range(40):
+        d_out.zero()
+        gen.generate_batch_dev(d_sec.ptr, P, dim, dim, d_out.ptr, n * Bs, Bs, first_participant=first)
+        got = d_out.to_numpy().reshape(P, n, Bs)[:, :, :B]
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (rep, len(bad), bad[:4].tolist())
+    assert capi_last_kernel().startswith("packed_gen_ngemm_kernel")
+
+
 def test_narrow_limb_gemm_share_combine_reveal_roundtrip(gpu):
     """tss's PSS_155_728_100 over tss's prime through the pipelined step (the dual-role launch: share generation of tile i and the
     clerk sum of tile i - 1 in one grid), clerk sums against the oracle, then the reveal from an arbitrary t + k clerks = the sum

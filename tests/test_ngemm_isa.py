@@ -1,0 +1,61 @@
+"""The narrow limb GEMM's row loop must not touch scratch memory (not a GPU test: hipcc cross-compiles the kernel to assembly here).
+
+Why a test: a B fragment that the register allocator parks in scratch memory and reloads inside the row loop costs more than the
+reload - the s_waitcnt vmcnt(0) in front of its use also waits for every share store the wave has in flight, and the kernel has a
+dedicated loader wave precisely so that its compute waves never wait for vmcnt there.  Builds that differed only in unrelated code
+ran 124 k or 180 k cycles per workgroup in the row-tile phase (DESIGN.md 4 "Narrow limb GEMM", profiles/r05/ngemm_phase_timing_*).
+The assembly is the only place where this shows without a GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+INSTANCES = {"1ELi4": 36, "2ELi2": 36, "4ELi2": 72, "8ELi1": 72}          # <KS, NT> -> matrix instructions per row tile and wave
+
+
+@pytest.fixture(scope="module")
+def assembly(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "ngemm.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", str(out),
+                    os.path.join(ROOT, "sda_amd", "csrc", "ngemm_kernels.hip")], check=True, capture_output=True, cwd=str(out.parent), timeout=600)
+    return out.read_text().split("\n")
+
+
+def kernel_body(lines, tag):
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3sda23packed_gen_ngemm_kernelILi" + tag) and l.rstrip().endswith((":", ")")) or
+                 l.startswith("_ZN3sda23packed_gen_ngemm_kernelILi" + tag) and ":" in l)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[start:end]
+
+
+@pytest.mark.parametrize("tag,mfma", sorted(INSTANCES.items()))
+def test_row_loop_is_free_of_scratch_accesses(assembly, tag, mfma):
+    body = kernel_body(assembly, tag)
+    # the row loop: from the header of an innermost loop to the per-tile s_barrier that follows the row tile's matrix instructions
+    headers = [i for i, l in enumerate(body) if "Loop Header" in l] + [len(body)]
+    found = False
+    for h, nxt in zip(headers, headers[1:]):
+        seg = [l.split(";")[0] for l in body[h:nxt]]
+        count, stop = 0, None
+        for i, l in enumerate(seg):
+            count += "v_mfma_i32_16x16x64_i8" in l
+            if count == mfma and "s_barrier" in l:
+                stop = i
+                break
+        if stop is None or count != mfma:
+            continue
+        found = True
+        loop = seg[:stop + 1]
+        scratch = [l.strip() for l in loop if "scratch_" in l]
+        assert not scratch, (tag, "row loop touches scratch memory", scratch[:4])
+        # and no vector-memory LOAD in the compute waves' loop (the global_load_lds prefetches have no destination register and are
+        # never waited for)
+        loads = [l.strip() for l in loop if re.search(r"\b(global|buffer|flat)_load_(?!lds)", l)]
+        assert not loads, (tag, loads[:4])
+    assert found, (tag, "no loop with %d matrix instructions found" % mfma)
+
