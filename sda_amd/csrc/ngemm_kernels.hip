@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         }
         return;
     }
-    // this lane's output rows: 4 g + i of every tile; its batch columns: bw + nt, ADJACENT (column col of batch tile nt is batch
+    // this lane's output rows: 4 g + i of every tile; its batch columns: bl + nt, ADJACENT (column col of batch tile nt is batch
     // NT col + nt of the wave), so that a lane stores two shares of a row with one 16-byte instruction: the CU's address path
     // takes a wave's store lane by lane, and 4 NT instructions of 8 bytes per lane and tile kept it busy for a fifth of the
     // row-tile phase (measured with the stores compiled out: 189k -> 147k cycles per workgroup of PSS_155_728_100)
