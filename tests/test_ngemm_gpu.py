@@ -219,6 +219,42 @@ def test_narrow_limb_gemm_share_combine_reveal_roundtrip(gpu):
     assert np.array_equal(rec, truth)
 
 
+def test_narrow_limb_gemm_repeated_dual_role_launches(gpu):
+    """the repeated-launch check of above through the pipelined step: the shares of a tile are only ever seen by the clerk sum
+    (dual-role grid), so every clerk's sum of 9 participants is compared, 15 times over (KS = 2: the shape that exposed the
+    store that left with the next row's value)"""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    p, k, t, n = TSS_P1, 70, 57, 242
+    w2, w3 = _root(p, 128), _root(p, 243)
+    dim, P, tiles = 70 * 260, 3, 3
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    B = gen.batch_count(dim)
+    Bs = (B + 15) // 16 * 16
+    rng = np.random.default_rng(23)
+    secs = [rng.integers(0, p, size=(P, dim), dtype=np.int64) for _ in range(tiles)]
+    d_secs = [DeviceBuffer.from_numpy(s) for s in secs]
+    shares = [coracle.packed_generate_csprng(p, k, t, n, w2, w3, secs[i][q], coracle.drbg_fill(KEY, i * P + q, B, t, p), gen.csprng_share_map())
+              for i in range(tiles) for q in range(P)]
+    want = np.stack([coracle.combine(p, np.stack([sh[c] for sh in shares])) for c in range(n)])
+    bufs = [DeviceBuffer(n * P * Bs).zero() for _ in range(2)]
+    d_sums = DeviceBuffer(n * B)
+    for rep in range(15):
+        comb = crypto.ShareCombiner(sch)
+        comb.begin_dev(n, B)
+        for i in range(tiles + 1):
+            gen.generate_combine_dev(comb, d_secs[i].ptr if i < tiles else 0, P if i < tiles else 0, dim, dim, bufs[i % 2].ptr, Bs, P * Bs,
+                                     d_prev=bufs[(i - 1) % 2].ptr if i > 0 else 0, prev_participants=P if i > 0 else 0,
+                                     first_participant=i * P)
+        comb.finish_dev(d_sums.ptr)
+        got = d_sums.to_numpy().reshape(n, B)
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (rep, len(bad), bad[:4].tolist())
+
+
 def test_narrow_limb_gemm_fallbacks_keep_the_shares(gpu):
     """what surrounds the kernel: (1) another ChaCha round count (A/B only) has no limb-GEMM instance - on this tss-valid shape the
     transform kernel serves those calls, which is tss's map whatever was requested, and csprng_share_map() SAYS so (round 4
