@@ -469,13 +469,16 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     const bool whole = near && b0 + WGB <= batches && ((reinterpret_cast<uintptr_t>(op) | row_bytes) & 15u) == 0;
     // (the five constants live in vector registers only while a tile is reduced: moved there by finish(), instead of occupying
     // five of the loop's registers through the matrix instructions)
-    int32_t c0, c1, c2, c3, c4;
+    // Columns 3 and 4 share one multiplication: c_4 = 256 c_3 (mod p), and C_3 + 256 C_4 fits 32 bits - column 4 holds only products
+    // of TOP digits, at most 65 for a centred matrix entry (|m| < 2^22) and 127 for a value: 512 x 65 x 128 x 256 + |C_3| < 2^31
+    // (tests/test_ngemm_model.py).  One full-rate shift-add instead of a quarter-rate 64-bit multiply-add per share.
+    int32_t c0, c1, c2, c3;
     auto reduce1 = [&](int nt, int i) {
+        const int32_t top = acc[nt][3][i] + (int32_t)((uint32_t)acc[nt][4][i] << 8);
         int64_t S = ng_mad(c0, acc[nt][0][i], 0);
         S = ng_mad(c1, acc[nt][1][i], S);
         S = ng_mad(c2, acc[nt][2][i], S);
-        S = ng_mad(c3, acc[nt][3][i], S);
-        S = ng_mad(c4, acc[nt][4][i], S);
+        S = ng_mad(c3, top, S);
         return ng_redc(S, P.np);
     };
     // shares = rows 16 rt + 4 g + i of tile rt, canonical, clerk-major (batched.rs:46-48).
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     // whole_tiles: the row tiles this workgroup stores without masks
     const uint32_t whole_tiles = whole ? (P.n / 16u < tiles ? P.n / 16u : tiles) : 0u;
     auto finish = [&](uint32_t rt) {
-        c0 = ng_pin_vgpr(P.c[0]); c1 = ng_pin_vgpr(P.c[1]); c2 = ng_pin_vgpr(P.c[2]); c3 = ng_pin_vgpr(P.c[3]); c4 = ng_pin_vgpr(P.c[4]);
+        c0 = ng_pin_vgpr(P.c[0]); c1 = ng_pin_vgpr(P.c[1]); c2 = ng_pin_vgpr(P.c[2]); c3 = ng_pin_vgpr(P.c[3]);
         if (rt < whole_tiles) finish_whole(rt); else if (near) finish_masked(rt); else finish_far(rt);
         __builtin_amdgcn_sched_barrier(0);                          // the next tile's matrix instructions stay behind this reduction
     };

@@ -43,8 +43,12 @@ def share(row, vals, p):
     for _ in range(5):
         cj.append(x - p if x > (p - 1) // 2 else x)
         x = x * 256 % p
+    # columns 3 and 4 share one multiplication (c_4 = 256 c_3 mod p): C_3 + 256 C_4 in a 32-bit register
+    top = C[3] + 256 * C[4]
+    assert -(1 << 31) <= top < (1 << 31)
+    assert (cj[4] - 256 * cj[3]) % p == 0
     S = 0
-    for c, k in zip(C, cj):
+    for c, k in zip(C[:3] + [top], cj[:4]):
         S += c * k
         assert -(1 << 63) <= S < (1 << 63)                        # v_mad_i64_i32 chain
     assert abs(S) < p << 31                                       # the reduction's operand bound
@@ -96,3 +100,11 @@ def test_column_bound_holds_for_any_operands_at_512_terms():
     assert 3 * 512 * 128 * 128 < 1 << 31
     # sum_j |C_j| <= terms * (sum |dM|) (sum |dV|) <= 512 * 384 * 384, |c_j| <= p / 2: |S| < p 2^31
     assert 512 * 384 * 384 // 2 < 1 << 31
+    # the merged top column: a centred matrix entry is below 2^22 in magnitude, so its top digit is at most 65 (2^22 + 128 * 257
+    # over 65536); a value's top digit at most 128: |C_3 + 256 C_4| <= 512 (128 * 128 + 65 * 128) + 256 * 512 * 65 * 128 < 2^31,
+    # and with it |S| <= (p / 2) (2 * 3 * 512 * 2^14 + 2^31 * 0.52) < p 2^31
+    top = 512 * (128 * 128 + 65 * 128) + 256 * 512 * 65 * 128
+    assert top < 1 << 31 and (3 * 3 * 512 * 128 * 128 + top) // 2 < 1 << 31
+    for p in PRIMES:
+        h = (p + 1) // 2
+        assert max(abs(digits(v, p, True)[2]) for v in (h - 1, h, h + 1, p - 1, 0, 1) if 0 <= v < p) <= 65
