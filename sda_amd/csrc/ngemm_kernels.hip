@@ -446,22 +446,28 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int c = 0; c < 5; ++c) acc[nt][c] = ng_v4i{0, 0, 0, 0};
-        // A fragments three groups ahead of their use; the first LDS step's B fragments at the start, the second one's when the
-        // first has been multiplied (position 2 of the order, three groups ahead of position 3)
-        ng_v4i a0 = fetch_a(0), a1 = GROUPS > 1 ? fetch_a(1) : a0, a2 = GROUPS > 2 ? fetch_a(2) : a0;
+        // A fragments AHEAD groups ahead of their use (three; two for the single-step instance, whose 4 x 5 accumulators leave the
+        // loop no register to spare); the first LDS step's B fragments at the start, the second one's when the first has been
+        // multiplied (position 2 of the order, three groups ahead of position 3)
+        constexpr int AHEAD = KS == 1 ? 2 : 3;
+        ng_v4i a[AHEAD];
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) a[j] = fetch_a(j < GROUPS ? j : 0);
         if constexpr (NLDS >= 1) fetch_b(NLDS == 2 ? KS - 2 : KS - 1);
 #pragma unroll
         for (int gi = 0; gi < GROUPS; ++gi) {
             const int ks = step_at(gi / 3), la = gi % 3;
-            ng_v4i a3 = a2;
-            if (gi + 3 < GROUPS) a3 = fetch_a(gi + 3);
+            ng_v4i an = a[AHEAD - 1];
+            if (gi + AHEAD < GROUPS) an = fetch_a(gi + AHEAD);
             if (NLDS == 2 && gi == 6) fetch_b(KS - 1);
 #pragma unroll
             for (int lb = 0; lb < 3; ++lb)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[nt][la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, ks >= KREG ? bl[nt][lb] : bfrag[nt][ks < KREG ? ks : 0][lb], acc[nt][la + lb], 0, 0, 0);
-            a0 = a1; a1 = a2; a2 = a3;
+                    acc[nt][la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0], ks >= KREG ? bl[nt][lb] : bfrag[nt][ks < KREG ? ks : 0][lb], acc[nt][la + lb], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j + 1 < AHEAD; ++j) a[j] = a[j + 1];
+            a[AHEAD - 1] = an;
         }
     };
     // uniform: every batch column of the workgroup exists, 16-byte stores are aligned, a tile's 16 rows span less than 4 GiB
@@ -485,14 +491,17 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     // A WHOLE tile (all but a participant's last chunk / the last row tile): no masks, a lane's two adjacent batch columns leave as
     // one 16-byte store as soon as they are reduced.  Buffer stores: the tile's row pointer in a scalar descriptor, row i as the
     // scalar offset, the lane offset in ONE vector register.
-    // The FIRST dword of a 16-byte store's data is written long before the store and not again until the next tile (all the even
-    // batch tiles' shares are reduced first, into registers of their own).  With {reduce1(nt, i), 0, reduce1(nt + 1, i), 0} built
-    // afresh for every row i in the same four registers, the store of row i now and then left with row i + 1's first share in lanes
-    // 12-15 of every row of 16 - in the waves that go from the reduction straight into the next products, one launch in ten, and
-    // neither wait states nor an s_waitcnt behind the stores changed it (the documented rule asks for 2 wait states; there were 11
-    // instructions).  This arrangement is the one rounds 4 and 5 shipped; tests/test_ngemm_gpu.py stresses it.
+    // The row offset goes into the DESCRIPTOR (one per row: two scalar adds), the scalar offset stays 0.  With the row in an SGPR soffset the compiler puts no
+    // wait state between buffer_store_dwordx4 and a write to its data registers (its rule: "no hazard when soffset is a register"),
+    // and on this chip the store then now and then reads the NEW value: one launch in ten left with row i + 1's first share in row
+    // i, 16 lanes of one store, only in the waves that reduce at full speed.  tools/microbench_store_war.hip: 2.5 % of such stores
+    // with 0 wait states, none with 1; global_store_dwordx4 needs 2 (the compiler inserts them); 8-byte stores need none
+    // (profiles/r05/microbench_store_war.txt).  tests/test_ngemm_isa.py rejects a 16-byte buffer store with an SGPR soffset.
+    // The even columns' shares are reduced first, into registers of their own (the arrangement the kernel shipped with): the data
+    // of a store is then not written again for a whole reduction either.
     auto finish_whole = [&](uint32_t rt) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(obase) + (size_t)rt * 16u * row_bytes, 0, 0xFFFFFFFFu, 0x00020000);
+        char* tbase = const_cast<char*>(obase) + (size_t)rt * 16u * row_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tbase, 0, 0xFFFFFFFFu, 0x00020000);
         if constexpr (NT == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -506,9 +515,10 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
                 for (int i = 0; i < 4; ++i) even[i] = reduce1(nt, i);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i) {                       // (row i: its own descriptor - scalar adds, no vector register)
                     const ng_v4u v = {even[i], 0u, reduce1(nt + 1, i), 0u};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, loff + 8 * nt, (uint32_t)i * (uint32_t)row_bytes, 2);
+                    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(tbase + (size_t)i * row_bytes, 0, 0xFFFFFFFFu, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsi, loff + 8 * nt, 0, 2);
                 }
             }
         }

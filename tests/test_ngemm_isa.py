@@ -59,3 +59,14 @@ def test_row_loop_is_free_of_scratch_accesses(assembly, tag, mfma):
         assert not loads, (tag, loads[:4])
     assert found, (tag, "no loop with %d matrix instructions found" % mfma)
 
+
+
+def test_no_16_byte_buffer_store_with_a_scalar_offset(assembly):
+    """hipcc puts no wait state between `buffer_store_dwordx4 ..., s<N> offen` and a write to its data registers (its hazard table
+    exempts MUBUF stores whose soffset is a register); on gfx950 such a store then reads the new value in 2.5 % of the cases
+    (tools/microbench_store_war.hip; with soffset 0 the compiler inserts the wait state that is enough).  This cost round 5 a wrong
+    4 x 4 block of shares in one launch of ten."""
+    stores = [l.split(";")[0].strip() for l in assembly if "buffer_store_dwordx4" in l or "buffer_store_dwordx3" in l]
+    assert stores, "the whole-tile path stores 16 bytes per lane"
+    bad = [l for l in stores if re.search(r"s\[\d+:\d+\],\s*s\d+", l)]
+    assert not bad, bad[:4]
