@@ -8,7 +8,9 @@ set -e
 cd "$(dirname "$0")/.."
 python3 -c "import __graft_entry__ as g; g.build()"
 OBJ=sda_amd/lib/obj
-(cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DNG_TIMING -c $OLDPWD/sda_amd/csrc/ngemm_kernels.hip -o $OLDPWD/$OBJ/ngemm_timing.o)
+# NG_DEFINE=NG_PHASES: only the two phases (staging / row tiles) - the per-pass timers of NG_TIMING cost registers, and the row loop
+# of an instrumented build is only comparable with the shipped one when it is as free of scratch reloads (tests/test_ngemm_isa.py)
+(cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -D${NG_DEFINE:-NG_TIMING} -c $OLDPWD/sda_amd/csrc/ngemm_kernels.hip -o $OLDPWD/$OBJ/ngemm_timing.o)
 SRC=$(python3 -c "import __graft_entry__ as g; print(' '.join('$OBJ/'+f+'.o' for f in g.SOURCES if f != 'ngemm_kernels.hip'))")
 (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-rpath,/opt/rocm/lib $(for f in $SRC; do echo $OLDPWD/$f; done) $OLDPWD/$OBJ/ngemm_timing.o -ldl -o $OLDPWD/sda_amd/lib/libsda_hip_timing.so)
 echo built sda_amd/lib/libsda_hip_timing.so
