@@ -37,8 +37,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <type_traits>
-
 #include "capi_internal.hpp"
 #include "chacha.hpp"
 #include "clerk_sum.hpp"
@@ -567,7 +565,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     const uint32_t pf_tile = tiles > 12u ? tiles - 10u : 0u;
     const uint64_t n_items = F.n_comb_wg ? F.n_gen : (uint64_t)gridDim.x;
     auto prefetch_next = [&]() {
-        const uint64_t nitem = item + 256u;
+        const uint64_t nitem = item + 256u;                          // (gfx950: 256 CUs, one workgroup each; blocks b and b + 256 share an XCD)
         if (nitem >= n_items) return;
         const uint64_t p2 = nitem / chunks, first = (nitem - p2 * chunks) * WGB * (uint64_t)P.k;     // first secret of that workgroup
         if (first >= L.len) return;
