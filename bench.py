@@ -216,6 +216,79 @@ def cpu_baseline(w, dim, budget_s=10.0, samples=3):
     return res
 
 
+# ---- exit codes of bench.py (DESIGN.md 6 lists them) -------------------------------------------------------------------------
+EXIT_OK = 0
+EXIT_COMM = 3          # a device is missing or the RCCL communicator could not be set up (and no rehearsal switch allows a fall-back)
+EXIT_DEADLINE = 4      # --deadline-s passed: the launcher (or a rank's own watchdog) ended every rank; NO JSON line was printed
+EXIT_EXCHANGE = 5      # a cross-rank exchange (communicator set-up or the modular reduce) did not return within its limit
+_T0 = time.monotonic()
+
+
+class Watchdog:
+    """Hang protection of ONE rank (the launcher has its own deadline in self_launch): a daemon thread that ends the process
+    with a distinct exit code - and says why on stderr - when the whole run passes --deadline-s or the phase in progress passes
+    its own limit.  The first multi-GPU run of the exchange must not be able to sit in a collective until the driver's
+    timeout: a rank that is ended here exits non-zero, and both launchers (self_launch, torch.distributed.run) then take
+    the other ranks down.  phase() also prints the one-line stderr heartbeat (rank, seconds since start, phase).
+
+    Test hook (tests only): SDA_BENCH_TEST_HANG="<phase prefix>:<rank or *>" makes that rank sleep forever when it enters the
+    phase - the stand-in for a rank that never comes back from a collective."""
+
+    def __init__(self, rank, world, deadline_s, exchange_timeout_s):
+        import threading
+        self.rank, self.world = rank, world
+        # a rank started by self_launch counts from the LAUNCHER's start and gives it 5 s to act first
+        base = float(os.environ.get("SDA_BENCH_LAUNCHER_T0", "nan"))
+        self.t0 = _T0
+        self.deadline = None
+        if deadline_s > 0:
+            self.deadline = (_T0 + deadline_s) if base != base else (base + deadline_s + 5.0)
+        self.deadline_s = deadline_s
+        self.exchange_timeout_s = exchange_timeout_s
+        self.name, self.limit_at, self.limit_s, self.code = "start", None, None, EXIT_DEADLINE
+        self.diag = lambda: ""                       # Env fills this in: peers, RCCL version, last library error
+        self.lock = threading.Lock()
+        hang = os.environ.get("SDA_BENCH_TEST_HANG", "")
+        self.hang_phase, _, who = hang.partition(":")
+        self.hang_me = bool(hang) and who in ("*", str(rank))
+        threading.Thread(target=self._watch, name="bench-watchdog", daemon=True).start()
+
+    def phase(self, name, limit_s=None, code=EXIT_DEADLINE):
+        with self.lock:
+            self.name, self.limit_s, self.code = name, limit_s, code
+            self.limit_at = None if not limit_s or limit_s <= 0 else time.monotonic() + limit_s
+        print(f"[bench] rank {self.rank}/{self.world} +{time.monotonic() - self.t0:.1f}s phase: {name}"
+              + (f" (limit {limit_s:g} s)" if limit_s else ""), file=sys.stderr, flush=True)
+        if self.hang_me and name.startswith(self.hang_phase):
+            print(f"[bench] rank {self.rank}: SDA_BENCH_TEST_HANG: sleeping forever in phase {name!r}", file=sys.stderr, flush=True)
+            while True:
+                time.sleep(3600)
+
+    def exchange(self, name):
+        """phase with the exchange limit and the exchange exit code"""
+        self.phase(name, self.exchange_timeout_s, EXIT_EXCHANGE)
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            t = time.monotonic()
+            with self.lock:
+                name, limit_at, limit_s, code = self.name, self.limit_at, self.limit_s, self.code
+            why = None
+            if limit_at is not None and t > limit_at:
+                why = f"phase {name!r} did not finish within its limit of {limit_s:g} s"
+            elif self.deadline is not None and t > self.deadline:
+                why, code = f"--deadline-s {self.deadline_s:g} passed in phase {name!r}", EXIT_DEADLINE
+            if why:
+                try:
+                    extra = self.diag()
+                except Exception as e:                                   # the diagnosis must never keep the process alive
+                    extra = f"(diagnosis failed: {e})"
+                print(f"[bench] rank {self.rank}/{self.world} WATCHDOG: {why}; {extra}; exiting with code {code}, no JSON line",
+                      file=sys.stderr, flush=True)
+                os._exit(code)
+
+
 class Env:
     """process-wide state: device, ranks, library, communicator.
 
@@ -223,7 +296,9 @@ class Env:
     max-over-ranks of the timing); the data-path reduce is the library's own RCCL code behind the C ABI
     (sda_comm_init / sda_modular_allreduce_dev)."""
 
-    def __init__(self):
+    def __init__(self, wd):
+        self.wd = wd
+        wd.phase("init: import torch, select the device, gloo control plane", 600)
         import torch
         import torch.distributed as dist
         from sda_amd import capi
@@ -252,7 +327,7 @@ class Env:
             # --gpus N on a box with fewer devices: nothing this run could print would be the N-GPU measurement
             print(f"[bench] rank {self.rank}: device {device_index} does not exist ({torch.cuda.device_count()} visible); FATAL - "
                   f"set SDA_SHARE_GPU=1 only to rehearse the N > 1 path on a one-GPU box", file=sys.stderr, flush=True)
-            os._exit(3)
+            os._exit(EXIT_COMM)
         torch.cuda.set_device(device_index)
         self.dev = torch.device("cuda", device_index)
         self.use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run
@@ -260,21 +335,29 @@ class Env:
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")                                      # control plane only
+        # A/B runs (tools/*.sh) and the one-rank RCCL test select non-default kernels by environment variable.  The RELEASE library
+        # has no knob table and reads no environment variable: only when such a variable is set does the bench - a measurement
+        # tool - load libsda_hip_test.so (same objects + the test hooks, include/sda_hip_debug.h) and hand the values over.  The
+        # default line never does: `library` on the line says which binary ran.
+        knob_names = ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
+                      "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM",
+                      "SDA_NO_WIDE_GROUP")
+        knobs = {n: os.environ[n] for n in knob_names if os.environ.get(n)}
+        if knobs:
+            capi.use_test_hooks()
         self.lib = capi.load()
-        # A/B runs (tools/*.sh) and the one-rank RCCL test select non-default kernels by environment variable; the release
-        # library reads none, so the bench - a measurement tool - hands them to its test-only entry point (sda_hip_debug.h)
-        for name in ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
-                     "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM",
-                     "SDA_NO_WIDE_GROUP"):
-            if os.environ.get(name):
-                v = os.environ[name]
-                capi.check(self.lib.sda_debug_set_knob(name.encode(), int(v) if v.lstrip("-").isdigit() else 1))
+        for name, v in knobs.items():
+            capi.check(self.lib.sda_debug_set_knob(name.encode(), int(v) if v.lstrip("-").isdigit() else 1))
         self.csprng_share_map = os.environ.get("SDA_BENCH_SHARE_MAP", "")   # "tss": A/B against the round-3 share map
         capi.check(self.lib.sda_set_device(device_index))
         self.comm = C.c_void_p()
         self.exchange = "none (one rank)" if self.world == 1 else "host-staged over gloo (ranks share one GPU)"
         path = "none (one rank)" if self.world == 1 else "host-staged gloo (SDA_SHARE_GPU rehearsal)"
+        self.rccl = {"ranks": 0, "path": path}
+        wd.diag = self.diagnosis
         if not self.share_gpu:
+            if self.world > 1:
+                wd.exchange("comm: RCCL unique id + ncclCommInitRank over %d ranks" % self.world)
             # RCCL prints its version banner to the C stdout at init: keep stdout for the ONE JSON line
             sys.stdout.flush()
             saved = os.dup(1)
@@ -306,6 +389,7 @@ class Env:
                     path = "send/recv (one rank, to itself)"
             else:
                 msg = self.lib.sda_last_error().decode()
+                capi.LAST_ERROR_SEEN = msg
                 if self.comm:
                     self.lib.sda_comm_free(self.comm)
                 self.comm = C.c_void_p()
@@ -314,7 +398,7 @@ class Env:
                     print(f"[bench] rank {self.rank}: sda_comm_init failed ({msg}); FATAL - set SDA_SHARE_GPU=1 only to "
                           f"rehearse the N > 1 path on a one-GPU box", file=sys.stderr, flush=True)
                     sys.stderr.flush()
-                    os._exit(3)
+                    os._exit(EXIT_COMM)
                 print(f"[bench] rank {self.rank}: sda_comm_init failed ({msg}); exchange falls back to host staging over gloo",
                       file=sys.stderr, flush=True)
                 self.exchange = "host-staged over gloo (RCCL communicator unavailable: " + msg[:80] + ")"
@@ -334,7 +418,17 @@ class Env:
                      "unique_devices": len({(h, b) for h, b, _ in everyone}),
                      "path": path,
                      "devices": [f"{b} (ordinal {o})" for _, b, o in everyone],
-                     "comm_device": int(self.lib.sda_comm_device(self.comm)) if self.comm else None}
+                     "comm_device": int(self.lib.sda_comm_device(self.comm)) if self.comm else None,
+                     "rccl_version": int(self.lib.sda_comm_rccl_version())}
+        wd.phase("init done: exchange = " + self.exchange)
+
+    def diagnosis(self):
+        """what the watchdog prints when it ends this rank: who the peers are, what carries the exchange, the RCCL version the
+        library bound and the library's last error on the main thread (as of the last call that failed)"""
+        r = self.rccl
+        return (f"device {self.dev}, peers {r.get('devices', '?')}, exchange path {r.get('path')!r}, communicator ranks "
+                f"{r.get('ranks')}, RCCL version {int(self.lib.sda_comm_rccl_version())}, "
+                f"last library error {self.capi.LAST_ERROR_SEEN!r}")
 
     def modular_allreduce(self, t, q=P62):
         """sum over ranks mod q of the int64 device tensor `t`, on every rank (new tensor)"""
@@ -607,6 +701,8 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
         for e in filled + consumed:
             e.record(torch.cuda.current_stream(dev))
 
+    wd = env.wd
+    wd.phase(f"warm-up: {name}, {warmup} step(s) of {n_sub} x {P} participants, dim {dim}")
     wtiles = warmup * n_sub
     comb.begin_dev(n, B)
     prime(wtiles)
@@ -622,19 +718,28 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
     sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
+    if world > 1:
+        # the FIRST exchange between the devices (nothing before this line has moved a byte from one GPU to another): under the
+        # exchange watchdog, so that a deadlocked send/recv group ends the run with EXIT_EXCHANGE and a diagnosis in seconds
+        wd.exchange(f"warm-up exchange: {name}, modular reduce of {8 * n * B} bytes per GPU over {world} ranks")
     env.modular_allreduce(sums, q)                           # connect RCCL outside the timed region, real message size
+    torch.cuda.synchronize(dev)
     env.barrier()
+    wd.phase(f"timed: {name}, {steps} step(s) of {n_sub} x {P} participants")
     t0 = time.perf_counter()
     for i in range(tiles + 1):
         launch(i, tiles, evs[2 * i:2 * i + 2])
     comb.finish_dev(sums.data_ptr())
     torch.cuda.synchronize(dev)
+    if world > 1:
+        wd.exchange(f"timed exchange: {name}")
     tx = time.perf_counter()
     total = env.modular_allreduce(sums, q)                   # X1: the only exchange step
     torch.cuda.synchronize(dev)
     exchange_ms = (time.perf_counter() - tx) * 1e3
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
+    wd.phase(f"verify: {name}")
     ms = C.c_float()
     launch_ms = []
     for i in range(tiles + 1):
@@ -731,6 +836,7 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
 
     for e in comb_done:
         e.record(s_comb)
+    env.wd.phase(f"warm-up: {name} (serial schedule)")
     tiles = steps * n_sub
     for i in range(warmup * n_sub):
         step(tiles + i, i % nbuf)
@@ -744,19 +850,27 @@ def measure(env, name, dim, P, n_sub, steps, warmup, row_align=16, overlap=0, ve
         capi.check(lib.sda_event_create(C.byref(e)))
         evs.append(e)
     sums = torch.zeros((n, B), dtype=torch.int64, device=dev)
+    wd = env.wd
+    if world > 1:
+        wd.exchange(f"warm-up exchange: {name}, modular reduce of {8 * n * B} bytes per GPU over {world} ranks")
     env.modular_allreduce(sums, q)
+    torch.cuda.synchronize(dev)
     env.barrier()
+    wd.phase(f"timed: {name} (serial schedule), {steps} step(s) of {n_sub} x {P} participants")
     t0 = time.perf_counter()
     for i in range(tiles):
         step(i, i % nbuf, evs[4 * i:4 * i + 4])
     comb.finish_dev(sums.data_ptr(), h_comb or 0)
     torch.cuda.synchronize(dev)
+    if world > 1:
+        wd.exchange(f"timed exchange: {name}")
     tx = time.perf_counter()
     total = env.modular_allreduce(sums, q)
     torch.cuda.synchronize(dev)
     exchange_ms = (time.perf_counter() - tx) * 1e3
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
+    wd.phase(f"verify: {name}")
     gen_ms = comb_ms = 0.0
     ms = C.c_float()
     for i in range(tiles):
@@ -868,11 +982,14 @@ def emit(full, details_path, fd, full_line=False):
     os.write(fd, (text + "\n").encode())
 
 
-def self_launch(n):
+def self_launch(n, deadline_s=0.0):
     """`python bench.py --gpus N` without a launcher: start the N ranks here - the same script, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them, stdout inherited (only rank 0 writes to it:
-    the ONE JSON line) - wait for all of them and return the WORST exit code (so a refused communicator stays exit code 3).
-    A rank that dies takes the others with it after a grace period instead of leaving them in a collective."""
+    the ONE JSON line) - wait for all of them and return the exit code of the rank that failed FIRST (so a refused
+    communicator stays EXIT_COMM, a stuck exchange EXIT_EXCHANGE).  A rank that dies takes the others with it after a grace
+    period instead of leaving them in a collective; and when `deadline_s` passes with ranks still running - a hang nobody
+    exited from - every rank is ended (SIGTERM, then SIGKILL) and the launcher returns EXIT_DEADLINE.  Rank 0 prints its line
+    only as its very last act, so a run that ends this way has printed none."""
     import signal
     import socket
     import subprocess
@@ -880,6 +997,7 @@ def self_launch(n):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                SDA_BENCH_LAUNCHER_T0=repr(_T0),
                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
@@ -890,10 +1008,27 @@ def self_launch(n):
             if p.poll() is None:
                 p.terminate()
     signal.signal(signal.SIGTERM, stop)
+    def kill_all(grace=5.0):
+        stop()
+        t_end = time.monotonic() + grace
+        while any(p.poll() is None for p in procs) and time.monotonic() < t_end:
+            time.sleep(0.1)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     first_bad, failed_at, stopped = 0, None, False
     try:
         while any(p.poll() is None for p in procs):
             time.sleep(0.2)
+            if deadline_s > 0 and time.monotonic() - _T0 > deadline_s:
+                alive = [r for r, p in enumerate(procs) if p.poll() is None]
+                print(f"[bench] launcher: --deadline-s {deadline_s:g} passed with rank(s) {alive} still running; ending all "
+                      f"{n} ranks, exit code {EXIT_DEADLINE}, no JSON line (each rank's last '[bench] rank r/N ... phase:' "
+                      f"line on stderr says where it was)", file=sys.stderr, flush=True)
+                kill_all()
+                for p in procs:
+                    p.wait()
+                return first_bad or EXIT_DEADLINE
             if not first_bad:
                 bad = [c for c in (p.poll() for p in procs) if c not in (None, 0)]
                 if bad:
@@ -948,6 +1083,12 @@ def main():
                     help="measurement scripts only (tools/*.sh): print the FULL record on stdout instead of the compact line")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
                     help="where the full record goes (stdout carries the compact line only)")
+    ap.add_argument("--deadline-s", type=float, default=900.0,
+                    help=f"hang protection: end every rank and exit with code {EXIT_DEADLINE} (no JSON line) when the whole run "
+                         "takes longer than this many seconds; 0 = no deadline (long custom runs)")
+    ap.add_argument("--exchange-timeout-s", type=float, default=90.0,
+                    help=f"hang protection: limit of ONE cross-rank exchange (communicator set-up, the warm-up and the timed "
+                         f"modular reduce); a rank that waits longer prints its diagnosis and exits with code {EXIT_EXCHANGE}")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("--steps must be >= 1 and --warmup >= 0")
@@ -957,7 +1098,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` by itself: become the launcher of its own N ranks (one process per GPU); the ranks
         # are this same script with the environment torch.distributed.run would give them
-        raise SystemExit(self_launch(args.gpus))
+        raise SystemExit(self_launch(args.gpus, args.deadline_s))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: one rank per GPU")
@@ -966,7 +1107,9 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    env = Env()
+    wd = Watchdog(int(os.environ.get("RANK", "0")), world, args.deadline_s, args.exchange_timeout_s)
+    wd.phase("start")
+    env = Env(wd)
 
     def run(name, steps, warmup, participants=0, dim=0, tile=0):
         w = WORKLOADS[name]
@@ -1035,13 +1178,17 @@ def main():
                                   f"= {per_gpu} per GPU" + (", Lagrange reveal included (reveal.ms)" if leg == "packed_dim16m" else ""))
             legs["config4_packed26" if leg == "packed26" else "config5_packed_dim16m"] = {k: r[k] for k in keep + ("scaling",) if k in r}
         line["additional_workloads"] = legs
+    wd.phase("cpu baseline on rank 0's host cores" if env.rank == 0 and not args.no_cpu_baseline else "waiting for rank 0")
     if env.rank == 0:
         # rank 0's host cores, at any world size (the other ranks wait at the closing barrier): the reference's CPU path
         # timed beside the GPU figure on the same box
         line["cpu_baseline"] = (None if args.no_cpu_baseline else
                                 cpu_baseline(WORKLOADS[args.workload], args.dim or WORKLOADS[args.workload].get("dim", 1 << 20)))
+    if env.use_dist:
+        env.barrier()                                        # (the other ranks wait here, under the run's deadline only)
     # tear the communicator down with the C stdout pointed at stderr (RCCL may print there), so that the JSON line is
     # the one and LAST thing on stdout
+    wd.phase("close: barrier, communicator teardown", 120 if env.world > 1 else None, EXIT_EXCHANGE)
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
@@ -1053,6 +1200,7 @@ def main():
         os.close(saved)
     sys.stdout.flush()
     C.CDLL(None).fflush(None)
+    wd.phase("emit")
     if env.rank == 0:
         emit(line, args.details, real_stdout, args.full_line)
     os.close(real_stdout)

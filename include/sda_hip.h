@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SDA_HIP_ABI_VERSION 5
+#define SDA_HIP_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum sda_status {
@@ -207,6 +207,14 @@ uint64_t sda_share_generator_rand_count(const sda_share_generator_t* g, size_t l
 int sda_share_generator_set_drbg_key(sda_share_generator_t* g, const uint8_t key[32]);
 int sda_share_generator_set_drbg_master_key(sda_share_generator_t* g, const uint8_t key[32]);
 int sda_share_generator_set_drbg_rounds(sda_share_generator_t* g, int rounds);
+/* Which draw rule of sda-drbg-v1 serves `modulus` (ABI 6): SDA_DRBG_RULE_WORD = one 64-bit candidate word per draw (every
+ * modulus above 0x7F7F7F; rounds 1 - 4 used it for all moduli), SDA_DRBG_RULE_PAIRED = one candidate word per TWO draws (moduli
+ * up to 0x7F7F7F since library 0.5: the shares a given deterministic-mode key produces over such a modulus differ from those of
+ * library 0.4 and earlier).  A deterministic-mode user who stores keys can detect the stream layout with this call.  Negative:
+ * an enum sda_status (modulus out of range). */
+#define SDA_DRBG_RULE_WORD 1
+#define SDA_DRBG_RULE_PAIRED 2
+int sda_drbg_draw_rule(int64_t modulus);
 
 /* CSPRNG share map (packed Shamir, rand == NULL only; ABI 4).  tss draws the polynomial's t free parameters as its values
  * at omega_secrets^(k+1 .. k+t) (packed_shamir.rs:42 -> tss share: values = [0] ++ secrets ++ randomness).  A caller who
@@ -617,6 +625,8 @@ int  sda_sealedbox_open(sda_sealedbox_t* b, const uint8_t pk[32], const uint8_t 
  *   sda_comm_unique_id : rank 0 makes the 128-byte RCCL id; the host hands it to the other ranks (any side channel)
  *   sda_comm_init      : collective over all ranks; binds the communicator to the calling thread's current device
  *                        (sda_set_device).  RCCL is loaded on first use (dlopen) - SDA_ERR_COMM if it is missing.
+ *   sda_comm_rccl_version : the version code of the RCCL the library bound (ncclGetVersion: major*10000 + minor*100 + patch),
+ *                        0 before the first sda_comm_unique_id / sda_comm_init or when RCCL has no such symbol.  Diagnostics only.
  *   sda_modular_allreduce_dev : d_partial[len] (any i64, this rank's partial sums) -> d_out[len] = sum over the ranks
  *                        mod modulus, canonical, on EVERY rank; asynchronous on `stream`; d_out may alias d_partial
  *                        only when world == 1.  len and modulus must agree on all ranks.
@@ -631,6 +641,7 @@ void sda_comm_free(sda_comm_t* c);
 int  sda_comm_rank(const sda_comm_t* c);
 int  sda_comm_world(const sda_comm_t* c);
 int  sda_comm_device(const sda_comm_t* c);   /* HIP ordinal the communicator was bound to at init; -1 for NULL */
+int  sda_comm_rccl_version(void);
 int  sda_modular_allreduce_dev(sda_comm_t* c, int64_t modulus, const int64_t* d_partial, size_t len, int64_t* d_out,
                                void* stream);
 int  sda_modsum_parts_dev(int64_t modulus, const int64_t* d_parts, size_t parts, size_t part_stride,

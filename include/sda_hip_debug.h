@@ -1,5 +1,15 @@
-/* sda_hip_debug.h - TEST / MEASUREMENT ONLY entry points of libsda_hip.so.  Not part of the drop-in boundary (include/sda_hip.h):
- * nothing a Rust shim binds.  The release library reads no environment variable; the kernels behind one C-ABI call are all
+/* sda_hip_debug.h - TEST / MEASUREMENT ONLY entry points.  Not part of the drop-in boundary (include/sda_hip.h): nothing a Rust
+ * shim binds.
+ *
+ * TWO LIBRARIES are built from the same objects (__graft_entry__.build(); only sda_capi.cpp is compiled twice):
+ *   sda_amd/lib/libsda_hip.so       the RELEASE library.  Of this header it exports ONLY the two read-only queries
+ *                                   sda_debug_last_kernel() and sda_debug_hooks_compiled_in() (= 0).  It has no knob table: no
+ *                                   in-process caller can change which kernel a later handle gets, and it reads no environment variable.
+ *   sda_amd/lib/libsda_hip_test.so  the same code with -DSDA_TEST_HOOKS: everything below (sda_debug_hooks_compiled_in() = 1).  What the
+ *                                   parity tests of the NON-DEFAULT kernels and the A/B measurement scripts load
+ *                                   (sda_amd.capi.use_test_hooks()); smoke(), bench.py's default line and the C / C++ examples never do.
+ *
+ * The release library reads no environment variable; the kernels behind one C-ABI call are all
  * bit-exact with each other, and which one serves a shape is the library's decision.  The parity tests still have to reach the
  * non-default kernels (the any-shape fallback, the 64-bit Montgomery form, the transform kernel on small tss-valid shapes, the
  * limb GEMM on shapes it is not the default for, both varint decode forms), and the A/B measurements of DESIGN.md have to
@@ -33,10 +43,13 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* ---- in BOTH libraries (read-only) ---- */
+int  sda_debug_hooks_compiled_in(void);                  /* 1 in libsda_hip_test.so, 0 in the release library */
+/* ---- libsda_hip_test.so only (-DSDA_TEST_HOOKS), except sda_debug_last_kernel ---- */
 int  sda_debug_set_knob(const char* name, long value);   /* SDA_ERR_INVALID_ARGUMENT for an unknown name */
 void sda_debug_reset_knobs(void);
 int  sda_debug_env_knobs_compiled_in(void);              /* 1 only in an SDA_AB_KNOBS build */
-/* What the library RAN: the kernel instance(s) launched by the last sda_share_generator_generate / _generate_batch_dev /
+/* (BOTH libraries.)  What the library RAN: the kernel instance(s) launched by the last sda_share_generator_generate / _generate_batch_dev /
  * _generate_combine_dev call on this thread, named as rocprofv3 prints them ("fused_packed_l31_kernel<3, 1, 20>";
  * two launches: "packed_gen_fft_kernel<...> + combine_update_walk_kernel (side stream)").  bench.py prints this as roofline.kernel. */
 const char* sda_debug_last_kernel(void);

@@ -6,4 +6,4 @@ traits.  This package only loads it (``capi``) and mirrors the reference's inter
 (``crypto``); ``distributed`` shards participants across GPUs.  There is no CPU fallback."""
 from . import capi  # noqa: F401
 
-__version__ = "0.5.0"          # = sda_version() of the library (tests/test_capi_cpu.py checks the two agree)
+__version__ = "0.6.0"          # = sda_version() of the library (tests/test_capi_cpu.py checks the two agree)

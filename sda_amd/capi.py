@@ -1,6 +1,12 @@
 """ctypes loader for libsda_hip.so - every symbol include/sda_hip.h declares, with its signature.
 
-Fails loudly: if the shared library is missing, ``load()`` raises (no fallback of any kind)."""
+Fails loudly: if the shared library is missing, ``load()`` raises (no fallback of any kind).
+
+Two builds of the library exist (include/sda_hip_debug.h): the RELEASE library ``libsda_hip.so`` - what ``load()`` gives unless
+told otherwise - and ``libsda_hip_test.so``, the same objects plus the test-only knob table and helpers (``HOOK_SIGNATURES``).
+``use_test_hooks()`` makes the test library the active one for this process (parity tests of the non-default kernels, A/B
+scripts); ``use_release()`` switches back.  ``load()`` returns a proxy that always forwards to the ACTIVE library, so a
+reference taken before a switch stays valid."""
 from __future__ import annotations
 
 import ctypes as C
@@ -8,7 +14,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDA_HIP_LIBRARY lets a developer A/B two builds of the same library; it is never a fallback
-LIB_PATH = os.environ.get("SDA_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libsda_hip.so")
+RELEASE_LIB_PATH = os.path.join(_HERE, "lib", "libsda_hip.so")
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libsda_hip_test.so")
+LIB_PATH = os.environ.get("SDA_HIP_LIBRARY") or RELEASE_LIB_PATH
 
 c_i64p = C.POINTER(C.c_int64)
 c_u8p = C.POINTER(C.c_uint8)
@@ -71,16 +79,9 @@ SIGNATURES = {
     "sda_scheme_reconstruction_threshold": (C.c_uint64, [_SS]),
     "sda_masking_has_mask": (C.c_int, [_MS]),
     "sda_abi_version": (C.c_int, []),
-    # include/sda_hip_debug.h - test / measurement only
-    "sda_debug_set_knob": (C.c_int, [C.c_char_p, C.c_long]),
-    "sda_debug_reset_knobs": (None, []),
-    "sda_debug_env_knobs_compiled_in": (C.c_int, []),
+    # include/sda_hip_debug.h - the two read-only queries both libraries export
+    "sda_debug_hooks_compiled_in": (C.c_int, []),
     "sda_debug_last_kernel": (C.c_char_p, []),
-    "sda_debug_stream_create": (C.c_int, [c_voidpp]),
-    "sda_debug_stream_destroy": (C.c_int, [C.c_void_p]),
-    "sda_debug_stream_synchronize": (C.c_int, [C.c_void_p]),
-    "sda_debug_mem_info": (C.c_int, [c_sizep, c_sizep]),
-    "sda_debug_select_path": (C.c_int, [_SS, C.c_char_p, C.c_char_p, C.c_size_t]),
     "sda_version": (C.c_char_p, []),
     "sda_build_id": (C.c_char_p, []),
     "sda_share_generator_path_name": (C.c_char_p, [_H]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "sda_share_generator_set_drbg_key": (C.c_int, [_H, c_u8p]),
     "sda_share_generator_set_drbg_master_key": (C.c_int, [_H, c_u8p]),
     "sda_share_generator_set_drbg_rounds": (C.c_int, [_H, C.c_int]),
+    "sda_drbg_draw_rule": (C.c_int, [C.c_int64]),
     "sda_share_generator_csprng_share_map": (C.c_int, [_H]),
     "sda_share_generator_set_csprng_share_map": (C.c_int, [_H, C.c_int]),
     "sda_share_generator_generate": (C.c_int, [_H, c_i64p, C.c_size_t, c_i64p, C.c_size_t, c_i64p, C.c_size_t]),
@@ -199,6 +201,7 @@ SIGNATURES = {
     "sda_comm_rank": (C.c_int, [_H]),
     "sda_comm_world": (C.c_int, [_H]),
     "sda_comm_device": (C.c_int, [_H]),
+    "sda_comm_rccl_version": (C.c_int, []),
     "sda_modular_allreduce_dev": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "sda_modsum_parts_dev": (C.c_int, [C.c_int64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                        C.c_void_p]),
@@ -210,24 +213,98 @@ SIGNATURES = {
     "sda_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
 }
 
-_lib = None
+# include/sda_hip_debug.h - libsda_hip_test.so only (-DSDA_TEST_HOOKS): the knob table and the tests' helpers
+HOOK_SIGNATURES = {
+    "sda_debug_set_knob": (C.c_int, [C.c_char_p, C.c_long]),
+    "sda_debug_reset_knobs": (None, []),
+    "sda_debug_env_knobs_compiled_in": (C.c_int, []),
+    "sda_debug_stream_create": (C.c_int, [c_voidpp]),
+    "sda_debug_stream_destroy": (C.c_int, [C.c_void_p]),
+    "sda_debug_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "sda_debug_mem_info": (C.c_int, [c_sizep, c_sizep]),
+    "sda_debug_select_path": (C.c_int, [_SS, C.c_char_p, C.c_char_p, C.c_size_t]),
+}
+
+_loaded = {}          # path -> CDLL with signatures attached
+_active_path = None   # None = LIB_PATH (the release library unless SDA_HIP_LIBRARY says otherwise)
 
 
-def load():
-    """Load libsda_hip.so and attach the signatures.  Raises OSError if it has not been built
-    (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise OSError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); "
+def _load_path(path):
+    lib = _loaded.get(path)
+    if lib is None:
+        if not os.path.exists(path):
+            raise OSError(f"{path} is missing: build it with __graft_entry__.build(); "
                           "there is no fallback implementation")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)           # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
-    return _lib
+        if lib.sda_debug_hooks_compiled_in():
+            for name, (res, args) in HOOK_SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+        _loaded[path] = lib
+    return lib
+
+
+class _ActiveLibrary:
+    """forwards every attribute to the library that is active NOW (see use_test_hooks)"""
+
+    def __getattr__(self, name):
+        lib = _load_path(_active_path or LIB_PATH)
+        if name in HOOK_SIGNATURES and not lib.sda_debug_hooks_compiled_in():
+            raise AttributeError(f"{name} exists only in libsda_hip_test.so: call sda_amd.capi.use_test_hooks() first "
+                                 f"(the release library {active_path()} has no test hooks)")
+        return getattr(lib, name)
+
+
+_proxy = _ActiveLibrary()
+
+
+def load():
+    """The active library (libsda_hip.so unless use_test_hooks() was called), signatures attached.  Raises OSError if it has
+    not been built (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    _load_path(_active_path or LIB_PATH)
+    return _proxy
+
+
+def active_path() -> str:
+    return _active_path or LIB_PATH
+
+
+def has_test_hooks() -> bool:
+    return bool(_load_path(active_path()).sda_debug_hooks_compiled_in())
+
+
+def use_test_hooks():
+    """make libsda_hip_test.so (same objects as the release library + the knob table) the active library of this process"""
+    global _active_path
+    if _active_path == TEST_LIB_PATH:
+        return _proxy
+    if LIB_PATH != RELEASE_LIB_PATH and _load_path(LIB_PATH).sda_debug_hooks_compiled_in():
+        return _proxy                                   # an SDA_HIP_LIBRARY A/B build that carries the hooks itself
+    _load_path(TEST_LIB_PATH)
+    _active_path = TEST_LIB_PATH
+    return _proxy
+
+
+def hooks_library():
+    """libsda_hip_test.so itself (signatures attached) WITHOUT making it the active library: for its stateless helpers - streams,
+    memory figures, the selection table - beside handles that live in the release library (both sit on the one HIP runtime)"""
+    return _load_path(TEST_LIB_PATH)
+
+
+def use_release():
+    """back to LIB_PATH; the knobs of the test library (if it was loaded) are reset first"""
+    global _active_path
+    if _active_path is not None:
+        lib = _loaded.get(_active_path)
+        if lib is not None and lib.sda_debug_hooks_compiled_in():
+            lib.sda_debug_reset_knobs()
+    _active_path = None
+    return _proxy
 
 
 class SdaError(RuntimeError):
@@ -239,8 +316,13 @@ class SdaError(RuntimeError):
         self.message = message
 
 
+LAST_ERROR_SEEN = ""        # text of the last failure check() raised (sda_last_error() is per thread: a watchdog thread reads this)
+
+
 def check(status: int) -> None:
     if status != OK:
+        global LAST_ERROR_SEEN
         lib = load()
         msg = lib.sda_last_error().decode() or lib.sda_strerror(status).decode()
+        LAST_ERROR_SEEN = msg
         raise SdaError(status, msg)

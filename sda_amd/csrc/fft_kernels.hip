@@ -200,7 +200,7 @@ __global__ __launch_bounds__(1024) void packed_gen_fft_kernel(GenLayout L, ModPa
                     if ((uint32_t)w == want_lo) lo = o[w];
                 }
                 const uint64_t bl = 8u * nb + jj;                          // batch inside the workgroup's group
-                const uint64_t pr = f_draw_pair<ROUNDS>(((uint64_t)hi << 32) | lo, kk, stream, (b_first + bl) * (uint64_t)t2 + j, mod.m, mod.lemire_thr);
+                const uint64_t pr = f_draw_pair<ROUNDS>(((uint64_t)hi << 32) | lo, kk, stream, (b_first + bl) * (uint64_t)t2 + j, mod.m, mod.lemire_thr2);
                 X[(size_t)bl * m2 + 1 + k + 2u * j] = (V)(uint32_t)pr;
                 if (2u * j + 1u < t) X[(size_t)bl * m2 + 2 + k + 2u * j] = (V)(uint32_t)(pr >> 32);
             }

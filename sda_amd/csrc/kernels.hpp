@@ -10,7 +10,9 @@ namespace sda {
 struct ModParams {
     uint64_t m;           // modulus, 2 <= m < 2^62
     uint64_t mu;          // floor(2^64 / m)          (Barrett)
-    uint64_t lemire_thr;  // 2^64 mod m               (Lemire rejection threshold)
+    uint64_t lemire_thr;  // 2^64 mod m               (Lemire rejection threshold of the one-word-per-draw rule), for EVERY modulus
+    uint64_t lemire_thr2; // 2^64 mod m^2             (threshold of the PAIRED rule, modarith.hpp) when drbg_paired(m), else 0: a
+                          //                          field of its own, so that no helper can be handed the other rule's threshold
 };
 
 struct MontParams {

@@ -149,7 +149,8 @@ SDA_HD bool lemire_sample(uint64_t x, uint64_t m, uint64_t lemire_thr, uint64_t&
 // draws.  x m m = (ra m + rb) 2^64 + lo is Lemire's method with range m^2 - accept iff lo >= 2^64 mod m^2, then ra m + rb is uniform
 // in [0, m^2) - read off in two steps, x m = ra 2^64 + l1 and l1 m = rb 2^64 + lo ("batched" bounded integers): (ra, rb) is a
 // uniform pair in [0, m)^2, with a rejection probability below 2^-18.  Draws 2j and 2j + 1 of a batch are such a pair; the block
-// counter of draw pair j of batch group g is g * ceil(T / 2) + j.  ModParams::lemire_thr holds 2^64 mod m^2 for these moduli.
+// counter of draw pair j of batch group g is g * ceil(T / 2) + j.  ModParams::lemire_thr2 holds 2^64 mod m^2 for these moduli
+// (lemire_thr stays 2^64 mod m for every modulus).
 // 155 draws per batch of tss's PSS_155_728_100 then cost 78 candidate words instead of 155 (the ChaCha20 blocks are a third of
 // that kernel's vector work).  Spec: DESIGN.md (sda-drbg-v1); vectors: tests/golden/drbg.json.
 static constexpr uint64_t kDrbgPairedMax = 0x7F7F7Full;
@@ -202,9 +203,11 @@ inline uint64_t h_barrett_mu(uint64_t m) {           // floor(2^64 / m), m >= 2
     return (uint64_t)((((u128)1) << 64) / m);
 }
 
-inline uint64_t h_lemire_thr(uint64_t m) {           // 2^64 mod m; for the paired rule's moduli 2^64 mod m^2
-    if (drbg_paired(m)) return (uint64_t)((((u128)1) << 64) % ((u128)m * m));
+inline uint64_t h_lemire_thr(uint64_t m) {           // 2^64 mod m
     return (uint64_t)((((u128)1) << 64) % m);
+}
+inline uint64_t h_lemire_thr2(uint64_t m) {          // the paired rule's threshold 2^64 mod m^2; 0 outside its domain
+    return drbg_paired(m) ? (uint64_t)((((u128)1) << 64) % ((u128)m * m)) : 0;
 }
 
 inline MontCtx h_mont_ctx(uint64_t p) {              // p odd

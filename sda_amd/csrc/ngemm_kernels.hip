@@ -107,7 +107,7 @@ __device__ __noinline__ void ng_load_pass(uint8_t* Bt, const int64_t* sp, const 
     constexpr int ROUNDS_ = WGB / kNgCompute;
     typedef const __attribute__((address_space(1))) int64_t* gptr;           // (a generic pointer argument would be read with flat loads)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, kt = k + t;
-    const ModParams mod{m, mu, 0};
+    const ModParams mod{m, mu, 0, 0};
     const uint32_t term = t_lo + lane;
     const bool is_secret = term < k, is_draw = !is_secret && term < kt;
     const bool reads = is_secret || (is_draw && rp != nullptr);
@@ -186,7 +186,7 @@ template <int KS, int NT> constexpr size_t ngemm_lds_bytes() {      // A ring + 
 // element that falls into its term range).
 template <int WGB>
 __device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t stream, uint64_t b0, uint32_t k, uint32_t t, uint32_t t_lo,
-                                          uint32_t d_lo, uint32_t cd, uint64_t m, uint64_t lemire_thr) {
+                                          uint32_t d_lo, uint32_t cd, uint64_t m, uint64_t thr2) {
     ng_lptr B = (ng_lptr)Bt;
     const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
     const uint32_t d_hi = d_lo + cd, t2 = (t + 1u) >> 1, j_lo = d_lo >> 1, cp = ((d_hi - 1u) >> 1) - j_lo + 1u;   // cd >= 1
@@ -202,7 +202,7 @@ __device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t str
         for (int jj = 0; jj < 8; ++jj) {
             const int cc = jj >> 1, e = jj & 1;
             const uint64_t xw = ((uint64_t)o[8 * e + cc] << 32) | o[8 * e + 4 + cc];
-            const uint64_t pr = f_draw_pair<20>(xw, kk, stream, (b0 + 8u * nb + jj) * (uint64_t)t2 + j, m, lemire_thr);
+            const uint64_t pr = f_draw_pair<20>(xw, kk, stream, (b0 + 8u * nb + jj) * (uint64_t)t2 + j, m, thr2);
             if (w0) ng_put(B, WGB, 8u * nb + jj, k + i0 - t_lo, ng_digits((uint32_t)pr));
             if (w1) ng_put(B, WGB, 8u * nb + jj, k + i1 - t_lo, ng_digits((uint32_t)(pr >> 32)));
         }
@@ -264,7 +264,7 @@ __device__ __forceinline__ void ng_stage(ng_v4i (&bfrag)[NT][KS > 1 ? NgBSource<
 #ifdef NG_TIMING
         ng_tm[0] += __builtin_readcyclecounter() - tq0;
 #endif
-        if (draws_here) ng_draw_pass<WGB>(Bt, key, stream, b0, k, t, t_lo, d_lo, d_hi - d_lo, mod.m, mod.lemire_thr);
+        if (draws_here) ng_draw_pass<WGB>(Bt, key, stream, b0, k, t, t_lo, d_lo, d_hi - d_lo, mod.m, mod.lemire_thr2);
     }
 #ifdef NG_TIMING
     const uint64_t tq1 = __builtin_readcyclecounter();
@@ -308,10 +308,20 @@ struct NgFuse {
     size_t job_stride, n_rows, row_stride, dimension, rows_per_split;
     uint32_t col_blocks, jobs, splits, pad;
     uint64_t n_gen, n_comb, n_comb_wg, period;                    // n_comb items in n_comb_wg workgroups; 0: share generation only
+    uint32_t cu_stride, pad2;                                     // grid positions between two workgroups of one CU (= the device's CU count:
+                                                                  // one workgroup per CU); 0: no prefetch of the next workgroup's secrets
 };
 static constexpr int kNgClerkUnroll = 8;      // row loads in flight per lane in the clerk role (4: 14.9, 8: 14.6, 16: 14.9, 32: 15.9 ms per tile)
 
 template <int KS> struct NgRing { static constexpr int depth = KS == 8 ? 2 : 4; };   // LDS slots of A tiles (a ring of 7 for KS = 4 changed nothing, also not for the 15 MB matrix of n = 19682)
+
+// The store hazard of gfx950 made safe IN THE SOURCE (it used to rest on the compiler's choice of operands alone): a buffer store
+// whose data registers are written again too early can leave with the NEW value (tools/microbench_store_war.hip: 2.5 % of 16-byte
+// stores at 0 wait states, none at 1; see finish_whole below).  The empty-bodied wait takes the stored registers as INPUTS: they
+// stay live and unwritten until it has executed, whatever the register allocator and the scheduler do around it - s_nop 1 = two wait
+// states, one more than the measured need.  tests/test_ngemm_isa.py (and __graft_entry__.build()) check the assembly for it.
+__device__ __forceinline__ void ng_store_guard(ng_v4u v) { asm volatile("s_nop 1" ::"v"(v)); }
+__device__ __forceinline__ void ng_store_guard(ng_v2u v) { asm volatile("s_nop 1" ::"v"(v)); }
 
 template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -329,6 +339,16 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     uint8_t* Junk = Side + (NgBSource<KS>::stash ? kNgCompute * NT * 3 * 1024 : 0);   // 256 bytes nobody reads: where the prefetch loads land
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, col = lane & 15u, g = lane >> 4;
     uint64_t item = blockIdx.x;
+    // grid position -> share-generation item (~0: a clerk position or a surplus one).  Used for this workgroup and for the one
+    // that runs next on this CU (prefetch_next)
+    auto gen_item_at = [&](uint64_t pos) -> uint64_t {
+        if (!F.n_comb_wg) return pos < (uint64_t)gridDim.x ? pos : ~0ull;
+        const uint64_t q = pos / F.period, rem = pos - q * F.period;
+        if (rem == 0 && q < F.n_comb_wg) return ~0ull;
+        const uint64_t before = q + (rem ? 1 : 0);
+        const uint64_t it = pos - (before < F.n_comb_wg ? before : F.n_comb_wg);
+        return it < F.n_gen ? it : ~0ull;
+    };
     if (F.n_comb_wg) {                                               // dual-role grid: which role is this workgroup's?
         const uint64_t q = item / F.period, rem = item - q * F.period;
         if (rem == 0 && q < F.n_comb_wg) {
@@ -494,7 +514,8 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     // and on this chip the store then now and then reads the NEW value: one launch in ten left with row i + 1's first share in row
     // i, 16 lanes of one store, only in the waves that reduce at full speed.  tools/microbench_store_war.hip: 2.5 % of such stores
     // with 0 wait states, none with 1; global_store_dwordx4 needs 2 (the compiler inserts them); 8-byte stores need none
-    // (profiles/r05/microbench_store_war.txt).  tests/test_ngemm_isa.py rejects a 16-byte buffer store with an SGPR soffset.
+    // (profiles/r05/microbench_store_war.txt).  tests/test_ngemm_isa.py rejects a 16-byte buffer store with an SGPR soffset, and
+    // since round 6 every buffer store is followed by ng_store_guard(): the hazard no longer depends on what the compiler hoists.
     // The even columns' shares are reduced first, into registers of their own (the arrangement the kernel shipped with): the data
     // of a store is then not written again for a whole reduction either.
     auto finish_whole = [&](uint32_t rt) {
@@ -505,6 +526,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
             for (int i = 0; i < 4; ++i) {
                 const ng_v2u v = {reduce1(0, i), 0u};
                 __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff, (uint32_t)i * (uint32_t)row_bytes, 2);       // aux 2: non-temporal
+                ng_store_guard(v);
             }
         } else {
 #pragma unroll
@@ -517,6 +539,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
                     const ng_v4u v = {even[i], 0u, reduce1(nt + 1, i), 0u};
                     const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(tbase + (size_t)i * row_bytes, 0, 0xFFFFFFFFu, 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsi, loff + 8 * nt, 0, 2);
+                    ng_store_guard(v);
                 }
             }
         }
@@ -532,7 +555,10 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const ng_v2u v = {reduce1(nt, i), 0u};
-                if ((uint32_t)nt < lim && row0 + (uint32_t)i < P.n) __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff + 8 * nt, (uint32_t)i * (uint32_t)row_bytes, 2);
+                if ((uint32_t)nt < lim && row0 + (uint32_t)i < P.n) {
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rs, loff + 8 * nt, (uint32_t)i * (uint32_t)row_bytes, 2);
+                    ng_store_guard(v);
+                }
             }
     };
     // clerk rows 256 MiB or more apart (33 M batches of one tile): plain 64-bit addresses, computed here and now (the inputs pass
@@ -563,10 +589,12 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     // the same, cache-resident secrets).  global_load_lds: no destination register, nothing to wait for - the four bytes per lane
     // land in LDS nobody reads; compute waves never wait for vmcnt in this loop.
     const uint32_t pf_tile = tiles > 12u ? tiles - 10u : 0u;
-    const uint64_t n_items = F.n_comb_wg ? F.n_gen : (uint64_t)gridDim.x;
     auto prefetch_next = [&]() {
-        const uint64_t nitem = item + 256u;                          // (gfx950: 256 CUs, one workgroup each; blocks b and b + 256 share an XCD)
-        if (nitem >= n_items) return;
+        // one workgroup per CU, dispatched in grid order: the workgroup that follows this one on its CU (and XCD) is cu_stride
+        // grid positions on - in a dual-role grid that position's OWN item (it may be a clerk position: nothing to touch)
+        if (!F.cu_stride) return;
+        const uint64_t nitem = gen_item_at((uint64_t)blockIdx.x + F.cu_stride);
+        if (nitem == ~0ull) return;
         const uint64_t p2 = nitem / chunks, first = (nitem - p2 * chunks) * WGB * (uint64_t)P.k;     // first secret of that workgroup
         if (first >= L.len) return;
         const uint64_t count = L.len - first < (uint64_t)WGB * P.k ? L.len - first : (uint64_t)WGB * P.k;
@@ -613,8 +641,12 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 #endif
 }
 
+// The kernel's prime bound and the paired rule's domain are ONE constant: ng_draw_pass draws with the paired rule unconditionally,
+// and every family must draw the same stream for the same key (the fft, l31 and narrow kernels switch on drbg_paired(m)).
+static constexpr uint64_t kNgPrimeMax = 0x7F7F7Full;                 // v + 0x808080 < 2^24 for every residue: three digits
+static_assert(kNgPrimeMax == kDrbgPairedMax, "the limb GEMM draws with the paired rule for every prime it accepts");
 bool packed_ngemm_path_available(uint32_t k, uint32_t t, uint64_t p) {
-    return k >= 1 && k + t >= 1 && k + t <= 512 && p <= 0x7F7F7Full;   // v + 0x808080 < 2^24 for every residue: three digits
+    return k >= 1 && k + t >= 1 && k + t <= 512 && p <= kNgPrimeMax && drbg_paired(p);
 }
 uint32_t packed_ngemm_steps(uint32_t k, uint32_t t) {                // 64-term steps the compiled instances provide: 1, 2, 4, 8
     const uint32_t need = (k + t + 63) / 64;
@@ -622,6 +654,16 @@ uint32_t packed_ngemm_steps(uint32_t k, uint32_t t) {                // 64-term 
 }
 
 size_t ngemm_tile_bytes(uint32_t ks) { return (size_t)ks * 3 * 1024; }     // one row tile of A fragments
+
+// CUs of the current device (one workgroup per CU: the stride between a workgroup and the next one on its CU); 0 if unknown
+static uint32_t ng_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n > 0 ? (uint32_t)n : 0u;
+}
 
 template <int KS, int NT>
 static hipError_t ngemm_launch(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, hipStream_t s) {
@@ -646,7 +688,9 @@ static hipError_t ngemm_launch(const GenLayout& L, const ModParams& mod, const D
         S.participants = cnt;
         S.first_participant = L.first_participant + p0;
         note_kernel("packed_gen_ngemm_kernel<%d, %d>", KS, NT);
-        kern<<<dim3((unsigned)(chunks * cnt)), dim3(kNgThreads), lds, s>>>(S, mod, key, P, chunks, batches, NgFuse{});
+        NgFuse F{};
+        F.cu_stride = ng_cu_count();
+        kern<<<dim3((unsigned)(chunks * cnt)), dim3(kNgThreads), lds, s>>>(S, mod, key, P, chunks, batches, F);
         if (hipError_t e = hipGetLastError()) return e;
     }
     return hipSuccess;
@@ -692,6 +736,7 @@ static hipError_t ngemm_launch_fused(const GenLayout& L, const ModParams& mod, c
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     *fused = true;
+    F.cu_stride = ng_cu_count();
     note_kernel("packed_gen_ngemm_kernel<%d, %d>", KS, NT);
     kern<<<dim3((unsigned)grid), dim3(kNgThreads), lds, s>>>(L, mod, key, P, chunks ? chunks : 1, batches, F);
     return hipGetLastError();

@@ -98,6 +98,14 @@ extern "C" const char* sda_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sda_abi_version(void) { return SDA_HIP_ABI_VERSION; }
 
 // ---- path-selection knobs (capi_internal.hpp) --------------------------------------------------------------------------
+// TWO builds of this translation unit (the only one that differs between them, __graft_entry__.build()):
+//   libsda_hip.so       the release library: knob() is the constant 0, nothing can redirect kernel selection, no sda_debug_*
+//                       entry point that changes or creates anything is exported;
+//   libsda_hip_test.so  -DSDA_TEST_HOOKS: the knob table and the test-only entry points of include/sda_hip_debug.h.
+#if defined(SDA_AB_KNOBS) && !defined(SDA_TEST_HOOKS)
+#define SDA_TEST_HOOKS 1
+#endif
+#ifdef SDA_TEST_HOOKS
 namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
@@ -134,7 +142,16 @@ extern "C" int sda_debug_env_knobs_compiled_in(void) {
     return 0;
 #endif
 }
-extern "C" const char* sda_version(void) { return "sda-hip 0.5.0 (gfx950)"; }
+extern "C" int sda_debug_hooks_compiled_in(void) { return 1; }
+#else
+long sda::knob(sda::Knob) { return 0; }                       // the release library: every knob is at its default, for good
+extern "C" int sda_debug_hooks_compiled_in(void) { return 0; }
+#endif
+#ifdef SDA_TEST_HOOKS
+extern "C" const char* sda_version(void) { return "sda-hip 0.6.0 (gfx950) +test-hooks"; }
+#else
+extern "C" const char* sda_version(void) { return "sda-hip 0.6.0 (gfx950)"; }
+#endif
 
 // ---- what ran, and what this binary was built from ------------------------------------------------------------------
 // SDA_BUILD_ID is handed in by __graft_entry__.build(): the sha256 (first 16 hex digits) over the library's sources, internal
@@ -153,6 +170,7 @@ void sda::note_kernel(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sda_debug_last_kernel(void) { return g_last_call_kernels; }
+#ifdef SDA_TEST_HOOKS
 extern "C" int sda_debug_stream_create(void** stream) {
     if (!stream) return fail(SDA_ERR_INVALID_ARGUMENT, "stream is NULL");
     hipStream_t s = nullptr;
@@ -173,6 +191,7 @@ extern "C" int sda_debug_mem_info(size_t* free_bytes, size_t* total_bytes) {
     HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
     return SDA_OK;
 }
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // device context
@@ -270,11 +289,17 @@ int make_mod(int64_t modulus, ModParams& mod) {
     mod.m = (uint64_t)modulus;
     mod.mu = h_barrett_mu(mod.m);
     mod.lemire_thr = h_lemire_thr(mod.m);
+    mod.lemire_thr2 = h_lemire_thr2(mod.m);
     return SDA_OK;
 }
 
 }  // namespace
 int capi_make_mod(int64_t modulus, sda::ModParams& mod) { return make_mod(modulus, mod); }
+extern "C" int sda_drbg_draw_rule(int64_t modulus) {
+    ModParams mod;
+    if (int st = make_mod(modulus, mod)) return st;
+    return drbg_paired(mod.m) ? SDA_DRBG_RULE_PAIRED : SDA_DRBG_RULE_WORD;
+}
 namespace {
 
 int os_entropy(void* buf, size_t len) {
@@ -1038,6 +1063,7 @@ extern "C" int sda_share_generator_new(const sda_sharing_scheme_t* scheme, sda_s
     return SDA_OK;
 }
 
+#ifdef SDA_TEST_HOOKS
 // The decision table without a device (tests/test_path_select.py runs it on a machine with no GPU): validates the scheme, builds
 // the host-side facts, calls select_path() under the NAMED knobs (comma separated, NULL / "" = defaults; the process-wide knob
 // state is not read) and describes the choice and what each kind of call would run.
@@ -1080,6 +1106,7 @@ extern "C" int sda_debug_select_path(const sda_sharing_scheme_t* scheme, const c
     sda_share_generator_free(g);
     return st;
 }
+#endif
 
 extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
     if (!g) return;
@@ -1305,16 +1332,17 @@ struct sda_share_combiner {
     // generate_combine_dev on stream A followed by finish_dev on stream B is ordered by the library, not by the caller
     // (clerk.rs:80-86 has one thread and no streams: the reference's caller cannot be asked to keep such a rule).
     hipEvent_t ev_done = nullptr;
-    hipStream_t last_stream = nullptr;
     bool pending = false;
+    // (the wait is issued whenever work is pending, also on the stream that recorded it - there it costs nothing - instead of
+    // comparing hipStream_t handles: a stream the caller destroyed and a new one that reuses its handle must not look alike)
     int join_pending(hipStream_t s) {
-        if (pending && s != last_stream) HIP_TRY(hipStreamWaitEvent(s, ev_done, 0));
+        if (pending) HIP_TRY(hipStreamWaitEvent(s, ev_done, 0));
         return SDA_OK;
     }
     int mark_pending(hipStream_t s) {
         if (!ev_done) HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev_done, s));
-        last_stream = s; pending = true;
+        pending = true;
         return SDA_OK;
     }
 };
@@ -1496,7 +1524,12 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     explicit_bzero(&key, sizeof key);
     // every path above leaves clerk-sum work for `c` in flight on `s` (after the join): whoever next uses the combiner on ANOTHER
     // stream waits for this point (sda_share_combiner::join_pending)
-    if (st == SDA_OK && prev_participants > 0) st = c->mark_pending(s);
+    // - ALSO when the call failed part-way (e.g. the share-generation launch after the clerk-sum update was queued): a later
+    // finish_dev on another stream must wait for what is already in flight
+    if (prev_participants > 0) {
+        const int mp = c->mark_pending(s);
+        if (st == SDA_OK) st = mp;
+    }
     if (fused) snprintf(g_last_call_kernels, sizeof g_last_call_kernels, "%s", g_last_gen_kernel);
     else snprintf(g_last_call_kernels, sizeof g_last_call_kernels, "%s%s%s", g_last_gen_kernel, g_last_gen_kernel[0] && prev_participants ? " + " : "",
                   prev_participants ? (side ? "combine_update_walk_kernel (side stream)" : "combine_update_kernel (two launches)") : "");
@@ -1749,7 +1782,7 @@ extern "C" int sda_secret_reconstructor_reconstruct(sda_secret_reconstructor_t* 
 namespace {
 struct MaskCore {
     sda_masking_scheme_t scheme;
-    ModParams mod{0, 0, 0};
+    ModParams mod{0, 0, 0, 0};
     Ctx ctx;
     AccState acc;
     DevBuf tile, d_a, d_b, d_out, d_seeds, d_flags, d_list;

@@ -39,6 +39,7 @@ struct Rccl {
     NcclResult (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     NcclResult (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(NcclResult) = nullptr;
+    NcclResult (*GetVersion)(int*) = nullptr;      // optional (diagnostics only)
 };
 
 Rccl g_rccl;
@@ -65,6 +66,7 @@ int load_rccl() {
     BIND(Recv, "ncclRecv")
     BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
+    *reinterpret_cast<void**>(&r.GetVersion) = dlsym(h, "ncclGetVersion");
     g_rccl = r;
     return SDA_OK;
 }
@@ -140,6 +142,12 @@ extern "C" void sda_comm_free(sda_comm_t* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
+}
+
+extern "C" int sda_comm_rccl_version(void) {
+    int v = 0;
+    if (!g_rccl.handle || !g_rccl.GetVersion || g_rccl.GetVersion(&v)) return 0;
+    return v;
 }
 
 extern "C" int sda_comm_rank(const sda_comm_t* c) { return c ? c->rank : -1; }

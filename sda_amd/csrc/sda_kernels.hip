@@ -117,16 +117,16 @@ __device__ __forceinline__ void drbg_pair(const DrbgKey& key, const QuadCol& qc,
     const uint64_t x1 = ((uint64_t)o2 << 32) | o3;
     if (paired) {
         uint32_t a0, b0, a1, b1;
-        const bool ok0 = lemire_pair(x0, (uint32_t)mod.m, mod.lemire_thr, a0, b0);
-        const bool ok1 = lemire_pair(x1, (uint32_t)mod.m, mod.lemire_thr, a1, b1);
+        const bool ok0 = lemire_pair(x0, (uint32_t)mod.m, mod.lemire_thr2, a0, b0);
+        const bool ok1 = lemire_pair(x1, (uint32_t)mod.m, mod.lemire_thr2, a1, b1);
         r0 = (i & 1u) ? b0 : a0;
         r1 = (i & 1u) ? b1 : a1;
         if (__builtin_expect(!ok0, 0))
             r0 = drbg_retry_pair<ROUNDS>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
-                                         (2 * pair) * (uint64_t)T2 + j, mod.m, mod.lemire_thr, i & 1u);
+                                         (2 * pair) * (uint64_t)T2 + j, mod.m, mod.lemire_thr2, i & 1u);
         if (__builtin_expect(!ok1, 0))
             r1 = drbg_retry_pair<ROUNDS>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
-                                         (2 * pair + 1) * (uint64_t)T2 + j, mod.m, mod.lemire_thr, i & 1u);
+                                         (2 * pair + 1) * (uint64_t)T2 + j, mod.m, mod.lemire_thr2, i & 1u);
         return;
     }
     const bool ok0 = lemire_sample(x0, mod.m, mod.lemire_thr, r0);

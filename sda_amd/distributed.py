@@ -14,7 +14,6 @@ torch.distributed is plumbing here (RCCL over xGMI with backend "nccl"; gloo on 
 """
 from __future__ import annotations
 
-import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -43,13 +42,16 @@ def _hip_modsum_parts(parts: torch.Tensor, modulus: int) -> torch.Tensor:
 
 
 def modular_allreduce(partial: torch.Tensor, modulus: int, group=None,
-                      local_modsum: Optional[Callable[[torch.Tensor, int], torch.Tensor]] = None) -> torch.Tensor:
+                      local_modsum: Optional[Callable[[torch.Tensor, int], torch.Tensor]] = None,
+                      force_collectives: bool = False) -> torch.Tensor:
     """Sum of every rank's `partial` (int64 residues, any shape, same on all ranks) modulo `modulus`,
-    returned on every rank.  `local_modsum(parts[G][len], modulus) -> [len]` defaults to the HIP kernel."""
+    returned on every rank.  `local_modsum(parts[G][len], modulus) -> [len]` defaults to the HIP kernel.
+    `force_collectives`: a ONE-rank group still goes through all_to_all / all_gather (tests of the exchange on one
+    device); an argument, not an environment variable - nothing in this package reads the environment to steer the path."""
     reduce_fn = local_modsum or _hip_modsum_parts
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     flat = partial.reshape(-1).contiguous()
-    force = dist.is_initialized() and os.environ.get("SDA_FORCE_COLLECTIVES") == "1"   # exercise RCCL with 1 rank
+    force = dist.is_initialized() and force_collectives                                 # exercise the exchange with 1 rank
     if world == 1 and not force:
         return reduce_fn(flat.unsqueeze(0), modulus).reshape(partial.shape)
     n = flat.numel()

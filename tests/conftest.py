@@ -41,18 +41,25 @@ VARINT_PATHS = {"stream": 1, "scan": 2}
 
 
 def set_knob(name, value=1):
-    """select a non-default kernel / schedule through the library's test-only entry point (include/sda_hip_debug.h); the
-    release library reads no environment variable.  Reset after every test by the fixture below."""
+    """select a non-default kernel / schedule through the test-only entry point of include/sda_hip_debug.h.  The RELEASE library
+    (libsda_hip.so) has no knob table: the first call makes libsda_hip_test.so - the same objects, sda_capi.cpp rebuilt with
+    -DSDA_TEST_HOOKS - the active library of this process (sda_amd.capi.use_test_hooks); the fixture below resets the knobs and
+    goes back to the release library after every test, so every test that does NOT touch a knob runs on the shipped binary."""
     from sda_amd import capi
     if isinstance(value, str):
         value = VARINT_PATHS[value] if name == "SDA_VARINT_PATH" else int(value)
+    capi.use_test_hooks()
     capi.check(capi.load().sda_debug_set_knob(name.encode(), value))
+
+
+def use_test_hooks():
+    """tests that need the helpers of the test library without a knob (streams, memory figures, the selection table)"""
+    from sda_amd import capi
+    return capi.use_test_hooks()
 
 
 @pytest.fixture(autouse=True)
 def _reset_knobs():
     yield
     if "sda_amd.capi" in sys.modules:
-        lib = sys.modules["sda_amd.capi"]._lib if hasattr(sys.modules["sda_amd.capi"], "_lib") else None
-        if lib is not None:
-            lib.sda_debug_reset_knobs()
+        sys.modules["sda_amd.capi"].use_release()          # resets the knobs of the test library if it was active

@@ -26,29 +26,73 @@ def test_library_exports_every_declared_symbol(built):
     lib = capi.load()
     declared = _declared()
     assert len(declared) >= 50
-    assert declared == set(capi.SIGNATURES), (declared ^ set(capi.SIGNATURES))
-    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
-    exported = set(re.findall(r" T (sda_[a-z0-9_]+)", out))
-    assert declared <= exported, declared - exported
-    assert lib.sda_abi_version() == 5 and b"gfx950" in lib.sda_version()
+    everything = set(capi.SIGNATURES) | set(capi.HOOK_SIGNATURES)
+    assert declared == everything, (declared ^ everything)
+    # the release library exports the boundary (+ the two read-only queries), the test library the hooks as well
+    for path, want in ((capi.RELEASE_LIB_PATH, set(capi.SIGNATURES)), (capi.TEST_LIB_PATH, everything)):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        exported = set(re.findall(r" T (sda_[a-z0-9_]+)", out))
+        assert want <= exported, (path, want - exported)
+    assert lib.sda_abi_version() == 6 and b"gfx950" in lib.sda_version()
 
 
 def test_release_library_reads_no_environment_variable(built):
     """kernel selection of a crypto library is not steered by the process environment: the shipped build has no getenv
     import at all (the A/B variant, -DSDA_AB_KNOBS, is built by tools/build_ab_variant.sh only), knobs move only through
-    the test-only sda_debug_set_knob, unknown names are refused, and the Python package and the library agree on the version."""
+    the test-only sda_debug_set_knob OF THE TEST LIBRARY, unknown names are refused, and the Python package and the library
+    agree on the version."""
     import sda_amd
     from sda_amd import capi
     lib = capi.load()
-    und = subprocess.check_output(["nm", "-D", "--undefined-only", capi.LIB_PATH], text=True)
-    assert not re.search(r"\bU (secure_)?getenv\b", und), "the release library imports getenv"
-    assert lib.sda_debug_env_knobs_compiled_in() == 0
-    assert lib.sda_debug_set_knob(b"SDA_FORCE_MFMA", 1) == capi.OK
-    lib.sda_debug_reset_knobs()
-    assert lib.sda_debug_set_knob(b"SDA_NO_SUCH_KNOB", 1) == capi.ERR_INVALID_ARGUMENT
+    for path in (capi.RELEASE_LIB_PATH, capi.TEST_LIB_PATH):
+        und = subprocess.check_output(["nm", "-D", "--undefined-only", path], text=True)
+        assert not re.search(r"\bU (secure_)?getenv\b", und), path + " imports getenv"
     assert sda_amd.__version__.encode() in lib.sda_version()
+    hooks = capi.use_test_hooks()
+    try:
+        assert hooks.sda_debug_env_knobs_compiled_in() == 0
+        assert hooks.sda_debug_set_knob(b"SDA_FORCE_MFMA", 1) == capi.OK
+        hooks.sda_debug_reset_knobs()
+        assert hooks.sda_debug_set_knob(b"SDA_NO_SUCH_KNOB", 1) == capi.ERR_INVALID_ARGUMENT
+        assert sda_amd.__version__.encode() in hooks.sda_version() and b"+test-hooks" in hooks.sda_version()
+    finally:
+        capi.use_release()
     build_py = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert "SDA_AB_KNOBS" not in build_py.split("def smoke")[0].replace("# SDA_AB_KNOBS", "")
+    # nothing outside the C ABI reads the environment to steer the product either (bench.py and tools/ are measurement tools)
+    for f in ("distributed.py", "crypto.py", "capi.py", "device.py"):
+        text = open(os.path.join(ROOT, "sda_amd", f)).read()
+        names = set(re.findall(r"environ(?:\.get)?\(?\[?[\"']([A-Z_]+)", text))
+        assert names <= {"SDA_HIP_LIBRARY"}, (f, names)
+
+
+def test_release_library_has_no_test_hooks(built):
+    """`nm -D libsda_hip.so | grep sda_debug_set_knob` is empty.  The release library exports none of the
+    entry points of include/sda_hip_debug.h that change or create anything (the knob table, the stream helpers, the selection
+    table); only the two read-only queries.  libsda_hip_test.so - same objects, sda_capi.cpp rebuilt with -DSDA_TEST_HOOKS -
+    exports all of them; both carry the build id of the tree; the loader refuses a hook on the release library by name."""
+    import ctypes
+    from sda_amd import capi
+    import __graft_entry__ as g
+
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return set(re.findall(r" T (sda_[a-z0-9_]+)", out))
+    rel, tst = exported(capi.RELEASE_LIB_PATH), exported(capi.TEST_LIB_PATH)
+    assert {n for n in rel if n.startswith("sda_debug_")} == {"sda_debug_last_kernel", "sda_debug_hooks_compiled_in"}
+    assert set(capi.HOOK_SIGNATURES) <= tst and not (set(capi.HOOK_SIGNATURES) & rel)
+    assert tst - rel == set(capi.HOOK_SIGNATURES), "the two libraries differ in the hooks only"
+    for path, want in ((capi.RELEASE_LIB_PATH, 0), (capi.TEST_LIB_PATH, 1)):
+        so = ctypes.CDLL(path)
+        so.sda_build_id.restype = ctypes.c_char_p
+        assert so.sda_debug_hooks_compiled_in() == want and so.sda_build_id().decode() == g.source_digest()
+    assert capi.active_path() == capi.RELEASE_LIB_PATH and not capi.has_test_hooks()
+    with pytest.raises(AttributeError, match="libsda_hip_test.so"):
+        capi.load().sda_debug_set_knob
+    # every function declared in the debug header is one of the two kinds
+    hdr = open(os.path.join(ROOT, "include", "sda_hip_debug.h")).read()
+    declared = set(re.findall(r"\b(sda_debug_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.HOOK_SIGNATURES) | {"sda_debug_last_kernel", "sda_debug_hooks_compiled_in"}, declared
 
 
 def test_host_side_under_address_and_undefined_behaviour_sanitizers(built):
@@ -142,10 +186,13 @@ def test_fails_loudly_without_a_gpu(built):
 
 def test_missing_library_raises(built, monkeypatch):
     from sda_amd import capi
-    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "_loaded", {})
     monkeypatch.setattr(capi, "LIB_PATH", os.path.join(ROOT, "sda_amd", "lib", "nope.so"))
     with pytest.raises(OSError, match="no fallback"):
         capi.load()
+    monkeypatch.setattr(capi, "TEST_LIB_PATH", os.path.join(ROOT, "sda_amd", "lib", "nope_test.so"))
+    with pytest.raises(OSError, match="no fallback"):
+        capi.use_test_hooks()
 
 
 def test_abi_misuse_returns_codes_not_crashes(built):

@@ -171,3 +171,75 @@ def test_bench_starts_its_own_ranks_and_reports_the_first_failure():
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert time.time() - t0 < 240
+
+
+def _bench_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
+                                                             "SDA_SHARE_GPU", "SDA_BENCH_TEST_HANG", "SDA_BENCH_LAUNCHER_T0")}
+    env.update(extra)
+    return env
+
+
+def test_bench_launcher_deadline_ends_a_run_in_which_a_rank_never_returns():
+    """`python bench.py --gpus 2` in which the ranks never come back (SDA_BENCH_TEST_HANG: every rank sleeps
+    forever when it enters its first phase - the stand-in for a send/recv group that deadlocks between two devices).  Nobody
+    EXITS, so the first-failure rule never fires: the launcher's --deadline-s must end all ranks and come back with the
+    distinct exit code 4 (EXIT_DEADLINE), no JSON line on stdout, and a stderr that says where each rank was."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--deadline-s", "6"], capture_output=True, text=True, timeout=120,
+                         env=_bench_env(SDA_BENCH_TEST_HANG="start:*"), cwd=root)
+    took = time.time() - t0
+    assert out.returncode == 4, (out.returncode, out.stderr[-2000:])
+    assert "{" not in out.stdout, out.stdout
+    assert took < 6 + 20, took                                   # the deadline, the grace of SIGTERM -> SIGKILL, interpreter start-up
+    assert "launcher: --deadline-s 6 passed with rank(s) [0, 1] still running" in out.stderr
+    for r in (0, 1):                                             # the heartbeat: every rank's last phase line
+        assert f"[bench] rank {r}/2 " in out.stderr and "phase: start" in out.stderr
+
+
+def test_bench_rank_watchdog_ends_a_hung_rank_without_a_launcher():
+    """the same hang with NO launcher of ours around the rank (the driver starts N > 1 runs with torch.distributed.run, which
+    only reacts to a rank that exits): the rank's own watchdog thread ends it at --deadline-s with exit code 4 and a
+    diagnosis on stderr; torch.distributed.run then takes the other ranks down."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                          "--deadline-s", "4"], capture_output=True, text=True, timeout=120,
+                         env=_bench_env(SDA_BENCH_TEST_HANG="start:0"), cwd=root)
+    assert out.returncode == 4, (out.returncode, out.stderr[-2000:])
+    assert "{" not in out.stdout and time.time() - t0 < 30
+    assert "WATCHDOG: --deadline-s 4 passed in phase 'start'" in out.stderr and "exiting with code 4, no JSON line" in out.stderr
+
+
+def test_bench_phase_limit_has_its_own_exit_code():
+    """a phase with a limit of its own (the cross-rank exchanges: communicator set-up, warm-up and timed modular reduce) ends
+    the rank with exit code 5 (EXIT_EXCHANGE) when it overruns - checked on the watchdog class itself, in a child process that
+    sits in such a phase"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "wd = bench.Watchdog(1, 8, 600.0, 1.5)\n"
+            "wd.diag = lambda: 'peers [a, b], RCCL version 22105'\n"
+            "wd.exchange('warm-up exchange: test')\n"
+            "time.sleep(60)\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=_bench_env(), cwd=root)
+    assert out.returncode == 5, (out.returncode, out.stderr)
+    assert "rank 1/8 WATCHDOG: phase 'warm-up exchange: test' did not finish within its limit of 1.5 s" in out.stderr
+    assert "peers [a, b], RCCL version 22105" in out.stderr and "phase: warm-up exchange: test (limit 1.5 s)" in out.stderr
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_codes", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert (bench.EXIT_COMM, bench.EXIT_DEADLINE, bench.EXIT_EXCHANGE) == (3, 4, 5)
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    for word in ("EXIT_COMM", "EXIT_DEADLINE", "EXIT_EXCHANGE", "--deadline-s", "--exchange-timeout-s"):
+        assert word in design, word + " is not documented in DESIGN.md 6"

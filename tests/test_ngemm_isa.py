@@ -17,13 +17,13 @@ INSTANCES = {"1ELi4": 36, "2ELi2": 36, "4ELi2": 72, "8ELi1": 72}          # <KS,
 
 
 @pytest.fixture(scope="module")
-def assembly(tmp_path_factory):
+def assembly():
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
-    out = tmp_path_factory.mktemp("isa") / "ngemm.s"
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", str(out),
-                    os.path.join(ROOT, "sda_amd", "csrc", "ngemm_kernels.hip")], check=True, capture_output=True, cwd=str(out.parent), timeout=600)
-    return out.read_text().split("\n")
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    return g.ngemm_assembly()
 
 
 def kernel_body(lines, tag):
@@ -61,12 +61,34 @@ def test_row_loop_is_free_of_scratch_accesses(assembly, tag, mfma):
 
 
 
-def test_no_16_byte_buffer_store_with_a_scalar_offset(assembly):
+def test_buffer_stores_are_guarded_against_the_store_hazard(assembly):
     """hipcc puts no wait state between `buffer_store_dwordx4 ..., s<N> offen` and a write to its data registers (its hazard table
     exempts MUBUF stores whose soffset is a register); on gfx950 such a store then reads the new value in 2.5 % of the cases
     (tools/microbench_store_war.hip; with soffset 0 the compiler inserts the wait state that is enough).  This cost round 5 a wrong
-    4 x 4 block of shares in one launch of ten."""
-    stores = [l.split(";")[0].strip() for l in assembly if "buffer_store_dwordx4" in l or "buffer_store_dwordx3" in l]
+    4 x 4 block of shares in one launch of ten.  Since round 6 the SOURCE carries the wait state (ng_store_guard: an `s_nop 1` that
+    takes the stored registers as inputs); __graft_entry__.store_hazard_findings checks both rules on the assembly, and build()
+    runs the same check before it links anything."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    assert g.store_hazard_findings(assembly) == []
+    stores = [l for l in assembly if l.strip().startswith("buffer_store_dwordx4")]
     assert stores, "the whole-tile path stores 16 bytes per lane"
-    bad = [l for l in stores if re.search(r"s\[\d+:\d+\],\s*s\d+", l)]
-    assert not bad, bad[:4]
+
+
+def test_the_store_hazard_check_finds_what_it_is_for():
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    ok = ["buffer_store_dwordx4 v[60:63], v136, s[16:19], 0 offen nt", "v_mad_i64_i32 v[0:1], s[16:17], v2, v148, 0", ";;#ASMSTART", "s_nop 1",
+          "v_mov_b32 v60, v1"]
+    assert g.store_hazard_findings(ok) == []
+    early = ["buffer_store_dwordx4 v[60:63], v136, s[16:19], 0 offen nt", "v_mov_b32 v61, v1", "s_nop 1"]
+    assert len(g.store_hazard_findings(early)) == 1
+    wide = ["buffer_store_dwordx2 v[128:129], v136, s[24:27], s38 offen nt", "v_mad_i64_i32 v[128:129], s[16:17], v2, v148, 0", "s_nop 1"]
+    assert len(g.store_hazard_findings(wide)) == 1
+    soff = ["buffer_store_dwordx4 v[60:63], v136, s[16:19], s38 offen nt", "s_nop 1"]
+    assert any("scalar offset" in f for f in g.store_hazard_findings(soff))
+    unguarded = ["buffer_store_dwordx4 v[60:63], v136, s[16:19], 0 offen nt", "v_add_u32 v1, v2, v3", "s_endpgm"]
+    assert len(g.store_hazard_findings(unguarded)) == 1
+    assert g.store_hazard_findings(["v_add_u32 v1, v2, v3"]) != []          # no store at all: wrong file

@@ -1065,27 +1065,27 @@ def test_comm_c_abi_single_rank_rccl(gpu, monkeypatch):
     import ctypes as C
     from sda_amd.capi import check
     from sda_amd.device import DeviceBuffer
-    ident = (C.c_uint8 * 128)()
-    check(gpu.sda_comm_unique_id(ident))
-    comm = C.c_void_p()
-    check(gpu.sda_comm_init(ident, 0, 1, C.byref(comm)))
-    assert gpu.sda_comm_rank(comm) == 0 and gpu.sda_comm_world(comm) == 1
     rng = np.random.default_rng(11)
-    try:
-        for force in (False, True):
-            if force:
-                set_knob("SDA_FORCE_COLLECTIVES", "1")
+    for force in (False, True):
+        if force:
+            set_knob("SDA_FORCE_COLLECTIVES", "1")      # (libsda_hip_test.so from here on: the communicator is made in the library that uses it)
+        ident = (C.c_uint8 * 128)()
+        check(gpu.sda_comm_unique_id(ident))
+        comm = C.c_void_p()
+        check(gpu.sda_comm_init(ident, 0, 1, C.byref(comm)))
+        assert gpu.sda_comm_rank(comm) == 0 and gpu.sda_comm_world(comm) == 1 and gpu.sda_comm_rccl_version() > 20000
+        try:
             for n in (1, 7, 1000, 22369 * 8 + 3):
                 v = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
                 d, o = DeviceBuffer.from_numpy(v), DeviceBuffer(n)
                 check(gpu.sda_modular_allreduce_dev(comm, P62, d.ptr, n, o.ptr, None))
                 check(gpu.sda_dev_synchronize())
                 assert np.array_equal(o.to_numpy(), np.mod(v.astype(object), P62).astype(np.int64)), (force, n)
-        check(gpu.sda_modular_allreduce_dev(comm, P62, None, 0, None, None))           # empty vector: nothing to do
-        assert gpu.sda_modular_allreduce_dev(None, P62, None, 0, None, None) == capi_err()
-        assert gpu.sda_comm_init(ident, 1, 1, C.byref(C.c_void_p())) == capi_err()    # rank out of range
-    finally:
-        gpu.sda_comm_free(comm)
+            check(gpu.sda_modular_allreduce_dev(comm, P62, None, 0, None, None))           # empty vector: nothing to do
+            assert gpu.sda_modular_allreduce_dev(None, P62, None, 0, None, None) == capi_err()
+            assert gpu.sda_comm_init(ident, 1, 1, C.byref(C.c_void_p())) == capi_err()    # rank out of range
+        finally:
+            gpu.sda_comm_free(comm)
 
 
 def capi_err():
@@ -1581,6 +1581,41 @@ def test_bench_launches_its_own_ranks(gpu, tmp_path):
     assert refused.returncode == 3, (refused.returncode, refused.stderr[-1500:])
     assert "FATAL" in refused.stderr
     assert not [l for l in refused.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_exchange_watchdog_ends_a_run_whose_peer_never_arrives(gpu, tmp_path, launcher):
+    """VERDICT r5 item 1 on the GPU box: two ranks (sharing this box's GPU), rank 1 falls asleep when it enters the WARM-UP
+    EXCHANGE - the first modular reduce between the ranks, the call no multi-GPU run has ever made.  Rank 0 is then inside the
+    exchange waiting for a peer that never arrives: its watchdog must end it after --exchange-timeout-s with exit code 5, a
+    diagnosis (rank, device, peers, exchange path, RCCL version) on stderr and NO JSON line; the launcher - ours or
+    torch.distributed.run - comes back promptly with a non-zero code."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(SDA_SHARE_GPU="1", SDA_BENCH_TEST_HANG="warm-up exchange:1")
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--participants", "40", "--dim", "65536",
+            "--no-cpu-baseline", "--no-additional", "--exchange-timeout-s", "10", "--deadline-s", "300",
+            "--details", os.path.join(str(tmp_path), "d.json")]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", _free_port()] + args
+    else:
+        cmd = [sys.executable] + args
+    t0 = time.time()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    took = time.time() - t0
+    assert out.returncode != 0 and (launcher == "torchrun" or out.returncode == 5), (out.returncode, out.stderr[-3000:])
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout
+    assert took < 240, took
+    err = out.stderr
+    assert "WATCHDOG: phase 'warm-up exchange: packed" in err and "did not finish within its limit of 10 s" in err
+    assert "exiting with code 5, no JSON line" in err and "peers [" in err and "RCCL version" in err
+    assert "SDA_BENCH_TEST_HANG: sleeping forever in phase 'warm-up exchange" in err
+    for r in (0, 1):
+        assert f"[bench] rank {r}/2 " in err
 
 
 def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu, tmp_path):

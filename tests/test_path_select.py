@@ -29,7 +29,7 @@ def lib():
     import __graft_entry__ as ge
     ge.build()
     from sda_amd import capi
-    return capi.load()
+    return capi.hooks_library()          # sda_debug_select_path (stateless) lives in libsda_hip_test.so only
 
 
 def select(lib, k, t, n, p, w2, w3, knobs=""):

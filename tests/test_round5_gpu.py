@@ -24,7 +24,7 @@ class Stream:
     def __init__(self):
         import ctypes as C
         from sda_amd import capi
-        self._lib, self._h = capi.load(), C.c_void_p()
+        self._lib, self._h = capi.hooks_library(), C.c_void_p()       # stateless helpers of libsda_hip_test.so; the handles stay in the release library
         capi.check(self._lib.sda_debug_stream_create(C.byref(self._h)))
         self.cuda_stream = self._h.value
 
@@ -43,7 +43,7 @@ def mem_free():
     import ctypes as C
     from sda_amd import capi
     f, t = C.c_size_t(), C.c_size_t()
-    capi.check(capi.load().sda_debug_mem_info(C.byref(f), C.byref(t)))
+    capi.check(capi.hooks_library().sda_debug_mem_info(C.byref(f), C.byref(t)))
     return f.value
 
 P62 = 4611686006577364993
