@@ -308,10 +308,14 @@ struct NgFuse {
     size_t job_stride, n_rows, row_stride, dimension, rows_per_split;
     uint32_t col_blocks, jobs, splits, pad;
     uint64_t n_gen, n_comb, n_comb_wg, period;                    // n_comb items in n_comb_wg workgroups; 0: share generation only
-    uint32_t cu_stride, pad2;                                     // grid positions between two workgroups of one CU (= the device's CU count:
+    uint64_t n_early;                                             // clerk workgroups 0 .. n_early - 1 sit at positions c * period among the share-generation
+                                                                  // workgroups, the others FOLLOW the last share-generation workgroup (they fill its tail)
+    uint32_t items_per_wg;                                        // clerk items one clerk workgroup sums (even: one per half of the compute waves at a time)
+    uint32_t cu_stride;                                     // grid positions between two workgroups of one CU (= the device's CU count:
                                                                   // one workgroup per CU); 0: no prefetch of the next workgroup's secrets
 };
 static constexpr int kNgClerkUnroll = 8;      // row loads in flight per lane in the clerk role (4: 14.9, 8: 14.6, 16: 14.9, 32: 15.9 ms per tile)
+static constexpr int kNgClerkUnrollShort = 20; // ... for items of a few rows (40 participants of PSS_155_19682_100: two rounds of loads instead of five)
 
 template <int KS> struct NgRing { static constexpr int depth = KS == 8 ? 2 : 4; };   // LDS slots of A tiles (a ring of 7 for KS = 4 changed nothing, also not for the 15 MB matrix of n = 19682)
 
@@ -341,29 +345,48 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     uint64_t item = blockIdx.x;
     // grid position -> share-generation item (~0: a clerk position or a surplus one).  Used for this workgroup and for the one
     // that runs next on this CU (prefetch_next)
-    auto gen_item_at = [&](uint64_t pos) -> uint64_t {
-        if (!F.n_comb_wg) return pos < (uint64_t)gridDim.x ? pos : ~0ull;
+    // grid position -> clerk workgroup index (role 1) or share-generation item (role 0); role 2: a surplus position
+    auto role_at = [&](uint64_t pos, uint64_t& idx) -> int {
+        if (!F.n_comb_wg) { idx = pos; return pos < (uint64_t)gridDim.x ? 0 : 2; }
+        const uint64_t mixed = F.n_gen + F.n_early;                 // positions below this: share generation with the early clerk positions in between
+        if (pos >= mixed) { idx = F.n_early + (pos - mixed); return idx < F.n_comb_wg ? 1 : 2; }
         const uint64_t q = pos / F.period, rem = pos - q * F.period;
-        if (rem == 0 && q < F.n_comb_wg) return ~0ull;
-        const uint64_t before = q + (rem ? 1 : 0);
-        const uint64_t it = pos - (before < F.n_comb_wg ? before : F.n_comb_wg);
-        return it < F.n_gen ? it : ~0ull;
+        if (rem == 0 && q < F.n_early) { idx = q; return 1; }
+        const uint64_t before = q + (rem ? 1 : 0);                   // clerk positions below this one
+        idx = pos - (before < F.n_early ? before : F.n_early);
+        return idx < F.n_gen ? 0 : 2;
     };
-    if (F.n_comb_wg) {                                               // dual-role grid: which role is this workgroup's?
-        const uint64_t q = item / F.period, rem = item - q * F.period;
-        if (rem == 0 && q < F.n_comb_wg) {
-            const uint64_t it = 2 * q + (tid >> 8);                  // threads 0-255: item 2 q, threads 256-511: item 2 q + 1
-            if (tid < 512u && it < F.n_comb) {
-                const uint64_t bx = it % F.col_blocks, rest = it / F.col_blocks;
-                combine_pair<true, kNgClerkUnroll>(F.acc_lo, F.acc_hi, F.prev, F.job_stride, F.n_rows, F.row_stride, F.dimension,
-                                                   F.rows_per_split, F.splits > 1, bx * 256u + (tid & 255u), rest % F.jobs, rest / F.jobs);
+    {
+        uint64_t idx;
+        const int role = role_at(item, idx);
+        if (role == 2) return;
+        if (role == 1) {
+            // a clerk workgroup sums items_per_wg consecutive items (adjacent column blocks of one job, then the next job's): two at a
+            // time, threads 0-255 the even one and threads 256-511 the odd one.  (One pair per workgroup, as the launch had it for
+            // shapes with fewer clerk items than share-generation workgroups, made 206 k clerk workgroups of PSS_155_19682_100's 413 k
+            // items - all of them in front of the 1640 share-generation workgroups: the two roles ran one after the other.)
+            if (tid < 512u) {
+                const uint64_t first = idx * F.items_per_wg + (tid >> 8);
+                for (uint32_t j = 0; j < F.items_per_wg; j += 2) {
+                    const uint64_t it = first + j;
+                    if (it >= F.n_comb) break;
+                    const uint64_t bx = it % F.col_blocks, rest = it / F.col_blocks;
+                    if (F.rows_per_split % kNgClerkUnrollShort == 0 && F.rows_per_split <= 4 * kNgClerkUnrollShort)
+                        combine_pair<true, kNgClerkUnrollShort>(F.acc_lo, F.acc_hi, F.prev, F.job_stride, F.n_rows, F.row_stride, F.dimension,
+                                                                F.rows_per_split, F.splits > 1, bx * 256u + (tid & 255u), rest % F.jobs, rest / F.jobs);
+                    else
+                        combine_pair<true, kNgClerkUnroll>(F.acc_lo, F.acc_hi, F.prev, F.job_stride, F.n_rows, F.row_stride, F.dimension,
+                                                           F.rows_per_split, F.splits > 1, bx * 256u + (tid & 255u), rest % F.jobs, rest / F.jobs);
+                }
             }
             return;
         }
-        const uint64_t before = q + (rem ? 1 : 0);                   // clerk positions below this one
-        item -= before < F.n_comb_wg ? before : F.n_comb_wg;
-        if (item >= F.n_gen) return;                                 // surplus position
+        item = idx;
     }
+    auto gen_item_at = [&](uint64_t pos) -> uint64_t {               // the share-generation item at a grid position, ~0 if it has none
+        uint64_t idx;
+        return role_at(pos, idx) == 0 ? idx : ~0ull;
+    };
     const uint64_t p = item / chunks, chunk = item - p * chunks;
     const uint64_t b0 = chunk * WGB;
     const int64_t* sp = L.secrets + p * L.secrets_stride;
@@ -722,12 +745,27 @@ static hipError_t ngemm_launch_fused(const GenLayout& L, const ModParams& mod, c
     splits = have_comb ? (prev_rows + F.rows_per_split - 1) / F.rows_per_split : 1;
     F.splits = (uint32_t)splits;
     F.n_comb = have_comb ? (uint64_t)F.col_blocks * F.jobs * splits : 0;
-    F.n_comb_wg = (F.n_comb + 1) / 2;
+    // Clerk workgroups: a pair of items each while that leaves at least two share-generation workgroups per clerk workgroup; a shape with
+    // MORE clerk items than that (19682 clerk rows x 40 participants: 413 k items beside 1640 share-generation workgroups) gets
+    // persistent clerk workgroups of items_per_wg items, so that the two roles still alternate in the grid.
+    uint64_t per_wg = 2;
+    const uint64_t most = F.n_gen == 0 ? (~0ull >> 2) : (F.n_gen / 2 ? F.n_gen / 2 : 1);    // (a clerk-only launch - the last of a run - keeps the pairs)
+    if ((F.n_comb + 1) / 2 > most) per_wg = 2 * ((F.n_comb + 2 * most - 1) / (2 * most));
+    if (per_wg > 0xFFFFFFFEull) return hipSuccess;                                // not fused: the caller issues the two launches
+    F.items_per_wg = (uint32_t)per_wg;
+    F.n_comb_wg = (F.n_comb + per_wg - 1) / per_wg;
+    // Few share-generation workgroups per CU (a tile of n = 19682 is 6.4 rounds of them): the last round's workgroups would run beside
+    // idle CUs.  A third of the clerk workgroups is kept back and FOLLOWS the last share-generation workgroup in the grid: short
+    // items (a third of a share-generation workgroup's time each) that fill the tail.
+    const uint32_t cus = ng_cu_count() ? ng_cu_count() : 256u;
+    const uint64_t late = F.n_gen < 16ull * cus ? F.n_comb_wg / 3 : 0;
+    F.n_early = F.n_comb_wg - late;
     // workgroup b runs on XCD b % 8: an odd period spreads the clerk positions over all of them
-    F.period = F.n_comb_wg ? F.n_gen / F.n_comb_wg + 1 : 1;
-    if (F.n_comb_wg && (F.period & 1) == 0) F.period = F.period > 2 ? F.period - 1 : 3;
+    F.period = F.n_early ? F.n_gen / F.n_early + 1 : 1;
+    if (F.n_early && (F.period & 1) == 0) F.period = F.period > 2 ? F.period - 1 : 3;
+    // (a smaller period than n_gen / n_early + 1 exhausts the early clerk positions before the share-generation items end: fine)
     uint64_t grid = F.n_gen + F.n_comb_wg;
-    if (F.n_comb_wg && (F.n_comb_wg - 1) * F.period + 1 > grid) grid = (F.n_comb_wg - 1) * F.period + 1;
+    if (F.n_early && (F.n_early - 1) * F.period + 1 > F.n_gen + F.n_early) return hipSuccess;   // cannot happen (period <= n_gen / n_early + 1)
     if (grid == 0) { *fused = true; return hipSuccess; }
     if (grid > 0x7FFFFFFFull) return hipSuccess;                                  // not fused: the caller issues the two launches
     if (F.n_comb_wg == 0) { *fused = true; return ngemm_launch<KS, NT>(L, mod, key, P, s); }
@@ -736,7 +774,7 @@ static hipError_t ngemm_launch_fused(const GenLayout& L, const ModParams& mod, c
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     *fused = true;
-    F.cu_stride = ng_cu_count();
+    F.cu_stride = cus;
     note_kernel("packed_gen_ngemm_kernel<%d, %d>", KS, NT);
     kern<<<dim3((unsigned)grid), dim3(kNgThreads), lds, s>>>(L, mod, key, P, chunks ? chunks : 1, batches, F);
     return hipGetLastError();

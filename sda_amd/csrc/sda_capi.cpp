@@ -1486,6 +1486,8 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
     // (the narrow limb GEMM fills every SIMD's registers with its own nine waves per CU: a clerk sum on a side stream found no
     // room beside it - 18.9 ms per 500-participant tile of PSS_155_728_100 against 16.9 for the two launches back to back)
     const bool gemm_form = g->fft && g->ngemm && g->drbg.rounds == 20;
+    // (round 6: single-wave clerk workgroups, which WOULD fit beside it - two per SIMD on the three SIMDs without the loader wave -
+    // are not placed there either: 14.9 ms against 12.8 for the dual-role grid, profiles/r06/ab_ngemm_side_waves_not_adopted.txt)
     bool side = false;
     if (st == SDA_OK && !fused && both && g->fft && !gemm_form && !g->knob_no_side_stream) {
         side = true;

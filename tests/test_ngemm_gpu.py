@@ -249,6 +249,8 @@ def test_narrow_limb_gemm_repeated_dual_role_launches(gpu):
             gen.generate_combine_dev(comb, d_secs[i].ptr if i < tiles else 0, P if i < tiles else 0, dim, dim, bufs[i % 2].ptr, Bs, P * Bs,
                                      d_prev=bufs[(i - 1) % 2].ptr if i > 0 else 0, prev_participants=P if i > 0 else 0,
                                      first_participant=i * P)
+            if rep == 0 and i == 1:                     # a call that carries both roles: ONE launch
+                assert gpu.sda_debug_last_kernel().decode() == "packed_gen_ngemm_kernel<2, 2>"
         comb.finish_dev(d_sums.ptr)
         got = d_sums.to_numpy().reshape(n, B)
         bad = np.argwhere(got != want)

@@ -1631,8 +1631,16 @@ def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu, tmp_pat
     compact, line, _ = _run_bench(cmd, tmp_path)
     legs = line["additional_workloads"]
     assert {"config4_full", "config5_full", "additive", "packed_pss728", "narrow_ref", "narrow26_ref", "narrow_pss728", "narrow_pss19682",
-            "packed_tss_nodes"} == set(legs) == set(compact["additional_workloads"])
+            "packed_tss_nodes", "packed_distinct", "additive_chacha12", "config4_chacha12"} == set(legs) == set(compact["additional_workloads"])
     assert all(v["verified"] is True for v in compact["additional_workloads"].values())
+    # round 6: the distinct-inputs price and the round-count price ride on the line, labelled
+    assert compact["additional_workloads"]["additive_chacha12"]["rounds"] == 12 == compact["additional_workloads"]["config4_chacha12"]["rounds"]
+    assert legs["additive_chacha12"]["roofline"]["kernel"] == "fused_additive_kernel<12>" and "ChaCha12" in legs["additive_chacha12"]["config"]["randomness"]
+    assert legs["config4_chacha12"]["config"]["share_count"] == 26 and legs["config4_chacha12"]["roofline"]["bound"] is None
+    d = legs["packed_distinct"]
+    assert d["config"]["inputs"].startswith("distinct") and d["fill_bytes_per_element"] == 8.0 and d["frac_with_fill"] > d["roofline"]["frac"] * 1.1
+    assert d["config"]["distinct_participants"] == d["config"]["participants_total"]
+    assert compact["additional_workloads"]["packed_distinct"]["frac_with_fill"] == pytest.approx(d["frac_with_fill"], rel=1e-3)
     # the kernel names are the library's own report of what it launched (sda_debug_last_kernel)
     assert legs["narrow_ref"]["roofline"]["kernel"].startswith("fused_packed_n31_kernel<8, ") and legs["narrow_ref"]["verified_reconstruct_equals_sum"] is True
     assert legs["narrow_ref"]["config"]["library_path"] == "l31+n31" and legs["config4_full"]["roofline"]["kernel"] == "fused_packed_l31_kernel<8, 2, 20>"

@@ -139,10 +139,13 @@ def _fat_record(n_gpus=1):
            "path_roofline": {"bytes_per_element": 60.0}, "verified_reconstruct_equals_sum": True, "verified_against": note,
            "reveal": {"ms": 0.0631928, "note": note}, "exchange_ms": 0.33, "exchange_bytes_per_gpu": 61070464}
     names = ["additive", "config4_full", "config5_full", "packed_pss728", "narrow_ref", "narrow26_ref", "narrow_pss728",
-             "narrow_pss19682", "packed_tss_nodes", "config4_packed26", "config5_packed_dim16m", "one_more_leg_with_a_long_name"]
+             "narrow_pss19682", "packed_tss_nodes", "packed_distinct", "additive_chacha12", "config4_chacha12", "config4_packed26",
+             "config5_packed_dim16m", "one_more_leg_with_a_long_name"]
     full = dict(leg, metric="share-gen + clerk-sum elements/sec (mod q)", warmup=5, higher_is_better=True, scaling="weak",
                 scaling_note=note, vs_baseline=None, dtype="u64", data="synthetic", build_id="0123456789abcdef",
-                additional_workloads={n: json.loads(json.dumps(leg)) for n in names},
+                additional_workloads={n: dict(json.loads(json.dumps(leg)), **({"rounds": 12} if n.endswith("chacha12") else {}),
+                                              **({"frac_with_fill": 0.7123456, "fill_bytes_per_element": 8.0} if n == "packed_distinct" else {}))
+                                      for n in names},
                 cpu_baseline={"value": 18196000.123, "unit": "elements/s", "cores": 1, "kind": "port", "sample": note, "samples": [1.0] * 9,
                               "port_notes": note, "cpu_model": "AMD EPYC 9575F 64-Core Processor", "physical_cores": 128,
                               "hardware_threads": 256, "usable_threads": 256,
@@ -170,8 +173,9 @@ def test_bench_stdout_line_stays_small_and_carries_the_contract(n_gpus):
     assert line["roofline"]["traffic"] is None and line["roofline"]["bound"] == "valu"
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and line["cpu_baseline"]["all_cores"]["cores"] == 64
     assert line["config"]["workload"].endswith("~") and len(line["config"]["workload"]) == 120
-    assert all(set(v) <= {"value", "frac", "bound", "verified", "reveal_ms"} for v in line["additional_workloads"].values())
-    assert len(line["additional_workloads"]) == 12 and line["details"] == "bench_details.json"
+    assert all(set(v) <= {"value", "frac", "bound", "verified", "reveal_ms", "rounds", "frac_with_fill"} for v in line["additional_workloads"].values())
+    assert len(line["additional_workloads"]) == 15 and line["details"] == "bench_details.json"
+    assert line["additional_workloads"]["config4_chacha12"]["rounds"] == 12 and line["additional_workloads"]["packed_distinct"]["frac_with_fill"] == 0.7123
     assert ("rccl" in line) == (n_gpus > 1)
     assert json.loads(text) == line                                        # strict JSON
 
