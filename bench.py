@@ -356,7 +356,7 @@ class Env:
         # default line never does: `library` on the line says which binary ran.
         knob_names = ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
                       "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM",
-                      "SDA_NO_WIDE_GROUP", "SDA_SIDE_STREAM_PRIORITY")
+                      "SDA_NO_WIDE_GROUP", "SDA_SIDE_STREAM_PRIORITY", "SDA_NGEMM_CLERK_WG")
         knobs = {n: os.environ[n] for n in knob_names if os.environ.get(n)}
         if knobs:
             capi.use_test_hooks()
@@ -971,7 +971,7 @@ def compact_line(full, details_path="bench_details.json"):
     extra = full.get("additional_workloads") or {}
     if extra:
         line["additional_workloads"] = {
-            name: {"value": _sig(r.get("value"), 5), "frac": _sig((r.get("roofline") or {}).get("frac"), 4),
+            name: {"value": _sig(r.get("value"), 5), "frac": _sig(r.get("frac_wall", (r.get("roofline") or {}).get("frac")), 4),
                    "bound": (r.get("roofline") or {}).get("bound"), "verified": r.get("verified_reconstruct_equals_sum"),
                    **({"reveal_ms": _sig(r["reveal"]["ms"], 4)} if name.startswith("config5") and r.get("reveal") else {}),
                    **({"rounds": r["rounds"]} if "rounds" in r else {}),
@@ -1190,8 +1190,11 @@ def main():
             r = run("packed", 5, 1, participants=(args.participants or 12_500), dim=args.dim, inputs="distinct")
             gb, cb = algorithmic_bytes_per_element(r["config"]["share_count"], r["config"]["secret_count"])
             r["fill_bytes_per_element"] = 8.0
-            r["frac_with_fill"] = r["roofline"]["frac"] * (gb + cb + 8.0) / (gb + cb)      # the same launches, the fill's 8 B counted
-            line["additional_workloads"]["packed_distinct"] = {k: r[k] for k in keep + ("fill_bytes_per_element", "frac_with_fill") if k in r}
+            # WALL-clock fractions for this leg: its launches run at the headline's speed, what it pays is the time they wait for
+            # the fill (roofline.frac, from the launch durations, would hide exactly that)
+            r["frac_wall"] = r["path_roofline"]["frac_of_hbm_peak"]
+            r["frac_with_fill"] = r["frac_wall"] * (gb + cb + 8.0) / (gb + cb)
+            line["additional_workloads"]["packed_distinct"] = {k: r[k] for k in keep + ("fill_bytes_per_element", "frac_wall", "frac_with_fill") if k in r}
         # The price of the round count, labelled: configs 2 and 4 are bound by the vector ALUs on ChaCha20 (two / 0.25 64-bit draws
         # per element); the same legs with the CSPRNG at 12 rounds show how much of their gap to the headline is that policy.  The
         # PRODUCT runs 20 rounds (what chacha.rs:36 - rand 0.3's ChaChaRng - uses) and these two are never the headline.

@@ -34,6 +34,8 @@
  *                              matrix cores, ngemm_kernels.hip)
  *   SDA_NO_WIDE_GROUP 1        three-digit limb-31 shapes of 9 .. 12 terms (BASELINE config 4's (8,2)): the 7 + rest grouping even where
  *                              the constants admit the dot product as ONE group (default: one group, one reduction, no normalisation)
+ *   SDA_NGEMM_CLERK_WG 1       limb GEMM, dual-role launch: the clerk sum in clerk WORKGROUPS at fixed grid positions (rounds 4 - 5) instead
+ *                              of the clerk WAVES inside every share-generation workgroup (round 6, the default)
  *   SDA_FORCE_COLLECTIVES 1    a one-rank communicator still goes through RCCL send/recv to itself
  * Built with -DSDA_AB_KNOBS (tools/build_ab_variant.sh; never by __graft_entry__.build()) an unset knob falls back to the
  * environment variable of the same name. */

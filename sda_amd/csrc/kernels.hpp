@@ -161,10 +161,13 @@ size_t ngemm_tile_bytes(uint32_t ks);
 bool packed_ngemm_path_available(uint32_t k, uint32_t t, uint64_t p);
 uint32_t packed_ngemm_steps(uint32_t k, uint32_t t);
 hipError_t launch_packed_generate_ngemm(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, hipStream_t s);
-// dual-role form: the clerk sum of the previous tile (two 512-column items per workgroup) at fixed positions of the same grid
+// dual-role form.  d_progress != nullptr (room for ngemm_clerk_slots(L, P) x 2 u64): the clerk sum of the previous tile rides in three
+// clerk WAVES of every share-generation workgroup, a follow-up kernel sums what they did not get to (round 6, the default);
+// d_progress == nullptr: clerk WORKGROUPS at fixed positions of the same grid (rounds 4 - 5; A/B knob SDA_NGEMM_CLERK_WG)
+uint64_t ngemm_clerk_slots(const GenLayout& L, const NGemmPlan& P);
 hipError_t launch_fused_packed_ngemm(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, uint64_t* acc_lo,
                                      int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs, size_t dimension, hipStream_t s,
-                                     bool* fused);
+                                     bool* fused, uint64_t* d_progress = nullptr, size_t progress_slots = 0);
 
 // packed Shamir, any shape: matrix in global memory, randomness must be materialised (L.rand != 0)
 hipError_t launch_packed_generate_generic(const GenLayout& L, uint32_t n, uint32_t k, uint32_t t,

@@ -23,8 +23,8 @@
 // adjacent batch columns and shares leave as 16-byte non-temporal buffer stores (row pointer in a scalar descriptor, one 32-bit
 // lane offset), 256-byte row segments.  The B fragments of the last two steps are read from LDS during the row tiles (the last
 // step's digit tile and a per-wave stash, NgBSource): the row loop must fit the 168 registers three waves per SIMD leave WITHOUT
-// scratch memory - a reload there waits for every share store in flight (tests/test_ngemm_isa.py reads the assembly).  Ten tiles
-// before it ends a workgroup touches the secrets of the workgroup that runs next on its XCD (L2 prefetch, see the row loop).
+// scratch memory - a reload there waits for every share store in flight (tests/test_ngemm_isa.py reads the assembly).
+// Round 6: THREE MORE WAVES per workgroup, the clerk waves, sum the PREVIOUS tile's shares while all this runs (ng_clerk_wave).
 // Values reach the B-operand layout through an LDS tile [digit][batch][64 terms], one 64-term step at a time; the draws are
 // sda-drbg-v1's PAIRED rule (every prime of this kernel is in its domain): one lane = one ChaCha20 block = draws 2j and 2j + 1
 // of 8 consecutive batches, the same words the transform kernel reads, so both produce identical shares from
@@ -52,7 +52,11 @@ typedef unsigned int ng_v2u __attribute__((ext_vector_type(2)));
 
 static constexpr int kNgCompute = 8;                // compute waves per workgroup (two per SIMD), one workgroup per CU
 static constexpr int kNgWorkers = 64 * kNgCompute;
-static constexpr int kNgThreads = kNgWorkers + 64;  // + the loader wave
+#ifndef NG_CLERK_WAVES
+#define NG_CLERK_WAVES 3                            // (tools/build_ngemm_variant.sh builds A/B variants with other counts; 0 = rounds 4 - 5's nine waves)
+#endif
+static constexpr int kNgClerkWaves = NG_CLERK_WAVES; // clerk waves of a share-generation workgroup (round 6): one on each SIMD that does not hold the loader
+static constexpr int kNgThreads = kNgWorkers + 64 + 64 * kNgClerkWaves;  // + the loader wave + the clerk waves: three waves on every SIMD
 typedef __attribute__((address_space(3))) uint8_t* ng_lptr;     // LDS pointers inside the non-inlined passes: a generic pointer argument costs
                                                                  // a 64-bit address computation per access
 static constexpr int kNgRow = 80;                 // bytes of one (digit, batch) row of the value tile: 64 terms + 16 (bank spread)
@@ -171,14 +175,14 @@ __device__ __noinline__ void ng_load_pass(uint8_t* Bt, const int64_t* sp, const 
 // stash the wave copies them to - fragment by fragment, 1 KiB each, in the side tile's memory, which is free by then; only the
 // steps before those are registers (KS = 4, NT = 2: 48 of them, all within the preserved set).
 // (Fetching two steps' values with one pass - one memory latency instead of two - was tried with a side tile in that memory and
-// made the pass slower, 35 k against 29 k cycles: it is the bytes in flight per CU that bound it, see the prefetch in the row loop.)
+// made the pass slower, 35 k against 29 k cycles: it is the bytes in flight per CU that bound it.)
 template <int KS> struct NgBSource {
     static constexpr bool last_in_tile = KS >= 2, stash = KS >= 4;
     static constexpr int in_regs = stash ? KS - 2 : last_in_tile ? KS - 1 : KS;      // steps 0 .. in_regs - 1 are registers
 };
-template <int KS, int NT> constexpr size_t ngemm_lds_bytes() {      // A ring + digit tile + stash + 256 bytes nobody reads (prefetch target)
+template <int KS, int NT> constexpr size_t ngemm_lds_bytes() {      // A ring + digit tile + stash
     return (size_t)(KS == 8 ? 2 : 4) * (size_t)KS * 3 * 1024 + 3 * (size_t)(16 * kNgCompute * NT) * kNgRow +
-           (NgBSource<KS>::stash ? (size_t)kNgCompute * NT * 3 * 1024 : 0) + 256;
+           (NgBSource<KS>::stash ? (size_t)kNgCompute * NT * 3 * 1024 : 0);
 }
 // the CSPRNG draws d_lo .. d_lo + cd - 1 of the workgroup's batches -> digit tile.  Every prime this kernel takes (p <= 0x7F7F7F) is
 // in the domain of sda-drbg-v1's PAIRED rule (modarith.hpp): one lane = one block = draws 2j AND 2j + 1 of 8 batches - 78 blocks per
@@ -311,8 +315,13 @@ struct NgFuse {
     uint64_t n_early;                                             // clerk workgroups 0 .. n_early - 1 sit at positions c * period among the share-generation
                                                                   // workgroups, the others FOLLOW the last share-generation workgroup (they fill its tail)
     uint32_t items_per_wg;                                        // clerk items one clerk workgroup sums (even: one per half of the compute waves at a time)
-    uint32_t cu_stride;                                     // grid positions between two workgroups of one CU (= the device's CU count:
-                                                                  // one workgroup per CU); 0: no prefetch of the next workgroup's secrets
+    uint32_t pad2;
+    // clerk WAVES (round 6, the default): every share-generation workgroup carries kNgClerkWaves waves that sum the PREVIOUS tile while
+    // the compute waves multiply - items of 128 columns x all rows of one job, cw_per_slot consecutive items per (workgroup, clerk
+    // wave) slot; what a slot did not get to is recorded in cw_progress (item, row) and summed by ngemm_clerk_rest_kernel afterwards
+    uint64_t cw_items, cw_per_slot;
+    uint64_t* cw_progress;                                        // [slots][2]
+    uint32_t cw_col_blocks, cw_pad;
 };
 static constexpr int kNgClerkUnroll = 8;      // row loads in flight per lane in the clerk role (4: 14.9, 8: 14.6, 16: 14.9, 32: 15.9 ms per tile)
 static constexpr int kNgClerkUnrollShort = 20; // ... for items of a few rows (40 participants of PSS_155_19682_100: two rounds of loads instead of five)
@@ -327,6 +336,197 @@ template <int KS> struct NgRing { static constexpr int depth = KS == 8 ? 2 : 4; 
 __device__ __forceinline__ void ng_store_guard(ng_v4u v) { asm volatile("s_nop 1" ::"v"(v)); }
 __device__ __forceinline__ void ng_store_guard(ng_v2u v) { asm volatile("s_nop 1" ::"v"(v)); }
 
+// ---- clerk waves (round 6) ---------------------------------------------------------------------------------------------------------
+// The dual-role GRID gives whole CUs to the clerk sum, and a CU in that role streams 27 - 45 GB/s (one workgroup of this kernel's
+// size per CU: 512 lanes of loads in flight) while its matrix cores idle; the two launches run back to back took 10.1 + 4.6 ms per
+// tile of PSS_155_728_100, the dual-role grid 12.8.  A second kernel on another stream is not placed beside this one's workgroups at
+// all (profiles/r06/ab_ngemm_side_waves_not_adopted.txt).  So the clerk sum rides INSIDE every share-generation workgroup: three more
+// waves - the SIMDs without the loader wave have the registers and the slot - that do nothing but load rows of the previous tile
+// and add them up, on ALL 256 CUs at once, in the issue slots the compute waves leave (VALU busy 0.37 - 0.46) and the HBM bandwidth
+// share generation does not use (3.6 of ~6.2 TB/s).
+//
+// A clerk wave must arrive at every workgroup barrier (2 per staging step + 1 per row tile): a barrier STEP is its unit of work.  Step
+// b: add up the R rows it asked for at step b - 2, ask for the next R rows, s_barrier - TWO register sets, so that a load has two
+// barrier intervals (~4 - 5 us) to arrive: with one set (measured, profiles/r06/ab_ngemm_clerk_waves_v1.txt) the wave waited 3+ us for
+// memory every step and held the whole workgroup's barrier - the share-generation kernel went from 19.9 to 30 ms on
+// PSS_155_19682_100.  The wait for a set must leave the YOUNGER set in flight: s_waitcnt vmcnt(R).  The compiler cannot emit that
+// for a wave that also stores (loads and stores return out of order with respect to each other, so its wait-count pass falls back
+// to vmcnt(0) whenever a store may be pending - and the running sums of a finished item are stored here).  The counted wait is
+// still correct: loads return in order AMONG LOADS, so "at most R operations outstanding" implies that every load older than the
+// youngest R loads has returned, whatever the stores do (a pending store only makes the wait longer).  Hence the loads are issued
+// and awaited in inline assembly (ng_clerk_load / ng_clerk_wait): the compiler sees values that flow from one asm statement to the
+// next and has no reason to touch them in between - tests/test_ngemm_isa.py walks the assembly and fails a build in which any
+// other instruction reads a register of a set between its load and its wait.  Every step issues exactly R row loads (an exhausted
+// slot re-reads a valid address), so R is always a lower bound of the younger loads.
+// Items = (job, 128 columns) over all rows of the tile, in a fixed order per slot; the running sums of an item are fetched with its
+// first rows and written back with its last (no other wave touches them in this launch).  Whatever is left when the workgroup's
+// last barrier has passed - the rest of the current item's rows and the slot's remaining items - goes to ngemm_clerk_rest_kernel
+// via cw_progress.
+struct NgClerkCursor {
+    uint64_t it, end;          // item index (job * col_blocks + column block), end of the slot
+    uint64_t job; uint32_t bx; // ... decomposed
+    uint32_t r;                // first row of the next quantum
+};
+static constexpr int kNgClerkRows = 10;      // rows per quantum and register set (40 registers each): 40 participants = 4 quanta, 500 = 50
+
+struct NgClerkSet {
+    ll2 v[kNgClerkRows];
+    ll2 al, ah;                               // the item's running sums (low words / high words of its two columns), fetched with its first quantum
+};
+
+__device__ __forceinline__ void ng_clerk_advance(NgClerkCursor& c, uint32_t n_rows, uint32_t col_blocks) {
+    c.r += kNgClerkRows;
+    if (c.r >= n_rows) {
+        c.r = 0; ++c.it;
+        if (++c.bx == col_blocks) { c.bx = 0; ++c.job; }
+    }
+}
+// one 16-byte load the compiler does not track ("NGCL" tags it for the ISA test).  nt: the shares are read once
+__device__ __forceinline__ void ng_clerk_load(ll2& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt ; NGCL" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ng_clerk_load_plain(ll2& dst, const void* p) {           // the running sums: cached like any data
+    asm volatile("global_load_dwordx4 %0, %1, off ; NGCL" : "=v"(dst) : "v"(p) : "memory");
+}
+// every load of the set has returned when at most `YOUNGER` vector-memory operations are outstanding (see above); the set's registers
+// are read-write operands, so that no use of them can be scheduled before this statement ("NGCW" + the registers for the ISA test)
+template <int YOUNGER>
+__device__ __forceinline__ void ng_clerk_wait(NgClerkSet& S) {
+    static_assert(kNgClerkRows == 10, "the operand list below names ten rows");
+    asm volatile("s_waitcnt vmcnt(%12) ; NGCW %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11"
+                 : "+v"(S.v[0]), "+v"(S.v[1]), "+v"(S.v[2]), "+v"(S.v[3]), "+v"(S.v[4]), "+v"(S.v[5]), "+v"(S.v[6]), "+v"(S.v[7]),
+                   "+v"(S.v[8]), "+v"(S.v[9]), "+v"(S.al), "+v"(S.ah)
+                 : "n"(YOUNGER)
+                 : "memory");
+}
+
+__device__ __forceinline__ void ng_clerk_wave(const NgFuse& F, uint64_t slot, uint32_t lane, uint32_t n_barriers) {
+    if (F.cw_items == 0) {                                           // a launch without a previous tile: the barriers, nothing else
+        for (uint32_t b = 0; b < n_barriers; ++b) __builtin_amdgcn_s_barrier();
+        return;
+    }
+    const uint32_t n_rows = (uint32_t)F.n_rows, col_blocks = F.cw_col_blocks;
+    NgClerkCursor is, cs;                                            // issue side, consume side (the same walk, two quanta behind)
+    is.it = slot * F.cw_per_slot < F.cw_items ? slot * F.cw_per_slot : F.cw_items;
+    is.end = is.it + F.cw_per_slot < F.cw_items ? is.it + F.cw_per_slot : F.cw_items;
+    is.job = is.it / col_blocks; is.bx = (uint32_t)(is.it - is.job * col_blocks); is.r = 0;
+    cs = is;
+    uint64_t lo0 = 0, lo1 = 0, bl0 = 0, bl1 = 0;                      // sums of the item being consumed; its running sums from memory
+    int64_t hi0 = 0, hi1 = 0, bh0 = 0, bh1 = 0;
+    NgClerkSet A, B;
+    bool validA = false, validB = false;
+    // the running sums are read and written 16 bytes (both columns of the lane) at a time: acc_lo / acc_hi + job * dimension + c0 is
+    // 16-byte aligned when dimension is even (c0 is); an odd dimension is not given to the clerk waves (ngemm_launch_fused)
+    auto issue = [&](NgClerkSet& S, bool& valid) {
+        valid = is.it < is.end;
+        size_t c0 = 2 * ((size_t)is.bx * 64 + lane);
+        if (c0 + 1 >= F.dimension) c0 = 0;                           // a lane beyond the last column pair re-reads columns 0, 1 (never stored)
+        const uint64_t job = valid ? is.job : 0;                     // (an exhausted slot: the same R loads from a valid address)
+        const uint32_t r0 = valid ? is.r : 0;
+        const int64_t* base = F.prev + job * F.job_stride + c0;
+        if (valid && r0 == 0) {
+            const size_t idx = job * F.dimension + c0;
+            ng_clerk_load_plain(S.al, F.acc_lo + idx);
+            ng_clerk_load_plain(S.ah, F.acc_hi + idx);
+        }
+#pragma unroll
+        for (int u = 0; u < kNgClerkRows; ++u) {
+            const uint32_t rr = r0 + u < n_rows ? r0 + u : n_rows - 1;                    // (clamped: never added)
+            ng_clerk_load(S.v[u], base + (size_t)rr * F.row_stride);
+        }
+        if (valid) ng_clerk_advance(is, n_rows, col_blocks);
+    };
+    auto flush = [&]() {                                             // the consumed rows of the current item -> its running sums in memory
+        const size_t c0 = 2 * ((size_t)cs.bx * 64 + lane);
+        if (c0 + 1 >= F.dimension) return;
+        const size_t idx = cs.job * F.dimension + c0;
+        const uint64_t n0 = bl0 + lo0, n1 = bl1 + lo1;
+        ll2 l, h;
+        l.x = (long long)n0; l.y = (long long)n1;
+        h.x = bh0 + hi0 + (n0 < bl0 ? 1 : 0); h.y = bh1 + hi1 + (n1 < bl1 ? 1 : 0);
+        *reinterpret_cast<ll2*>(F.acc_lo + idx) = l;
+        *reinterpret_cast<ll2*>(F.acc_hi + idx) = h;
+    };
+    auto consume = [&](NgClerkSet& S, bool& valid) {                 // (after ng_clerk_wait(S))
+        if (!valid) return;
+        valid = false;
+        if (cs.r == 0) {
+            bl0 = (uint64_t)S.al.x; bl1 = (uint64_t)S.al.y; bh0 = S.ah.x; bh1 = S.ah.y;
+            lo0 = lo1 = 0; hi0 = hi1 = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kNgClerkRows; ++u)
+            if (cs.r + u < n_rows) { acc_add(lo0, hi0, S.v[u].x); acc_add(lo1, hi1, S.v[u].y); }
+        if (cs.r + kNgClerkRows >= n_rows) flush();
+        ng_clerk_advance(cs, n_rows, col_blocks);
+    };
+    // (the sets start as zeros: the first waits name registers nothing was loaded into yet)
+#pragma unroll
+    for (int u = 0; u < kNgClerkRows; ++u) { A.v[u] = ll2{0, 0}; B.v[u] = ll2{0, 0}; }
+    A.al = A.ah = B.al = B.ah = ll2{0, 0};
+    uint32_t b = 0;
+    for (; b + 1 < n_barriers; b += 2) {
+        ng_clerk_wait<kNgClerkRows>(A);                              // B's rows (asked for one step ago) stay in flight
+        consume(A, validA); issue(A, validA);
+        __builtin_amdgcn_s_barrier();
+        ng_clerk_wait<kNgClerkRows>(B);
+        consume(B, validB); issue(B, validB);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (b < n_barriers) {                                            // an odd number of barriers: A is the younger set afterwards
+        ng_clerk_wait<kNgClerkRows>(A);
+        consume(A, validA); issue(A, validA);
+        __builtin_amdgcn_s_barrier();
+        ng_clerk_wait<0>(B); consume(B, validB);
+        ng_clerk_wait<0>(A); consume(A, validA);
+    } else {
+        ng_clerk_wait<0>(A); consume(A, validA);
+        ng_clerk_wait<0>(B); consume(B, validB);
+    }
+    // the workgroup is done: the rows consumed of an unfinished item go to memory, the rest of the slot to the follow-up kernel
+    if (cs.it < cs.end && cs.r != 0) flush();
+    if (F.cw_progress && lane == 0) { F.cw_progress[2 * slot] = cs.it; F.cw_progress[2 * slot + 1] = cs.r; }
+}
+
+// what the clerk waves of a launch did not get to: one single-wave workgroup per slot, from the recorded (item, row) to the slot's end.
+// The same sums in the same layout (items = 128 columns of one job), kNgClerkRest rows in flight per lane.
+static constexpr int kNgClerkRest = 16;
+__global__ __launch_bounds__(64) void ngemm_clerk_rest_kernel(NgFuse F, uint64_t slots) {
+    const uint32_t lane = threadIdx.x, n_rows = (uint32_t)F.n_rows;
+    for (uint64_t slot = blockIdx.x; slot < slots; slot += gridDim.x) {
+        uint64_t it = F.cw_progress[2 * slot];
+        uint32_t r0 = (uint32_t)F.cw_progress[2 * slot + 1];
+        const uint64_t first = slot * F.cw_per_slot < F.cw_items ? slot * F.cw_per_slot : F.cw_items;
+        const uint64_t end = first + F.cw_per_slot < F.cw_items ? first + F.cw_per_slot : F.cw_items;
+        for (; it < end; ++it, r0 = 0) {
+            const uint64_t job = it / F.cw_col_blocks, bx = it - job * F.cw_col_blocks;
+            const size_t c0 = 2 * ((size_t)bx * 64 + lane);
+            if (c0 >= F.dimension) continue;
+            const bool two = c0 + 1 < F.dimension;
+            const int64_t* base = F.prev + job * F.job_stride + c0;
+            const size_t idx = job * F.dimension + c0;
+            const uint64_t l0 = F.acc_lo[idx], l1 = two ? F.acc_lo[idx + 1] : 0;
+            const int64_t h0 = F.acc_hi[idx], h1 = two ? F.acc_hi[idx + 1] : 0;
+            uint64_t lo0 = 0, lo1 = 0;
+            int64_t hi0 = 0, hi1 = 0;
+            for (uint32_t r = r0; r < n_rows; r += kNgClerkRest) {
+                ll2 v[kNgClerkRest];
+#pragma unroll
+                for (int u = 0; u < kNgClerkRest; ++u) {
+                    const uint32_t rr = r + u < n_rows ? r + u : n_rows - 1;
+                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(base + (size_t)rr * F.row_stride));
+                }
+#pragma unroll
+                for (int u = 0; u < kNgClerkRest; ++u)
+                    if (r + u < n_rows) { acc_add(lo0, hi0, v[u].x); if (two) acc_add(lo1, hi1, v[u].y); }
+            }
+            uint64_t nl = l0 + lo0;
+            F.acc_lo[idx] = nl; F.acc_hi[idx] = h0 + hi0 + (nl < l0 ? 1 : 0);
+            if (two) { nl = l1 + lo1; F.acc_lo[idx + 1] = nl; F.acc_hi[idx + 1] = h1 + hi1 + (nl < l1 ? 1 : 0); }
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int KS, int NT>
@@ -340,11 +540,8 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     uint8_t* Abuf = ng_lds;                                          // [DEPTH][ATILE]
     uint8_t* Bt = ng_lds + DEPTH * ATILE;                            // [3][WGB][kNgRow]
     uint8_t* Side = Bt + 3 * WGB * kNgRow;                           // [wave][NT][3][1 KiB]: the stash of step KS - 2's B fragments (KS >= 4)
-    uint8_t* Junk = Side + (NgBSource<KS>::stash ? kNgCompute * NT * 3 * 1024 : 0);   // 256 bytes nobody reads: where the prefetch loads land
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, col = lane & 15u, g = lane >> 4;
     uint64_t item = blockIdx.x;
-    // grid position -> share-generation item (~0: a clerk position or a surplus one).  Used for this workgroup and for the one
-    // that runs next on this CU (prefetch_next)
     // grid position -> clerk workgroup index (role 1) or share-generation item (role 0); role 2: a surplus position
     auto role_at = [&](uint64_t pos, uint64_t& idx) -> int {
         if (!F.n_comb_wg) { idx = pos; return pos < (uint64_t)gridDim.x ? 0 : 2; }
@@ -383,10 +580,11 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         }
         item = idx;
     }
-    auto gen_item_at = [&](uint64_t pos) -> uint64_t {               // the share-generation item at a grid position, ~0 if it has none
-        uint64_t idx;
-        return role_at(pos, idx) == 0 ? idx : ~0ull;
-    };
+    if (wave > (uint32_t)kNgCompute) {                              // a clerk wave: every barrier of the workgroup, nothing else of it
+        const uint32_t cw = __builtin_amdgcn_readfirstlane(wave) - (uint32_t)kNgCompute - 1u;
+        ng_clerk_wave(F, item * (uint64_t)kNgClerkWaves + cw, lane, 2u * (uint32_t)KS + P.row_tiles);
+        return;
+    }
     const uint64_t p = item / chunks, chunk = item - p * chunks;
     const uint64_t b0 = chunk * WGB;
     const int64_t* sp = L.secrets + p * L.secrets_stride;
@@ -453,7 +651,12 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     // (systematic share map: the matrix has the rows direct_rows .. n - 1, rows 0 .. direct_rows - 1 were the draws)
     // Addresses: a UNIFORM row pointer (scalar registers, stepped by 16 rows per tile) plus ONE 32-bit lane offset (column and
     // row 4 g) - row pointers per lane were 10 vector registers of a loop that has none to spare (see finish()).
-    const char* obase = reinterpret_cast<const char*>(op + b0 + (size_t)(rp ? 0u : L.direct_rows) * L.out_stride_clerk);
+    // (the row pointer is wave-uniform by construction; saying so keeps it in scalar registers - in one build of the <8, 1> instance
+    // it had ended up in vector registers and every masked store became a readfirstlane loop around its descriptor)
+    const uint64_t obase_v = reinterpret_cast<uint64_t>(op + b0 + (size_t)(rp ? 0u : L.direct_rows) * L.out_stride_clerk);
+    const uint32_t obase_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(obase_v >> 32));       // (the builtin returns a SIGNED int:
+    const uint32_t obase_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)obase_v);               //  widen each half as unsigned)
+    const char* obase = reinterpret_cast<const char*>(((uint64_t)obase_hi << 32) | (uint64_t)obase_lo);
     const size_t row_bytes = L.out_stride_clerk * sizeof(int64_t);
     const uint32_t loff = bl * 8u + 4u * g * (uint32_t)row_bytes;  // (the fast path asks for 16 rows below 4 GiB)
     const bool late = wave >= (uint32_t)(kNgCompute / 2);
@@ -606,34 +809,16 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         if (rt < whole_tiles) finish_whole(rt); else if (near) finish_masked(rt); else finish_far(rt);
         __builtin_amdgcn_sched_barrier(0);                          // the next tile's matrix instructions stay behind this reduction
     };
-    // The secrets of the workgroup that runs next on this XCD (one workgroup per CU: the one 256 items on), touched a few tiles
-    // before this one ends: its load passes then find them in L2.  A pass is bound by the bytes a CU keeps in flight times the
-    // latency of memory that every other CU is writing shares to (35 k cycles per workgroup; 23 k with every workgroup reading
-    // the same, cache-resident secrets).  global_load_lds: no destination register, nothing to wait for - the four bytes per lane
-    // land in LDS nobody reads; compute waves never wait for vmcnt in this loop.
-    const uint32_t pf_tile = tiles > 12u ? tiles - 10u : 0u;
-    auto prefetch_next = [&]() {
-        // one workgroup per CU, dispatched in grid order: the workgroup that follows this one on its CU (and XCD) is cu_stride
-        // grid positions on - in a dual-role grid that position's OWN item (it may be a clerk position: nothing to touch)
-        if (!F.cu_stride) return;
-        const uint64_t nitem = gen_item_at((uint64_t)blockIdx.x + F.cu_stride);
-        if (nitem == ~0ull) return;
-        const uint64_t p2 = nitem / chunks, first = (nitem - p2 * chunks) * WGB * (uint64_t)P.k;     // first secret of that workgroup
-        if (first >= L.len) return;
-        const uint64_t count = L.len - first < (uint64_t)WGB * P.k ? L.len - first : (uint64_t)WGB * P.k;
-        const char* base = reinterpret_cast<const char*>(L.secrets + p2 * L.secrets_stride + first);
-#pragma unroll 1
-        for (uint64_t off = (uint64_t)tid * 128u; off < count * 8u; off += (uint64_t)kNgWorkers * 128u)    // one lane, one 128-byte line
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                             (__attribute__((address_space(3))) void*)Junk, 4, 0, 0);
-    };
+    // (Rounds 4 - 5 touched the NEXT workgroup's secrets ten tiles before this one ended - an L2 prefetch that bought 21 k cycles of
+    // staging per workgroup and fetched every secret twice (9.6 GB for 4.2 GB of secrets per 500-participant tile).  With the clerk
+    // waves streaming the previous tile through the same L2 it no longer pays: 12.6 ms per tile without it, 12.7 - 13.0 with it at any
+    // distance (profiles/r06/ab_ngemm_prefetch.txt) - removed.)
     // The two compute waves of a SIMD run half a period apart: waves 0-3 multiply tile r and THEN reduce and store it, waves 4-7
     // first reduce and store tile r - 1 and then multiply tile r - so one wave's products run beside the other's vector work.
     // (With every wave in the same order the per-tile barrier keeps all of them in lockstep: all on the matrix cores, then all on
     // the vector ALUs - 3700 cycles per tile where 2300 are matrix-core time, measured.)
     uint32_t slot = 0;
     for (uint32_t rt = 0; rt < tiles; ++rt) {
-        if (rt == pf_tile && !rp) prefetch_next();
         if (late && rt) finish(rt - 1);
         products(slot);
         slot = slot + 1 == (uint32_t)DEPTH ? 0u : slot + 1;
@@ -712,7 +897,6 @@ static hipError_t ngemm_launch(const GenLayout& L, const ModParams& mod, const D
         S.first_participant = L.first_participant + p0;
         note_kernel("packed_gen_ngemm_kernel<%d, %d>", KS, NT);
         NgFuse F{};
-        F.cu_stride = ng_cu_count();
         kern<<<dim3((unsigned)(chunks * cnt)), dim3(kNgThreads), lds, s>>>(S, mod, key, P, chunks, batches, F);
         if (hipError_t e = hipGetLastError()) return e;
     }
@@ -731,12 +915,37 @@ hipError_t launch_packed_generate_ngemm(const GenLayout& L, const ModParams& mod
 
 template <int KS, int NT>
 static hipError_t ngemm_launch_fused(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, NgFuse F,
-                                     size_t prev_rows, hipStream_t s, bool* fused) {
+                                     size_t prev_rows, hipStream_t s, bool* fused, uint64_t* d_progress, size_t progress_slots) {
     constexpr int WGB = 16 * kNgCompute * NT;
     const uint64_t batches = (L.len + P.k - 1) / P.k;
     const uint64_t chunks = (batches + WGB - 1) / WGB;
     F.n_gen = chunks * L.participants;
     const bool have_comb = F.prev && prev_rows > 0 && F.jobs > 0 && F.dimension > 0;
+    // ---- the default: clerk WAVES inside the share-generation workgroups (see ng_clerk_wave), then the follow-up kernel for the rest
+    const uint64_t slots = F.n_gen * (uint64_t)kNgClerkWaves;
+    // (an even dimension: the clerk waves read and write the running sums of a lane's two columns as one 16-byte access)
+    if (d_progress && have_comb && F.n_gen > 0 && F.n_gen <= 0x7FFFFFFFull && slots <= progress_slots && prev_rows < (1ull << 31) &&
+        F.dimension % 2 == 0) {
+        const uint64_t col_blocks = (((F.dimension + 1) / 2) + 63) / 64;
+        if (col_blocks <= 0xFFFFFFFFull) {
+            F.cw_col_blocks = (uint32_t)col_blocks;
+            F.cw_items = col_blocks * F.jobs;
+            F.cw_per_slot = (F.cw_items + slots - 1) / slots;
+            F.cw_progress = d_progress;
+            F.n_comb = 0; F.n_comb_wg = 0; F.n_early = 0; F.period = 1; F.items_per_wg = 0;
+            const size_t lds = ngemm_lds_bytes<KS, NT>();
+            auto kern = packed_gen_ngemm_kernel<KS, NT>;
+            if (lds > 64 * 1024)
+                if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
+            *fused = true;
+            note_kernel("packed_gen_ngemm_kernel<%d, %d>", KS, NT);
+            kern<<<dim3((unsigned)F.n_gen), dim3(kNgThreads), lds, s>>>(L, mod, key, P, chunks ? chunks : 1, batches, F);
+            if (hipError_t e = hipGetLastError()) return e;
+            const uint64_t cap = 256ull * 32ull;                      // single-wave workgroups walking the slots
+            ngemm_clerk_rest_kernel<<<dim3((unsigned)(slots < cap ? slots : cap)), dim3(64), 0, s>>>(F, slots);
+            return hipGetLastError();
+        }
+    }
     F.col_blocks = (uint32_t)((((F.dimension + 1) / 2) + 255) / 256);
     // clerk-sum items of up to 512 rows (as in the other dual-role launches)
     uint64_t splits = have_comb ? (prev_rows + 511) / 512 : 1;
@@ -774,17 +983,24 @@ static hipError_t ngemm_launch_fused(const GenLayout& L, const ModParams& mod, c
     if (lds > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     *fused = true;
-    F.cu_stride = cus;
     note_kernel("packed_gen_ngemm_kernel<%d, %d>", KS, NT);
     kern<<<dim3((unsigned)grid), dim3(kNgThreads), lds, s>>>(L, mod, key, P, chunks ? chunks : 1, batches, F);
     return hipGetLastError();
 }
 
+// (participant, chunk) workgroups x clerk waves of a share-generation launch over L: the progress slots the caller provides
+uint64_t ngemm_clerk_slots(const GenLayout& L, const NGemmPlan& P) {
+    const int nt = P.ks == 1 ? 4 : P.ks == 8 ? 1 : 2;
+    const uint64_t wgb = 16ull * kNgCompute * nt, batches = (L.len + P.k - 1) / P.k;
+    return (batches + wgb - 1) / wgb * L.participants * (uint64_t)kNgClerkWaves;
+}
+
 hipError_t launch_fused_packed_ngemm(const GenLayout& L, const ModParams& mod, const DrbgKey& key, const NGemmPlan& P, uint64_t* acc_lo,
                                      int64_t* acc_hi, const int64_t* d_prev, size_t prev_rows, size_t jobs, size_t dimension, hipStream_t s,
-                                     bool* fused) {
+                                     bool* fused, uint64_t* d_progress, size_t progress_slots) {
     *fused = false;
     if (L.rand) return hipSuccess;
+    if (L.participants == 0 || L.len == 0) return hipSuccess;       // nothing to generate: the plain clerk-sum kernel streams at the HBM rate
     const bool have_comb = d_prev && prev_rows > 0 && jobs > 0 && dimension > 0;
     // the clerk role reads the previous tile with 16-byte loads
     if (have_comb && !(((reinterpret_cast<uintptr_t>(d_prev) & 15u) == 0) && (L.out_stride_clerk % 2 == 0) && (L.out_stride_participant % 2 == 0)))
@@ -794,10 +1010,10 @@ hipError_t launch_fused_packed_ngemm(const GenLayout& L, const ModParams& mod, c
     F.job_stride = L.out_stride_clerk; F.row_stride = L.out_stride_participant;
     F.n_rows = prev_rows; F.dimension = dimension; F.jobs = (uint32_t)jobs;
     switch (P.ks) {
-        case 1: return ngemm_launch_fused<1, 4>(L, mod, key, P, F, prev_rows, s, fused);
-        case 2: return ngemm_launch_fused<2, 2>(L, mod, key, P, F, prev_rows, s, fused);
-        case 4: return ngemm_launch_fused<4, 2>(L, mod, key, P, F, prev_rows, s, fused);
-        case 8: return ngemm_launch_fused<8, 1>(L, mod, key, P, F, prev_rows, s, fused);
+        case 1: return ngemm_launch_fused<1, 4>(L, mod, key, P, F, prev_rows, s, fused, d_progress, progress_slots);
+        case 2: return ngemm_launch_fused<2, 2>(L, mod, key, P, F, prev_rows, s, fused, d_progress, progress_slots);
+        case 4: return ngemm_launch_fused<4, 2>(L, mod, key, P, F, prev_rows, s, fused, d_progress, progress_slots);
+        case 8: return ngemm_launch_fused<8, 1>(L, mod, key, P, F, prev_rows, s, fused, d_progress, progress_slots);
         default: return hipErrorInvalidValue;
     }
 }

@@ -110,7 +110,7 @@ namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
     "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES",
-    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP", "SDA_NO_NGEMM", "SDA_NO_WIDE_GROUP"};
+    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP", "SDA_NO_NGEMM", "SDA_NO_WIDE_GROUP", "SDA_NGEMM_CLERK_WG"};
 std::atomic<long> g_knobs[sda::KNOB_COUNT];
 }  // namespace
 long sda::knob(sda::Knob k) {
@@ -584,7 +584,7 @@ struct sda_share_generator {
     MatArg* matarg_n31_sys = nullptr;    // int32 constants, systematic map
     PathChoice path{};                   // what select_path() decided for this scheme (path_select.hpp) ...
     PathKnobs knobs{};                   // ... under these knobs, snapshotted when the handle was created
-    long knob_fft_g = 0, knob_no_lazy = 0, knob_no_side_stream = 0, knob_side_wgs = 0, knob_side_prio_high = 0;
+    long knob_fft_g = 0, knob_no_lazy = 0, knob_no_side_stream = 0, knob_side_wgs = 0, knob_side_prio_high = 0, knob_ngemm_clerk_wg = 0;
     bool fast = false;
     bool l31 = false;                    // balanced-31-bit-limb kernel, matrix in the kernarg segment
     bool l31g = false;                   // the same with run-time (k, t) and the matrix in global memory (d_M)
@@ -595,6 +595,7 @@ struct sda_share_generator {
     bool ngemm = false;                  // narrow prime (p < 2^23): the transform shapes run as a limb GEMM on the matrix cores instead
     NGemmPlan gplan{}, gplan_sys{};      // tss's share map (n rows) / the systematic one (n - t rows, shares 0..t-1 = the draws)
     DevBuf d_ngemm, d_ngemm_sys;
+    DevBuf d_cw_progress;                // limb GEMM, dual-role launch: (item, row) each clerk-wave slot stopped at (ngemm_kernels.hip)
     L31Params lp{};
     Drbg drbg;
     Ctx ctx;
@@ -967,6 +968,7 @@ static PathKnobs snapshot_knobs() {
 static void snapshot_call_knobs(sda_share_generator* g) {
     g->knob_fft_g = knob(KNOB_FFT_G); g->knob_no_lazy = knob(KNOB_NO_LAZY); g->knob_no_side_stream = knob(KNOB_NO_SIDE_STREAM);
     g->knob_side_wgs = knob(KNOB_SIDE_STREAM_WGS); g->knob_side_prio_high = knob(KNOB_SIDE_STREAM_PRIORITY_HIGH);
+    g->knob_ngemm_clerk_wg = knob(KNOB_NGEMM_CLERK_WG);
 }
 // what select_path() needs to know about the constants: host arithmetic only (g->Mmont must be built)
 static PathFacts path_facts(const sda_share_generator* g, const PathKnobs& kn) {
@@ -1111,7 +1113,7 @@ extern "C" int sda_debug_select_path(const sda_sharing_scheme_t* scheme, const c
 extern "C" void sda_share_generator_free(sda_share_generator_t* g) {
     if (!g) return;
     if (g->ctx.device >= 0) (void)hipSetDevice(g->ctx.device);
-    g->d_M.release(); g->d_Msys.release(); g->d_fft.release(); g->d_ngemm.release(); g->d_ngemm_sys.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
+    g->d_M.release(); g->d_Msys.release(); g->d_fft.release(); g->d_ngemm.release(); g->d_ngemm_sys.release(); g->d_cw_progress.release(); g->d_secrets.wipe_release(); g->d_rand.wipe_release(); g->d_out.wipe_release();
     if (g->aux) { (void)hipStreamSynchronize(g->aux); (void)hipStreamDestroy(g->aux); }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
@@ -1461,9 +1463,19 @@ extern "C" int sda_share_generator_generate_combine_dev(sda_share_generator_t* g
                                          s, &fused);
             break;
         case FAM_NGEMM:
-            he = launch_fused_packed_ngemm(L, g->mod, key, sys ? g->gplan_sys : g->gplan, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev,
-                                           prev_participants, c->jobs, c->dimension, s, &fused);
+        {
+            const NGemmPlan& gp = sys ? g->gplan_sys : g->gplan;
+            // the clerk waves' progress slots (grow-only; A/B knob SDA_NGEMM_CLERK_WG: rounds 4 - 5's clerk workgroups instead)
+            const uint64_t slots = g->knob_ngemm_clerk_wg ? 0 : ngemm_clerk_slots(L, gp);
+            if (slots && slots <= (1ull << 32)) {
+                const int rs = g->d_cw_progress.reserve((size_t)slots * 16);
+                if (rs != SDA_OK) { explicit_bzero(&key, sizeof key); return rs; }
+            }
+            he = launch_fused_packed_ngemm(L, g->mod, key, gp, c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev,
+                                           prev_participants, c->jobs, c->dimension, s, &fused,
+                                           slots && slots <= (1ull << 32) ? g->d_cw_progress.as<uint64_t>() : nullptr, (size_t)slots);
             break;
+        }
         case FAM_L31:
             he = launch_fused_packed_l31(L, g->n, g->k, g->t, g->mod, g->lp, sys ? *g->matarg_sys : *g->matarg, key, g->drbg.rounds,
                                          c->acc.lo.as<uint64_t>(), c->acc.hi.as<int64_t>(), d_prev, prev_participants, c->jobs,

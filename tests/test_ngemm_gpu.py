@@ -257,6 +257,54 @@ def test_narrow_limb_gemm_repeated_dual_role_launches(gpu):
         assert len(bad) == 0, (rep, len(bad), bad[:4].tolist())
 
 
+@pytest.mark.parametrize("form,P,batches", [("waves", 23, 300), ("waves", 41, 38), ("workgroups", 23, 300), ("waves", 5, 261)])
+def test_narrow_limb_gemm_clerk_waves_and_clerk_workgroups(gpu, form, P, batches):
+    """the two forms of the dual-role launch (round 6).  "waves": three clerk waves inside every share-generation workgroup sum the
+    previous tile with two register sets of ten rows in flight (ng_clerk_wave: hand-written counted waits), and
+    ngemm_clerk_rest_kernel sums what they did not get to - P = 23 / 41 rows make quanta of 10 + 10 + 3 / 4 x 10 + 1 (the partial
+    last quantum, an item that ends mid-workgroup, the recorded (item, row) the follow-up kernel resumes from); 38 batches leave
+    most lanes of a 128-column item without a column.  "workgroups": rounds 4 - 5's clerk workgroups in the grid, now persistent
+    (knob SDA_NGEMM_CLERK_WG).  An ODD number of batches (261) cannot use the clerk waves' 16-byte accesses to the running sums
+    and takes the workgroup form by itself.  Every clerk's sum over three tiles is compared with the oracle, five times over."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    if form == "workgroups":
+        set_knob("SDA_NGEMM_CLERK_WG", 1)
+    p, k, t, n = TSS_P1, 70, 57, 242
+    w2, w3 = _root(p, 128), _root(p, 243)
+    dim, tiles = 70 * batches - 11, 3
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    B = gen.batch_count(dim)
+    assert B == batches
+    Bs = (B + 15) // 16 * 16
+    rng = np.random.default_rng(29)
+    secs = [rng.integers(0, p, size=(P, dim), dtype=np.int64) for _ in range(tiles)]
+    d_secs = [DeviceBuffer.from_numpy(s) for s in secs]
+    want = np.zeros((n, B), dtype=np.int64)
+    for i in range(tiles):
+        for q in range(P):
+            sh = coracle.packed_generate_csprng(p, k, t, n, w2, w3, secs[i][q], coracle.drbg_fill(KEY, i * P + q, B, t, p), gen.csprng_share_map())
+            want = (want + sh) % p
+    bufs = [DeviceBuffer(n * P * Bs).zero() for _ in range(2)]
+    d_sums = DeviceBuffer(n * B)
+    for rep in range(5):
+        comb = crypto.ShareCombiner(sch)
+        comb.begin_dev(n, B)
+        for i in range(tiles + 1):
+            gen.generate_combine_dev(comb, d_secs[i].ptr if i < tiles else 0, P if i < tiles else 0, dim, dim, bufs[i % 2].ptr, Bs, P * Bs,
+                                     d_prev=bufs[(i - 1) % 2].ptr if i > 0 else 0, prev_participants=P if i > 0 else 0,
+                                     first_participant=i * P)
+            if i == 1:
+                assert gpu.sda_debug_last_kernel().decode() == "packed_gen_ngemm_kernel<2, 2>"      # ONE share-generation launch carries both roles
+        comb.finish_dev(d_sums.ptr)
+        got = d_sums.to_numpy().reshape(n, B)
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (form, rep, len(bad), bad[:4].tolist())
+
+
 def test_narrow_limb_gemm_fallbacks_keep_the_shares(gpu):
     """what surrounds the kernel: (1) another ChaCha round count (A/B only) has no limb-GEMM instance - on this tss-valid shape the
     transform kernel serves those calls, which is tss's map whatever was requested, and csprng_share_map() SAYS so (round 4

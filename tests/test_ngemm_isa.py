@@ -92,3 +92,39 @@ def test_the_store_hazard_check_finds_what_it_is_for():
     unguarded = ["buffer_store_dwordx4 v[60:63], v136, s[16:19], 0 offen nt", "v_add_u32 v1, v2, v3", "s_endpgm"]
     assert len(g.store_hazard_findings(unguarded)) == 1
     assert g.store_hazard_findings(["v_add_u32 v1, v2, v3"]) != []          # no store at all: wrong file
+
+
+def test_clerk_waves_load_pipeline_is_untouched_between_load_and_wait(assembly):
+    """The clerk waves (ng_clerk_wave) keep TWO register sets of row loads in flight and wait for one with a counted s_waitcnt
+    vmcnt(10) written by hand: the loads are inline assembly the compiler does not track.  Safe only if nothing else touches a set's
+    registers between its load and the wait that names them - __graft_entry__.clerk_pipeline_findings walks the loop of every
+    instance (twice: the back edge carries registers in flight); build() runs the same check."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    assert g.clerk_pipeline_findings(assembly) == []
+    waits = [l for l in assembly if "NGCW" in l]
+    assert waits and all("s_waitcnt vmcnt(10)" in l or "s_waitcnt vmcnt(0)" in l for l in waits), waits[:3]
+    assert sum("s_waitcnt vmcnt(10)" in l for l in waits) >= 8                 # two per instance in the loop
+
+
+def test_the_clerk_pipeline_check_finds_what_it_is_for():
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    head = ["_ZN3sda23packed_gen_ngemm_kernelILi4ELi2EEEvX:", ".LBB1_1:"]
+    loads = ["\tglobal_load_dwordx4 v[%d:%d], v[100:101], off nt ; NGCL" % (4 * i, 4 * i + 3) for i in range(10)]
+    loads_b = ["\tglobal_load_dwordx4 v[%d:%d], v[100:101], off nt ; NGCL" % (40 + 4 * i, 43 + 4 * i) for i in range(10)]
+    wait_a = "\ts_waitcnt vmcnt(10) ; NGCW " + " ".join("v[%d:%d]" % (4 * i, 4 * i + 3) for i in range(10))
+    wait_b = "\ts_waitcnt vmcnt(10) ; NGCW " + " ".join("v[%d:%d]" % (40 + 4 * i, 43 + 4 * i) for i in range(10))
+    tail = ["\ts_cbranch_scc1 .LBB1_1", ".Lfunc_end1:"]
+    good = head + [wait_a, "\tv_add_co_u32 v110, vcc, v0, v1"] + loads + ["\ts_barrier", wait_b, "\tv_add_co_u32 v111, vcc, v40, v41"] + loads_b + ["\ts_barrier"] + tail
+    assert g.clerk_pipeline_findings(good) == []
+    # a copy of a register that is still in flight (set A's v[4:7] read after its load, before its wait - across the back edge)
+    moved = head + [wait_a] + loads + ["\ts_barrier", wait_b, "\tv_mov_b32 v120, v5"] + loads_b + ["\ts_barrier"] + tail
+    assert any("touches v5" in f for f in g.clerk_pipeline_findings(moved))
+    # a use of set B right after the wait for set A
+    early = head + [wait_a, "\tv_add_u32 v110, v40, v41"] + loads + ["\ts_barrier", wait_b] + loads_b + ["\ts_barrier"] + tail
+    assert any("touches v40" in f for f in g.clerk_pipeline_findings(early))
+    assert g.clerk_pipeline_findings(["v_add_u32 v1, v2, v3"]) != []
+    assert any("missing" in f for f in g.clerk_pipeline_findings(head + ["\tv_add_u32 v1, v2, v3"] + tail))

@@ -1638,7 +1638,8 @@ def test_bench_single_gpu_line_carries_configs_4_and_5_as_full_jobs(gpu, tmp_pat
     assert legs["additive_chacha12"]["roofline"]["kernel"] == "fused_additive_kernel<12>" and "ChaCha12" in legs["additive_chacha12"]["config"]["randomness"]
     assert legs["config4_chacha12"]["config"]["share_count"] == 26 and legs["config4_chacha12"]["roofline"]["bound"] is None
     d = legs["packed_distinct"]
-    assert d["config"]["inputs"].startswith("distinct") and d["fill_bytes_per_element"] == 8.0 and d["frac_with_fill"] > d["roofline"]["frac"] * 1.1
+    assert d["config"]["inputs"].startswith("distinct") and d["fill_bytes_per_element"] == 8.0 and d["frac_with_fill"] == pytest.approx(d["frac_wall"] * 58.6667 / 50.6667, rel=1e-3)
+    assert d["frac_wall"] == pytest.approx(d["path_roofline"]["frac_of_hbm_peak"]) and compact["additional_workloads"]["packed_distinct"]["frac"] == pytest.approx(d["frac_wall"], rel=1e-3)
     assert d["config"]["distinct_participants"] == d["config"]["participants_total"]
     assert compact["additional_workloads"]["packed_distinct"]["frac_with_fill"] == pytest.approx(d["frac_with_fill"], rel=1e-3)
     # the kernel names are the library's own report of what it launched (sda_debug_last_kernel)
