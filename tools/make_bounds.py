@@ -40,7 +40,8 @@ for w in sorted(os.listdir(root)):
     for key, c in sq.items():
         kern, grid = [x.strip() for x in key.rsplit("::", 1)]
         short = kern.replace("void ", "").split("<")[0].replace("sda::", "")
-        role = ("fused" if short.startswith("fused") else "serial_gen" if "_gen_" in short or short.endswith("gen_kernel") else
+        dual_ngemm = short == "packed_gen_ngemm_kernel" and str(cfg.get("schedule", "")).startswith("dual-role")
+        role = ("fused" if short.startswith("fused") or dual_ngemm else "serial_gen" if "_gen_" in short or short.endswith("gen_kernel") else
                 "serial_comb" if short == "combine_update_kernel" else None)
         if role is None or "SQ_INSTS_VALU" not in c or "GRBM_GUI_ACTIVE" not in c:
             continue

@@ -32,12 +32,16 @@ for w in sorted(os.listdir(root)):
         fetch = c["FETCH_SIZE"]["mean_KiB"] * 1024 * 2
         write = c["WRITE_SIZE"]["mean_KiB"] * 1024
         short = kern.replace("void ", "").split("<")[0].replace("sda::", "")
-        tag = "fused" if "fused" in short else "gen" if "gen" in short else "comb" if "combine_update" in short else None
+        dual_ngemm = short == "packed_gen_ngemm_kernel" and str(cfg.get("schedule", "")).startswith("dual-role")
+        tag = ("fused" if "fused" in short or dual_ngemm else "rest" if short == "ngemm_clerk_rest_kernel" else
+               "gen" if "gen" in short else "comb" if "combine_update" in short else None)
         if tag:
             entry[tag + "_kernel"] = kern
             entry[tag + "_fetch_corrected_bytes"] = fetch
             entry[tag + "_write_bytes"] = write
             entry[tag + "_bytes_per_launch"] = fetch + write
+    if "rest_bytes_per_launch" in entry and "fused_bytes_per_launch" in entry:       # one call = the dual-role kernel + its follow-up kernel
+        entry["fused_bytes_per_launch"] += entry["rest_bytes_per_launch"]
     traffic[f"{cfg['name']}:tile{P}:dim{dim}"] = entry
     n, k = cfg["share_count"], cfg["secret_count"]
     alg = P * dim * (8 + 16 * n / k)
