@@ -19,6 +19,8 @@ from sda_amd.device import DeviceBuffer, DeviceBytes, synchronize  # noqa: E402
 
 P62 = 4611686006577364993
 W8, W9 = 631229665360524489, 3451275676410824977
+if any(os.environ.get(_k) for _k in ("SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU")):
+    capi.use_test_hooks()                                        # the knob table exists in libsda_hip_test.so only
 lib = capi.load()
 for _knob in ("SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU"):       # residency caps for the two-stream schedule (include/sda_hip_debug.h)
     if os.environ.get(_knob):

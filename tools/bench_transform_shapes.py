@@ -18,6 +18,8 @@ def root(p, order):
     return w
 
 
+if any(os.environ.get(_k) for _k in ("SDA_NO_XCD_MAP", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM")):
+    capi.use_test_hooks()                                        # the knob table exists in libsda_hip_test.so only
 lib = capi.load()
 for _k in ("SDA_NO_XCD_MAP", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM"):
     if os.environ.get(_k):

@@ -49,6 +49,7 @@ for rows in [int(x) for x in os.environ.get("ROWS", "2000,16000").split(",")]:
     comb = crypto.ShareCombiner(crypto.Additive(3, P62))
     o2 = DeviceBuffer(L)
     ref = None
+    capi.use_test_hooks()                                        # both decode forms: the knob table exists in libsda_hip_test.so only
     for path in ("scan", "stream"):
         capi.check(capi.load().sda_debug_set_knob(b"SDA_VARINT_PATH", 1 if path == "stream" else 2))
         dt = timed(lambda: codec.decode_dev(d_bytes.ptr, total[0], d_off.ptr, rows, L, dec.ptr, stride, st.ptr), reps=3)
@@ -68,7 +69,7 @@ for rows in [int(x) for x in os.environ.get("ROWS", "2000,16000").split(",")]:
                                            "GBps_algorithmic": (nv * 8 + total[0]) / dt / 1e9}
         out[f"wire_clerk_sum_{path}_{rows}x{L}"] = {"ms": dt2 * 1e3, "values_per_s": nv / dt2,
                                                    "GBps_wire_bytes": total[0] / dt2 / 1e9, "sums_equal_first_form": same}
-    capi.load().sda_debug_reset_knobs()
+    capi.use_release()
     # slotted rows: single pass on both sides
     del d_bytes
     slot = codec.slot_size(L)
