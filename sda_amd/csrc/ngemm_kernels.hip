@@ -188,14 +188,40 @@ template <int KS, int NT> constexpr size_t ngemm_lds_bytes() {      // A ring + 
 // in the domain of sda-drbg-v1's PAIRED rule (modarith.hpp): one lane = one block = draws 2j AND 2j + 1 of 8 batches - 78 blocks per
 // 8 batches of PSS_155_728_100 instead of 155.  A pair that straddles two 64-term steps is computed in both (each step writes the
 // element that falls into its term range).
+// the rare rejections of a draw pass (below 2^-18 per pair), redone from the retry stream: `rej` bit 8 * round + jj = pair (u, jj) of this
+// lane's round-th block was rejected (64 bits: up to eight rounds).  Cold and not inlined - see ng_draw_pass
+template <int WGB>
+__device__ __noinline__ void ng_draw_fixup(uint8_t* Bt, DrbgKey key, uint64_t stream, uint64_t b0, uint32_t k, uint32_t t, uint32_t t_lo,
+                                           uint32_t d_lo, uint32_t cd, uint64_t m, uint64_t thr2, uint64_t rej) {
+    ng_lptr B = (ng_lptr)Bt;
+    const uint32_t d_hi = d_lo + cd, t2 = (t + 1u) >> 1, j_lo = d_lo >> 1, cp = ((d_hi - 1u) >> 1) - j_lo + 1u;
+    for (uint32_t bit = 0; bit < 64u; ++bit) {
+        if (!((rej >> bit) & 1ull)) continue;
+        const uint32_t u = threadIdx.x + (bit >> 3) * (uint32_t)kNgWorkers, jj = bit & 7u;
+        const uint32_t nb = u / cp, j = j_lo + (u - nb * cp);
+        const uint64_t pr = f_drbg_retry_pair<20>(key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7], stream,
+                                                  (b0 + 8u * nb + jj) * (uint64_t)t2 + j, m, thr2);
+        const uint32_t i0 = 2u * j, i1 = i0 + 1u;
+        if (i0 >= d_lo) ng_put(B, WGB, 8u * nb + jj, k + i0 - t_lo, ng_digits((uint32_t)pr));
+        if (i1 < d_hi) ng_put(B, WGB, 8u * nb + jj, k + i1 - t_lo, ng_digits((uint32_t)(pr >> 32)));
+    }
+}
+
 template <int WGB>
 __device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t stream, uint64_t b0, uint32_t k, uint32_t t, uint32_t t_lo,
                                           uint32_t d_lo, uint32_t cd, uint64_t m, uint64_t thr2) {
     ng_lptr B = (ng_lptr)Bt;
     const uint32_t kk[8] = {key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7]};
     const uint32_t d_hi = d_lo + cd, t2 = (t + 1u) >> 1, j_lo = d_lo >> 1, cp = ((d_hi - 1u) >> 1) - j_lo + 1u;   // cd >= 1
+    // A rejected pair is NOT redone here: the call to the retry stream inside this loop made every value that lives across it (the
+    // block's sixteen words, the key, the loop state) a callee-saved register - 27 of them saved and restored in scratch memory by
+    // EVERY call of this pass, 166 KB per workgroup, and with the L2 turning over every few microseconds those bytes went to HBM and
+    // back (PSS_155_728_100: 33.7 GB written per tile for 30.5 GB of shares; the same with either share map).  The rejected pairs are
+    // noted in a mask (at most five blocks per lane and pass: (WGB / 8) * cp <= 64 * 33) and redone by ng_draw_fixup, called last.
+    uint64_t rej = 0;
+    uint32_t round = 0;
 #pragma unroll 1
-    for (uint32_t u = threadIdx.x; u < (uint32_t)(WGB / 8) * cp; u += kNgWorkers) {
+    for (uint32_t u = threadIdx.x; u < (uint32_t)(WGB / 8) * cp; u += kNgWorkers, ++round) {
         const uint32_t nb = u / cp, j = j_lo + (u - nb * cp);
         const uint64_t I = ((b0 >> 3) + nb) * (uint64_t)t2 + j;
         uint32_t o[16];
@@ -206,11 +232,13 @@ __device__ __noinline__ void ng_draw_pass(uint8_t* Bt, DrbgKey key, uint64_t str
         for (int jj = 0; jj < 8; ++jj) {
             const int cc = jj >> 1, e = jj & 1;
             const uint64_t xw = ((uint64_t)o[8 * e + cc] << 32) | o[8 * e + 4 + cc];
-            const uint64_t pr = f_draw_pair<20>(xw, kk, stream, (b0 + 8u * nb + jj) * (uint64_t)t2 + j, m, thr2);
-            if (w0) ng_put(B, WGB, 8u * nb + jj, k + i0 - t_lo, ng_digits((uint32_t)pr));
-            if (w1) ng_put(B, WGB, 8u * nb + jj, k + i1 - t_lo, ng_digits((uint32_t)(pr >> 32)));
+            uint32_t ra, rb;
+            if (!lemire_pair(xw, (uint32_t)m, thr2, ra, rb)) rej |= 1ull << (8u * round + (uint32_t)jj);
+            if (w0) ng_put(B, WGB, 8u * nb + jj, k + i0 - t_lo, ng_digits(ra));
+            if (w1) ng_put(B, WGB, 8u * nb + jj, k + i1 - t_lo, ng_digits(rb));
         }
     }
+    if (__builtin_expect(rej != 0, 0)) ng_draw_fixup<WGB>(Bt, key, stream, b0, k, t, t_lo, d_lo, cd, m, thr2, rej);
 }
 
 // systematic share map: draw i of a batch IS its share i.  The step's draws are read back from the tile (three digits ->
@@ -529,6 +557,34 @@ __global__ __launch_bounds__(64) void ngemm_clerk_rest_kernel(NgFuse F, uint64_t
 
 template <int N> __device__ __forceinline__ void ng_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// The loader wave's part of the row tiles, a function of its own (NOT inlined): in one build of the <8, 1> instance the compiler merged
+// this loop with the compute waves' row loop (one loop, the per-tile barrier shared) and parked the loader's lane offset in scratch
+// memory - reloaded every tile, behind a vmcnt(0) that also waits for the tiles in flight.  A call keeps the two loops apart.
+template <int KS>
+__device__ __noinline__ void ng_loader_rows(const uint8_t* A, uint8_t* Abuf, uint32_t tiles, uint32_t lane) {
+    constexpr int PIECES = KS * 3, ATILE = PIECES * 1024, DEPTH = NgRing<KS>::depth;
+    auto issue_tile = [&](uint32_t tile, uint32_t slot) {
+        const uint8_t* src = A + (size_t)tile * ATILE + lane * 16;
+        uint8_t* dst = Abuf + slot * ATILE;
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+    };
+    uint32_t slot = DEPTH - 1;                                      // slot of tile rt + DEPTH - 1
+    for (uint32_t rt = 0; rt < tiles; ++rt) {
+        const uint32_t nxt = rt + DEPTH - 1;
+        if (nxt < tiles) {
+            issue_tile(nxt, slot);                                  // the slot tile rt - 1 was read from (free since the last barrier)
+            ng_wait_vm<PIECES * (DEPTH - 2) < 63 ? PIECES * (DEPTH - 2) : 0>();     // tile rt + 1 has landed
+        } else {
+            ng_wait_vm<0>();
+        }
+        slot = slot + 1 == (uint32_t)DEPTH ? 0u : slot + 1;
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 template <int KS, int NT>
 // 168 registers: three waves per SIMD, i.e. the ten waves of two workgroups on a CU's four SIMDs
 __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void packed_gen_ngemm_kernel(GenLayout L, ModParams mod, DrbgKey key, NGemmPlan P,
@@ -629,18 +685,7 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 
     // ---- the row tiles ---------------------------------------------------------------------------------------------------
     if (loader) {
-        uint32_t slot = DEPTH - 1;                                  // slot of tile rt + DEPTH - 1
-        for (uint32_t rt = 0; rt < tiles; ++rt) {
-            const uint32_t nxt = rt + DEPTH - 1;
-            if (nxt < tiles) {
-                issue_tile(nxt, slot);                              // the slot tile rt - 1 was read from (free since the last barrier)
-                ng_wait_vm<PIECES * (DEPTH - 2) < 63 ? PIECES * (DEPTH - 2) : 0>();     // tile rt + 1 has landed
-            } else {
-                ng_wait_vm<0>();
-            }
-            slot = slot + 1 == (uint32_t)DEPTH ? 0u : slot + 1;
-            __builtin_amdgcn_s_barrier();
-        }
+        ng_loader_rows<KS>(P.A, Abuf, tiles, lane);
         return;
     }
     // this lane's output rows: 4 g + i of every tile; its batch columns: bl + nt, ADJACENT (column col of batch tile nt is batch

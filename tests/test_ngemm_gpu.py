@@ -305,6 +305,41 @@ def test_narrow_limb_gemm_clerk_waves_and_clerk_workgroups(gpu, form, P, batches
         assert len(bad) == 0, (form, rep, len(bad), bad[:4].tolist())
 
 
+def test_narrow_limb_gemm_rejected_draw_pairs_are_redone_from_the_retry_stream(gpu):
+    """The paired rule rejects a candidate word with probability (2^64 mod p^2) / 2^64 - below 2^-18, so rare that a parity test of
+    ordinary size never sees one.  The limb GEMM notes rejected pairs in a mask and redoes them in a cold function called LAST
+    (ng_draw_fixup: round 6 - a call to the retry stream inside the loop made the pass save 27 registers in scratch memory on every
+    call).  Here the prime is the one below 2^23 with the highest rejection rate among those that admit the shape (8211457:
+    2.95e-6) and the job has 12 million draw pairs: 35 rejections expected (none at all: probability e^-35).  With the library's
+    own randomness the draws ARE shares 0..t-1, so those rows are compared with the oracle's draws, every one of them."""
+    from sda_amd import crypto
+    from sda_amd.capi import check
+    from sda_amd.device import DeviceBuffer
+    from oracle import coracle
+    p, k, t, n = 8211457, 40, 23, 242
+    assert p <= 0x7F7F7F and (p - 1) % 64 == 0 and (p - 1) % 243 == 0
+    w2, w3 = _root(p, 64), _root(p, 243)
+    P, B = 2, 500_000
+    dim = k * B
+    expected_rejections = ((1 << 64) % (p * p)) / 2.0 ** 64 * P * B * ((t + 1) // 2)
+    assert expected_rejections > 30, expected_rejections
+    sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+    gen = crypto.ShareGenerator(sch)
+    gen.set_drbg_key(KEY)
+    assert gen.path_name().endswith("ngemm") and gen.csprng_share_map() == gen.SHARE_MAP_SYSTEMATIC and gen.batch_count(dim) == B
+    secrets = DeviceBuffer(P * dim)
+    check(gpu.sda_fill_synthetic_dev(secrets.ptr, P, dim, dim, 0, 77, p, None))
+    out = DeviceBuffer(n * P * B)
+    gen.generate_batch_dev(secrets.ptr, P, dim, dim, out.ptr, B, P * B, first_participant=5)
+    assert gpu.sda_debug_last_kernel().decode() == "packed_gen_ngemm_kernel<1, 4>"
+    for q in range(P):
+        want = coracle.drbg_fill(KEY, 5 + q, B, t, p).reshape(B, t)
+        for i in range(t):
+            got = out.to_numpy(B, (i * P + q) * B)
+            bad = np.flatnonzero(got != want[:, i])
+            assert len(bad) == 0, (q, i, len(bad), bad[:4].tolist())
+
+
 def test_narrow_limb_gemm_fallbacks_keep_the_shares(gpu):
     """what surrounds the kernel: (1) another ChaCha round count (A/B only) has no limb-GEMM instance - on this tss-valid shape the
     transform kernel serves those calls, which is tss's map whatever was requested, and csprng_share_map() SAYS so (round 4
@@ -398,3 +433,48 @@ def test_narrow_limb_gemm_random_shapes(gpu):
             w = coracle.packed_generate_csprng(p, k, t, n, w2, w3, sec[0], coracle.drbg_fill(KEY, trial, B, t, p), share_map)
             assert np.array_equal(o[:, :B], w), (trial, p, k, t, n, dim, share_map)
             assert not o[:, B:].any()
+
+
+def test_narrow_limb_gemm_dual_role_random_shapes(gpu):
+    """the dual-role launch over random shapes: every instance (1, 2, 4, 8 steps), 1 - 45 participants per tile (the clerk waves'
+    quanta of ten rows: fewer rows than one quantum, exact multiples, ragged ends), batch counts that fill a 128-column clerk item
+    partly, exactly or several times, even (clerk waves) and odd (clerk workgroups), row strides with padding.  The shares
+    themselves are pinned by the tests above; here the clerk sums of three tiles are compared with the column sums of the tiles
+    as they lie in device memory - every element."""
+    from sda_amd import crypto
+    from sda_amd.device import DeviceBuffer
+    rng = np.random.default_rng(606)
+    for trial in range(14):
+        p = (TSS_P1, TSS_P2)[trial % 2]
+        o2, o3 = (1024, 729) if p == TSS_P1 else (256, 19683)
+        kt = min(int(rng.choice([20, 63, 64, 100, 128, 200, 255, 300])), o2 - 1)
+        t = int(rng.integers(1, kt))
+        k = kt - t
+        n = int(rng.integers(kt, kt + 120))
+        w2, w3 = _root(p, o2), _root(p, o3)
+        B = int(rng.choice([2, 64, 126, 128, 130, 256, 258, 300, 514, 65, 257]))
+        P = int(rng.choice([1, 3, 9, 10, 11, 20, 29, 30, 45]))
+        dim, tiles = B * k - int(rng.integers(0, k)), 3
+        sch = crypto.PackedShamir(k, n, t, p, w2, w3)
+        gen = crypto.ShareGenerator(sch)
+        gen.set_drbg_key(KEY)
+        assert gen.batch_count(dim) == B
+        Bs = (B + 15) // 16 * 16 + 16 * (trial % 2)
+        secs = [DeviceBuffer.from_numpy(rng.integers(0, p, size=(P, dim), dtype=np.int64)) for _ in range(tiles)]
+        bufs = [DeviceBuffer(n * P * Bs).zero() for _ in range(2)]
+        comb = crypto.ShareCombiner(sch)
+        comb.begin_dev(n, B)
+        want = np.zeros((n, B), dtype=np.int64)
+        for i in range(tiles + 1):
+            gen.generate_combine_dev(comb, secs[i].ptr if i < tiles else 0, P if i < tiles else 0, dim, dim, bufs[i % 2].ptr, Bs, P * Bs,
+                                     d_prev=bufs[(i - 1) % 2].ptr if i > 0 else 0, prev_participants=P if i > 0 else 0,
+                                     first_participant=i * P)
+            if i < tiles:
+                tile = bufs[i % 2].to_numpy().reshape(n, P, Bs)[:, :, :B]
+                assert tile.min() >= 0 and tile.max() < p
+                want = (want + tile.sum(axis=1)) % p
+        d_sums = DeviceBuffer(n * B)
+        comb.finish_dev(d_sums.ptr)
+        got = d_sums.to_numpy().reshape(n, B)
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (trial, p, k, t, n, B, P, Bs, len(bad), bad[:4].tolist())

@@ -33,32 +33,58 @@ def kernel_body(lines, tag):
     return lines[start:end]
 
 
+def loops_of(body):
+    """{header label: [lines of the blocks LLVM annotates as belonging to that loop]} - block labels carry `in Loop: Header=BBx_y`
+    (the header itself `=>This Inner Loop Header` / `This Loop Header`), whatever order the blocks were laid out in (a rotated
+    loop has its latch, with the per-tile barrier, ABOVE its header)"""
+    loops, cur = {}, None
+    for l in body:
+        m = re.match(r"^(?:\.L(BB\d+_\d+):|; %bb\.\d+:)\s*(?:;\s*(.*))?$", l)
+        if m:
+            note = m.group(2) or ""
+            if "Loop Header" in note and m.group(1):
+                cur = m.group(1)
+            else:
+                h = re.search(r"in Loop: Header=(BB\d+_\d+)", note)
+                cur = h.group(1) if h else None
+        elif "Loop Header" in l and cur is None:
+            pass
+        if cur:
+            loops.setdefault(cur, []).append(l)
+    return loops
+
+
 @pytest.mark.parametrize("tag,mfma", sorted(INSTANCES.items()))
 def test_row_loop_is_free_of_scratch_accesses(assembly, tag, mfma):
     body = kernel_body(assembly, tag)
-    # the row loop: from the header of an innermost loop to the per-tile s_barrier that follows the row tile's matrix instructions
-    headers = [i for i, l in enumerate(body) if "Loop Header" in l] + [len(body)]
     found = False
-    for h, nxt in zip(headers, headers[1:]):
-        seg = [l.split(";")[0] for l in body[h:nxt]]
-        count, stop = 0, None
-        for i, l in enumerate(seg):
-            count += "v_mfma_i32_16x16x64_i8" in l
-            if count == mfma and "s_barrier" in l:
-                stop = i
-                break
-        if stop is None or count != mfma:
+    for header, lines in loops_of(body).items():
+        code = [l.split(";")[0] for l in lines]
+        if sum("v_mfma_i32_16x16x64_i8" in l for l in code) != mfma:
             continue
         found = True
-        loop = seg[:stop + 1]
-        scratch = [l.strip() for l in loop if "scratch_" in l]
+        assert any("s_barrier" in l for l in code), (tag, header, "the row loop has lost its per-tile barrier")
+        scratch = [l.strip() for l in code if "scratch_" in l]
         assert not scratch, (tag, "row loop touches scratch memory", scratch[:4])
-        # and no vector-memory LOAD in the compute waves' loop (the global_load_lds prefetches have no destination register and are
-        # never waited for)
-        loads = [l.strip() for l in loop if re.search(r"\b(global|buffer|flat)_load_(?!lds)", l)]
+        # and no vector-memory LOAD in the compute waves' loop (they never wait for vmcnt there: the loader wave streams the tiles)
+        loads = [l.strip() for l in code if re.search(r"\b(global|buffer|flat)_load_(?!lds)", l)]
         assert not loads, (tag, loads[:4])
     assert found, (tag, "no loop with %d matrix instructions found" % mfma)
 
+
+@pytest.mark.parametrize("ks", [1, 2, 4, 8])
+def test_loader_loop_waits_with_counted_vmcnt_only(assembly, ks):
+    """the loader wave's row loop (ng_loader_rows, a function of its own since round 6): tile loads straight into LDS, a counted
+    s_waitcnt vmcnt, the barrier - no scratch access, no register-destination load (either would be waited for with vmcnt(0)
+    and stall the tiles in flight)"""
+    start = next(i for i, l in enumerate(assembly) if l.startswith("_ZN3sda14ng_loader_rowsILi%dE" % ks) and ":" in l)
+    end = next(i for i in range(start, len(assembly)) if assembly[i].startswith(".Lfunc_end"))
+    loops = loops_of(assembly[start:end])
+    assert loops, "no loop in ng_loader_rows"
+    for header, lines in loops.items():
+        code = [l.split(";")[0] for l in lines]
+        assert any("global_load_lds_dwordx4" in l for l in code) and any("s_barrier" in l for l in code), header
+        assert not [l for l in code if "scratch_" in l or re.search(r"\b(global|buffer|flat)_load_(?!lds)", l)], header
 
 
 def test_buffer_stores_are_guarded_against_the_store_hazard(assembly):
