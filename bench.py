@@ -669,8 +669,23 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     w, n, k, t, scheme, B, Bs, gen, comb = _setup(env, name, dim, P, row_align, rounds)
     q = prime_of(w)
     distinct = inputs == "distinct"
-    secrets = [torch.empty((P, dim), dtype=torch.int64, device=dev) for _ in range(2 if distinct else 1)]
-    shares = [torch.empty((n, P, Bs), dtype=torch.int64, device=dev) for _ in range(2)]
+    # ONE allocation for the resident working set (secrets, the two share buffers), the buffers 1 MiB apart inside it.  With three
+    # separate allocations the physical placement of the two share buffers relative to each other is a lottery per process: in
+    # about half the runs every second launch (the ones that write the second buffer) took 23.1 ms instead of 22.0 - 114 - 116
+    # Gelem/s where 118.5 - 119.5 is the kernel's rate (profiles/r06/headline_launch_pattern.txt, headline_arena.txt).
+    # SDA_BENCH_ARENA_PAD=<bytes> sets another gap, -1 the separate allocations (experiments only).
+    arena_pad = int(os.environ.get("SDA_BENCH_ARENA_PAD", str(1 << 20)))
+    n_sec = 2 if distinct else 1
+    if arena_pad >= 0:
+        e_sec, e_sh, gap = P * dim, n * P * Bs, arena_pad // 8
+        arena = torch.empty(n_sec * (e_sec + gap) + 2 * (e_sh + gap) + 64, dtype=torch.int64, device=dev)
+        secrets = [arena[j * (e_sec + gap):j * (e_sec + gap) + e_sec].view(P, dim) for j in range(n_sec)]
+        off = n_sec * (e_sec + gap)
+        shares = [arena[off + i * (e_sh + gap):off + i * (e_sh + gap) + e_sh].view(n, P, Bs) for i in range(2)]
+    else:
+        arena = None
+        secrets = [torch.empty((P, dim), dtype=torch.int64, device=dev) for _ in range(n_sec)]
+        shares = [torch.empty((n, P, Bs), dtype=torch.int64, device=dev) for _ in range(2)]
     side = torch.cuda.Stream(dev) if distinct else None
     filled = [torch.cuda.Event() for _ in secrets]          # secrets[j] holds its tile
     consumed = [torch.cuda.Event() for _ in secrets]        # the launch that read secrets[j] has finished
@@ -789,6 +804,7 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
                        "both_roles_launch_ms_median": _median(full) if full else None,
                        "both_roles_launch_ms_min_max": [min(full), max(full)] if full else None,
                        "first_launch_ms_share_gen_only": launch_ms[0], "last_launch_ms_clerk_sum_only": launch_ms[-1],
+                       "launch_ms_each": [round(x, 3) for x in launch_ms],          # (details file only: every launch, in order)
                        "note": "one launch = share-gen of a tile (8 + 8n/k B/element) + clerk-sum of the previous tile "
                                "(8n/k B/element); K tiles take K+1 launches (the first only generates, the last only "
                                "sums), achieved = K x algorithmic_bytes_per_launch / sum of the K+1 launch durations"}
@@ -801,7 +817,8 @@ def measure_fused(env, name, dim, P, n_sub, steps, warmup, row_align=16, verify=
     res["reveal"] = reveal
     res["exchange_ms"] = env.max_over_ranks(exchange_ms)      # the cross-GPU modular reduce, inside the timed region
     res["exchange_bytes_per_gpu"] = 8 * n * B
-    del secrets, shares, sums, total
+    res["config"]["allocation"] = ("one arena, buffers %d bytes apart" % arena_pad) if arena_pad >= 0 else "separate allocations"
+    del secrets, shares, sums, total, arena
     torch.cuda.empty_cache()
     return res
 

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 DOCS = ["DESIGN.md", "BASELINE.md", "README.md"]
 # the builder's runs of THIS round's final code (compact stdout lines of bench.py), in the order they are listed
-BUILDER_RUNS = ["profiles/r06/driver_form/bench_line.json", "profiles/r06/bench_line_clerk_waves.json"]
+BUILDER_RUNS = ["profiles/r06/driver_form/bench_line.json", "profiles/r06/bench_line_default.json"]
 ROUND = 6
 
 LEGS = [  # (key on the line, what it is)
@@ -88,7 +88,8 @@ def bench_block():
                       f"(`narrow_pss728`, `narrow_pss19682`) and legs it added are marked" if stale else "") + ".")
     else:
         out.append("Driver record: none with a parsed line.")
-    out.append(f"Builder runs of round {ROUND}'s code (each on a fresh gpurun box; box-to-box spread is about +-2 %): "
+    out.append(f"Builder runs of round {ROUND}'s code (each on a fresh gpurun box; the same command gives figures 2 - 4 % apart from run to run "
+               f"and box to box - `profiles/r06/headline_warmup.txt`, `headline_launch_pattern.txt`, `headline_arena.txt`): "
                + ", ".join(f"`{p}` (`--steps {l['steps']} --warmup {l['warmup']}`, build `{l.get('build_id')}`)" for p, l in runs) + ".")
     out.append("")
     out.append("| leg of the bench line | driver: G elements/s = fraction of 8 TB/s | builder boxes, round %d code: G elements/s = fraction (lo - hi) | bound | verified |" % ROUND)

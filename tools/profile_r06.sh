@@ -6,10 +6,12 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r06_final; mkdir -p $O
 # tiles = the ones bench.py runs in the driver form (its `roofline.traffic` is a measurement of exactly that tile or null)
 declare -A TILE=( [packed]=2500 [additive]=2000 [packed26]=1250 [packed_ref]=1500 [packed26_ref]=1500 [packed_dim16m]=125 [packed_pss728]=500 [narrow_ref]=1500 [narrow26_ref]=1500 [narrow_pss728]=500 [narrow_pss19682]=40 )
 declare -A SCHED=( [packed_pss728]="--schedule serial" )
-WLS="${@:-packed additive packed26 packed_dim16m packed_pss728 narrow_ref narrow26_ref narrow_pss728 narrow_pss19682}"
+# (name@tile: the same workload at another tile - packed@2000 is what `python bench.py` without flags runs, 50 steps of 2000)
+WLS="${@:-packed packed@2000 additive packed26 packed_dim16m packed_pss728 narrow_ref narrow26_ref narrow_pss728 narrow_pss19682}"
 cd /tmp && export TMPDIR=/tmp
-for W in $WLS; do
-  T=${TILE[$W]}; S=${SCHED[$W]}; D=$O/$W; mkdir -p $D
+for WT in $WLS; do
+  W=${WT%@*}; T=${TILE[$W]}; D=$O/$W; [ "$WT" != "$W" ] && { T=${WT#*@}; D=$O/${W}_tile$T; }
+  S=${SCHED[$W]}; mkdir -p $D
   A="--full-line --workload $W --tile $T --no-cpu-baseline --no-verify --no-additional $S"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python $R/bench.py $A --steps 10 --warmup 2 --participants $((10*T)) 2>$D/rocprof_stats.log | tail -1 > $D/bench_under_rocprof.json
   for c in fetch write sq; do
