@@ -1188,7 +1188,8 @@ def main():
                                         "packed_pss728": {k: pss[k] for k in keep if k in pss}}
         # the reference's OWN valid domain (tss multiplies i64 residues without widening): the tss-valid shapes over a 31-bit
         # prime and tss's shipped PSS_155_728_100 over its own prime 746497, through the narrow (one 32-bit limb) kernels
-        for nm, part, tile in (("narrow_ref", 6000, 1500), ("narrow26_ref", 6000, 1500), ("narrow_pss728", 4000, 500),
+        # (tiles of 2000 for the two small shapes: 2 - 4 % above tiles of 1500, profiles/r06/narrow_tile_sweep.txt)
+        for nm, part, tile in (("narrow_ref", 8000, 2000), ("narrow26_ref", 8000, 2000), ("narrow_pss728", 4000, 500),
                                ("narrow_pss19682", 160, 40)):
             r = run(nm, 4, 1, participants=part, tile=tile)
             line["additional_workloads"][nm] = {k: r[k] for k in keep if k in r}

@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 DOCS = ["DESIGN.md", "BASELINE.md", "README.md"]
 # the builder's runs of THIS round's final code (compact stdout lines of bench.py), in the order they are listed
-BUILDER_RUNS = ["profiles/r06/driver_form/bench_line.json", "profiles/r06/bench_line_default.json"]
+BUILDER_RUNS = ["profiles/r06/lines/bench_line_driver_form_1.json", "profiles/r06/lines/bench_line_driver_form_2.json",
+                "profiles/r06/lines/bench_line_default.json"]
 ROUND = 6
 
 LEGS = [  # (key on the line, what it is)

@@ -4,7 +4,7 @@
 # (tools/pmc_sq.txt, two more passes).   bash tools/profile_r06.sh [workloads...]  ->  gpurun_out/r06_final/<workload>/
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r06_final; mkdir -p $O
 # tiles = the ones bench.py runs in the driver form (its `roofline.traffic` is a measurement of exactly that tile or null)
-declare -A TILE=( [packed]=2500 [additive]=2000 [packed26]=1250 [packed_ref]=1500 [packed26_ref]=1500 [packed_dim16m]=125 [packed_pss728]=500 [narrow_ref]=1500 [narrow26_ref]=1500 [narrow_pss728]=500 [narrow_pss19682]=40 )
+declare -A TILE=( [packed]=2500 [additive]=2000 [packed26]=1250 [packed_ref]=1500 [packed26_ref]=1500 [packed_dim16m]=125 [packed_pss728]=500 [narrow_ref]=2000 [narrow26_ref]=2000 [narrow_pss728]=500 [narrow_pss19682]=40 )
 declare -A SCHED=( [packed_pss728]="--schedule serial" )
 # (name@tile: the same workload at another tile - packed@2000 is what `python bench.py` without flags runs, 50 steps of 2000)
 WLS="${@:-packed packed@2000 additive packed26 packed_dim16m packed_pss728 narrow_ref narrow26_ref narrow_pss728 narrow_pss19682}"
