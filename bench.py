@@ -1124,7 +1124,7 @@ def main():
     ap.add_argument("--deadline-s", type=float, default=900.0,
                     help=f"hang protection: end every rank and exit with code {EXIT_DEADLINE} (no JSON line) when the whole run "
                          "takes longer than this many seconds; 0 = no deadline (long custom runs)")
-    ap.add_argument("--exchange-timeout-s", type=float, default=90.0,
+    ap.add_argument("--exchange-timeout-s", type=float, default=180.0,
                     help=f"hang protection: limit of ONE cross-rank exchange (communicator set-up, the warm-up and the timed "
                          f"modular reduce); a rank that waits longer prints its diagnosis and exits with code {EXIT_EXCHANGE}")
     args = ap.parse_args()
