@@ -318,7 +318,10 @@ int sda_share_combiner_set_residency(sda_share_combiner_t* c, unsigned max_workg
  * overlaps the two; the shares are still materialised in HBM and read back.  `c` must have been begun with
  * jobs = share_count and dimension = batches.  participants == 0 -> clerk-sum only (last tile);
  * prev_participants == 0 -> generation only (first tile).  Randomness: the on-device CSPRNG, stream ids
- * first_participant + p - identical shares to sda_share_generator_generate_batch_dev. */
+ * first_participant + p - identical shares to sda_share_generator_generate_batch_dev.
+ * For the limb GEMM shapes (a prime below 2^23, k + t > 16) the clerk sum rides inside the share-generation kernel and a
+ * short follow-up launch on the same stream finishes it; the two communicate through scratch memory the GENERATOR owns:
+ * consecutive calls on one generator go on ONE stream (or are ordered by the caller), like every other use of a handle. */
 int sda_share_generator_generate_combine_dev(sda_share_generator_t* g, sda_share_combiner_t* c,
                                              const int64_t* d_secrets, size_t participants, size_t len,
                                              size_t secrets_stride, uint64_t first_participant,
