@@ -412,3 +412,39 @@ def test_integration_md_rust_shim_matches_the_header(built, tmp_path):
             off += size[t]
             align = max(align, a)
         assert got[(sname, "size")] == (off + align - 1) // align * align, sname
+
+
+def test_drbg_draw_rule_query(built):
+    """ABI 6: which draw rule of sda-drbg-v1 serves a modulus - the paired rule (one candidate word per two draws) up to 0x7F7F7F,
+    one word per draw above; out-of-range moduli come back as status codes.  No device needed."""
+    from sda_amd import capi
+    lib = capi.load()
+    assert lib.sda_drbg_draw_rule(433) == 2 and lib.sda_drbg_draw_rule(746497) == 2 and lib.sda_drbg_draw_rule(0x7F7F7F) == 2
+    assert lib.sda_drbg_draw_rule(0x7F7F7F + 1) == 1 and lib.sda_drbg_draw_rule(2147482801) == 1
+    assert lib.sda_drbg_draw_rule(4611686006577364993) == 1
+    assert lib.sda_drbg_draw_rule(1) == capi.ERR_INVALID_ARGUMENT and lib.sda_drbg_draw_rule(-5) == capi.ERR_INVALID_ARGUMENT
+    assert lib.sda_drbg_draw_rule(1 << 62) == capi.ERR_UNSUPPORTED
+    assert lib.sda_comm_rccl_version() == 0                      # nothing has bound RCCL in this process
+
+
+def test_loader_switches_between_the_two_libraries(built):
+    """sda_amd.capi: load() is a proxy for the ACTIVE library - the release one unless use_test_hooks() was called; a reference
+    taken before a switch follows it; use_release() resets the knobs it leaves behind."""
+    from sda_amd import capi
+    lib = capi.load()
+    assert capi.active_path() == capi.RELEASE_LIB_PATH and lib.sda_debug_hooks_compiled_in() == 0
+    assert b"+test-hooks" not in lib.sda_version()
+    capi.use_test_hooks()
+    try:
+        assert capi.active_path() == capi.TEST_LIB_PATH and capi.has_test_hooks() and lib.sda_debug_hooks_compiled_in() == 1
+        assert b"+test-hooks" in lib.sda_version()
+        assert lib.sda_debug_set_knob(b"SDA_FORCE_GENERIC", 1) == capi.OK
+        assert capi.hooks_library().sda_debug_hooks_compiled_in() == 1
+    finally:
+        capi.use_release()
+    assert capi.active_path() == capi.RELEASE_LIB_PATH and lib.sda_debug_hooks_compiled_in() == 0
+    # the knob did not survive: the selection table of the test library (stateless call) still says what the defaults say
+    import ctypes as C
+    s = capi.SharingScheme(capi.SHARING_PACKED_SHAMIR, 8, 4611686006577364993, 3, 1, 631229665360524489, 3451275676410824977)
+    buf = C.create_string_buffer(256)
+    assert capi.hooks_library().sda_debug_select_path(C.byref(s), None, buf, 256) == capi.OK and b"wide=l31" in buf.value

@@ -191,3 +191,23 @@ def test_bench_emit_refuses_an_oversized_line(tmp_path, capfd):
     assert os.read(r, 10) == b"" and "4096" in str(e.value)                # nothing reached "stdout"
     os.close(r)
     assert json.load(open(tmp_path / "d.json"))["metric"] == full["metric"]   # the details file was still written
+
+
+def test_bench_cpu_sweep_cache_is_keyed_by_host_and_workload(tmp_path, monkeypatch):
+    """bench.py's all-cores CPU sweep (100 s of round 5's 163 s default run) is taken from profiles/cpu_baseline_hosts.json only for
+    the SAME cpu model, thread count, workload and dimension; the one-core baseline is always timed; `fresh` ignores the file"""
+    bench = _bench()
+    host = bench._host_cpu()
+    w, dim = dict(bench.WORKLOADS["additive"]), 4096
+    key = f"{host['cpu_model']}|{host['usable_threads']} threads|additive|dim {dim}"
+    cache = tmp_path / "hosts.json"
+    cache.write_text(json.dumps({key: {"value": 123.0, "unit": "elements/s", "cores": 7, "sample": "from the file"}}))
+    monkeypatch.setattr(bench, "CPU_SWEEP_CACHE", str(cache))
+    got = bench.cpu_baseline(w, dim, budget_s=0.3, samples=1, name="additive", mode="auto")
+    assert got["cores"] == 1 and got["value"] > 0 and got["all_cores"]["cached"] is True and got["all_cores"]["value"] == 123.0
+    other = bench.cpu_baseline(w, 2048, budget_s=0.3, samples=1, name="additive", mode="auto")          # another dimension: not in the file
+    assert other["value"] > 0 and not (other.get("all_cores") or {}).get("cached", False)
+    fresh = bench.cpu_baseline(w, dim, budget_s=0.3, samples=1, name="additive", mode="fresh")
+    assert not (fresh.get("all_cores") or {}).get("cached", False)
+    committed = json.load(open(os.path.join(ROOT, "profiles", "cpu_baseline_hosts.json")))
+    assert any(k.endswith("|packed|dim 1048576") for k in committed if not k.startswith("_"))
