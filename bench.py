@@ -1188,16 +1188,18 @@ def main():
                                         "packed_pss728": {k: pss[k] for k in keep if k in pss}}
         # the reference's OWN valid domain (tss multiplies i64 residues without widening): the tss-valid shapes over a 31-bit
         # prime and tss's shipped PSS_155_728_100 over its own prime 746497, through the narrow (one 32-bit limb) kernels
-        # (tiles of 2000 for the two small shapes: 2 - 4 % above tiles of 1500, profiles/r06/narrow_tile_sweep.txt)
-        for nm, part, tile in (("narrow_ref", 8000, 2000), ("narrow26_ref", 8000, 2000), ("narrow_pss728", 4000, 500),
-                               ("narrow_pss19682", 160, 40)):
-            r = run(nm, 4, 1, participants=part, tile=tile)
+        # (tiles of 2000 for the two small shapes: 2 - 4 % above tiles of 1500, profiles/r06/narrow_tile_sweep.txt.  TWELVE tiles per
+        # leg: K tiles take K + 1 launches - the first only generates, the last only sums - and with round 5's four tiles that
+        # pipeline fill was a fifth of a leg's time, 0.61 on the line for a kernel whose both-roles launches run at 0.65)
+        for nm, part, tile in (("narrow_ref", 24000, 2000), ("narrow26_ref", 24000, 2000), ("narrow_pss728", 6000, 500),
+                               ("narrow_pss19682", 480, 40)):
+            r = run(nm, 12, 1, participants=part, tile=tile)
             line["additional_workloads"][nm] = {k: r[k] for k in keep if k in r}
         # the REFERENCE's own share map on the headline shape (packed_shamir.rs:42 -> tss share: values = [0] ++ secrets ++
         # randomness): every other number on this line is on the library's systematic map (n - t dot products per batch)
         if not env.csprng_share_map:
             env.csprng_share_map = "tss"
-            r = run("packed", 4, 1, participants=(args.participants or 10_000), dim=args.dim)
+            r = run("packed", 10, 1, participants=(args.participants or 25_000), dim=args.dim)
             env.csprng_share_map = ""
             line["additional_workloads"]["packed_tss_nodes"] = {k: r[k] for k in keep if k in r}
         # The price of 100,000 DIFFERENT participants (participate.rs:37-76 runs once per participant; the headline replays one
@@ -1217,10 +1219,10 @@ def main():
         # per element); the same legs with the CSPRNG at 12 rounds show how much of their gap to the headline is that policy.  The
         # PRODUCT runs 20 rounds (what chacha.rs:36 - rand 0.3's ChaChaRng - uses) and these two are never the headline.
         if args.drbg_rounds == 20:
-            r = run("additive", 4, 1, participants=8_000, rounds=12)
+            r = run("additive", 5, 2, rounds=12)                                 # config 2's own job: 10,000 participants, 5 tiles
             r["rounds"] = 12
             line["additional_workloads"]["additive_chacha12"] = {k: r[k] for k in keep + ("rounds",) if k in r}
-            r = run("packed26", 4, 1, participants=(args.leg_participants or 10_000), dim=args.leg_dim or 0, tile=1250, rounds=12)
+            r = run("packed26", 20, 1, participants=(args.leg_participants or 50_000), dim=args.leg_dim or 0, tile=1250, rounds=12)
             r["rounds"] = 12
             line["additional_workloads"]["config4_chacha12"] = {k: r[k] for k in keep + ("rounds",) if k in r}
     if env.world > 1 and not args.no_additional and args.workload == "packed":

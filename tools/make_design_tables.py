@@ -29,7 +29,7 @@ LEGS = [  # (key on the line, what it is)
     ("additive", "BASELINE config 2: additive 3-way, 10,000 participants"),
     ("additive_chacha12", "config 2 with the CSPRNG at 12 rounds (A/B leg; the product runs ChaCha20)"),
     ("config4_full", "BASELINE config 4 at its full job size on ONE GPU: 1,000,000 participants of (k=8, t=2, n=26)"),
-    ("config4_chacha12", "config 4's shape with the CSPRNG at 12 rounds (A/B leg, 10,000 participants)"),
+    ("config4_chacha12", "config 4's shape with the CSPRNG at 12 rounds (A/B leg, 50,000 participants)"),
     ("config5_full", "BASELINE config 5 at its full job size on ONE GPU: 100,000 participants at dim 16 Mi, reveal included"),
     ("narrow_ref", "tss-valid (k=3, t=4, n=8) over a 31-bit prime (the reference's own domain; narrow kernels)"),
     ("narrow26_ref", "tss-valid (k=8, t=7, n=26) over a 31-bit prime"),
