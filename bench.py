@@ -972,8 +972,8 @@ def compact_line(full, details_path="bench_details.json"):
     line["config"] = _pick(full.get("config", {}), ("workload", "baseline_config", "name", "dim", "participants_total",
                                                      "tile_participants", "modulus", "csprng_share_map", "inputs", "library_path"))
     roof = full.get("roofline") or {}
-    line["roofline"] = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
-                                    "both_roles_launch_ms", "avg_launch_ms", "launches"))
+    line["roofline"] = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "tables_current",
+                                    "algorithmic_bytes_per_launch", "both_roles_launch_ms", "avg_launch_ms", "launches"))
     cpu = full.get("cpu_baseline")
     if cpu:
         line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "sample", "cpu_model", "physical_cores"))
@@ -1162,6 +1162,13 @@ def main():
     line = run(args.workload, args.steps, args.warmup, args.participants, args.dim, args.tile)
     line["rccl"] = env.rccl
     line["build_id"] = env.lib.sda_build_id().decode()
+    line["kernel_id"] = env.lib.sda_kernel_id().decode()
+    # `roofline.traffic` / `roofline.bound` are look-ups in profiles/{traffic,bounds}.json: say whether those tables were measured
+    # on the kernels that are running now (their `_kernel_id` stamp against sda_kernel_id()) - a kernel change that forgot to
+    # regenerate them would otherwise print a stale figure
+    stamps = {f: _profiles_json(f).get("_kernel_id") for f in ("traffic.json", "bounds.json")}
+    line["roofline"]["tables_current"] = all(v == line["kernel_id"] for v in stamps.values())
+    line["roofline"]["tables_kernel_id"] = stamps
     line["library"] = env.lib.sda_version().decode()
     keep = ("value", "unit", "n_gpus", "steps", "ms_per_step", "config", "kernels", "roofline", "path_roofline",
             "verified_reconstruct_equals_sum", "verified_against", "reveal", "exchange_ms", "exchange_bytes_per_gpu")

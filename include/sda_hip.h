@@ -129,6 +129,8 @@ const char* sda_version(void);
 const char* sda_build_id(void);              /* first 16 hex digits of the sha256 over the sources, internal headers and
                                                 the public headers this binary was compiled from ("unknown" for a hand build);
                                                 __graft_entry__.source_digest() recomputes it from a tree */
+const char* sda_kernel_id(void);             /* the same over the DEVICE code only (.hip files + internal headers): which kernels this
+                                                binary carries - what a table of counter measurements is valid for (ABI 6) */
 int         sda_device_count(void);          /* number of visible HIP devices, 0 if none      */
 int         sda_set_device(int ordinal);     /* device used by handles created afterwards     */
 int         sda_device_pci_bus_id(int ordinal, char* out, size_t cap);   /* "0000:05:00.0"; cap >= 16; identifies the

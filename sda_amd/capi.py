@@ -84,6 +84,7 @@ SIGNATURES = {
     "sda_debug_last_kernel": (C.c_char_p, []),
     "sda_version": (C.c_char_p, []),
     "sda_build_id": (C.c_char_p, []),
+    "sda_kernel_id": (C.c_char_p, []),
     "sda_share_generator_path_name": (C.c_char_p, [_H]),
     "sda_device_count": (C.c_int, []),
     "sda_set_device": (C.c_int, [C.c_int]),

@@ -160,6 +160,10 @@ extern "C" const char* sda_version(void) { return "sda-hip 0.6.0 (gfx950)"; }
 #define SDA_BUILD_ID "unknown"
 #endif
 extern "C" const char* sda_build_id(void) { return SDA_BUILD_ID; }
+#ifndef SDA_KERNEL_ID
+#define SDA_KERNEL_ID "unknown"
+#endif
+extern "C" const char* sda_kernel_id(void) { return SDA_KERNEL_ID; }
 
 static thread_local char g_last_gen_kernel[192];       // the last share-generation kernel instance launched on this thread
 static thread_local char g_last_call_kernels[320];     // ... and the launches of the last generate call, as one string

@@ -85,7 +85,9 @@ def test_release_library_has_no_test_hooks(built):
     for path, want in ((capi.RELEASE_LIB_PATH, 0), (capi.TEST_LIB_PATH, 1)):
         so = ctypes.CDLL(path)
         so.sda_build_id.restype = ctypes.c_char_p
+        so.sda_kernel_id.restype = ctypes.c_char_p
         assert so.sda_debug_hooks_compiled_in() == want and so.sda_build_id().decode() == g.source_digest()
+        assert so.sda_kernel_id().decode() == g.kernel_digest() != g.source_digest()          # the device code's own digest
     assert capi.active_path() == capi.RELEASE_LIB_PATH and not capi.has_test_hooks()
     with pytest.raises(AttributeError, match="libsda_hip_test.so"):
         capi.load().sda_debug_set_knob

@@ -22,11 +22,13 @@ FLOOR = {"fused": 5940.0, "serial_gen": 6140.0, "serial_comb": 6510.0}
 XCDS, SIMDS = 8, 1024
 bounds = {"_note": __doc__.split("Rule.")[1].strip(), "_floors_GBps": FLOOR}
 rows = []
+kernel_ids = set()
 for w in sorted(os.listdir(root)):
     d = os.path.join(root, w)
     if not os.path.isfile(os.path.join(d, "pmc_sq.json")):
         continue
     line = json.loads(open(os.path.join(d, "bench_under_rocprof.json")).read().splitlines()[-1])
+    kernel_ids.add(line.get("kernel_id"))
     cfg, roof = line["config"], line["roofline"]
     P, dim = cfg["tile_participants"], cfg["dim"]
     hbm = json.load(open(os.path.join(d, "pmc_hbm.json")))
@@ -82,6 +84,7 @@ for w in sorted(os.listdir(root)):
         h = e.get("hbm", {})
         rows.append((cfg["name"], role, e["bound"], h.get("pmc_GBps", float("nan")), h.get("frac_of_floor", float("nan")),
                      e["valu"]["valu_wave_instr_per_element"], e["valu"]["simd_cycles_per_valu_instr"], e["valu"]["valu_busy"]))
+bounds["_kernel_id"] = kernel_ids.pop() if len(kernel_ids) == 1 else "mixed: " + ", ".join(sorted(str(k) for k in kernel_ids))
 out = os.path.join(os.path.dirname(os.path.dirname(root.rstrip("/"))), "bounds.json")
 json.dump(bounds, open(out, "w"), indent=1)
 print("| workload | launch | bound | PMC GB/s | of the no-arithmetic floor | VALU wave-instr / element | SIMD cycles / VALU instr | VALU busy |")

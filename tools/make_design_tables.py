@@ -125,7 +125,14 @@ def counters_block():
     import bench
     traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     bounds = json.load(open(os.path.join(ROOT, "profiles", "bounds.json")))
-    out = ["Counters (`profiles/traffic.json`, `profiles/bounds.json`; written by `tools/make_traffic.py` / `tools/make_bounds.py` from the "
+    import __graft_entry__ as ge
+    now = ge.kernel_digest()
+    stamps = {traffic.get("_kernel_id"), bounds.get("_kernel_id")}
+    state = (f"measured on the kernels of this tree (`sda_kernel_id()` = `{now}`)" if stamps == {now} else
+             f"**STALE: measured on kernel id {sorted(str(x) for x in stamps)}, the tree's device code is `{now}` - rerun `tools/profile_r06.sh`, "
+             f"`make_traffic.py`, `make_bounds.py`**")
+    out = [f"Tables {state}; `bench.py` prints the same comparison as `roofline.tables_current`.", "",
+           "Counters (`profiles/traffic.json`, `profiles/bounds.json`; written by `tools/make_traffic.py` / `tools/make_bounds.py` from the "
            "rocprofv3 passes of `tools/profile_r06.sh`: kernel stats, FETCH_SIZE and WRITE_SIZE in separate `--pmc` passes, SQ counters; "
            "FETCH_SIZE doubled as the microarchitecture guide prescribes).  One launch = one tile of the size shown; \"algorithmic\" = "
            "tile x dim x (8 + 16 n / k) B, for the limb GEMM plus the clerk sum's 128-bit running sums (n x B x 32 B read and written per launch, "

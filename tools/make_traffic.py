@@ -10,12 +10,14 @@ traffic = {"_note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc pas
                     "gfx950; WRITE_SIZE (KiB) is used as reported (calibrated in round 1 on fill_synthetic_kernel: 16.777 GB written, "
                     "16.777 GB reported). Dual-role kernels: the both-roles launches (the largest grid)."}
 rows = []
+kernel_ids = set()
 for w in sorted(os.listdir(root)):
     d = os.path.join(root, w)
     if not os.path.isfile(os.path.join(d, "pmc_hbm.json")):
         continue
     pmc = json.load(open(os.path.join(d, "pmc_hbm.json")))
     line = json.loads(open(os.path.join(d, "bench_under_rocprof.json")).read().splitlines()[-1])
+    kernel_ids.add(line.get("kernel_id"))
     cfg = line["config"]
     P, dim = cfg["tile_participants"], cfg["dim"]
     per = {}
@@ -48,6 +50,8 @@ for w in sorted(os.listdir(root)):
     r = line["roofline"]
     meas = entry.get("fused_bytes_per_launch") or (entry.get("gen_bytes_per_launch", 0) + entry.get("comb_bytes_per_launch", 0))
     rows.append((cfg["name"], P, line["value"] / 1e9, line["path_roofline"]["frac_of_hbm_peak"], r["kernel"], r["avg_launch_ms"], alg / 1e9, meas / 1e9))
+# the kernels the passes ran on (sda_kernel_id() of the profiled build, from the records): ONE id or the table says "mixed"
+traffic["_kernel_id"] = kernel_ids.pop() if len(kernel_ids) == 1 else "mixed: " + ", ".join(sorted(str(k) for k in kernel_ids))
 json.dump(traffic, open(os.path.join(os.path.dirname(root.rstrip("/")), "traffic.json"), "w"), indent=1)
 # ... and the copy bench.py reads for `roofline.traffic` (always the current round's)
 json.dump(traffic, open(os.path.join(os.path.dirname(os.path.dirname(root.rstrip("/"))), "traffic.json"), "w"), indent=1)
