@@ -356,7 +356,7 @@ class Env:
         # default line never does: `library` on the line says which binary ran.
         knob_names = ("SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
                       "SDA_SIDE_STREAM_WGS", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_FORCE_COLLECTIVES", "SDA_NO_NARROW", "SDA_NO_LAZY", "SDA_NO_NGEMM",
-                      "SDA_NO_WIDE_GROUP", "SDA_SIDE_STREAM_PRIORITY", "SDA_NGEMM_CLERK_WG")
+                      "SDA_NO_WIDE_GROUP", "SDA_SIDE_STREAM_PRIORITY", "SDA_NGEMM_CLERK_WG", "SDA_NO_KARATSUBA")
         knobs = {n: os.environ[n] for n in knob_names if os.environ.get(n)}
         if knobs:
             capi.use_test_hooks()

@@ -34,6 +34,8 @@
  *                              matrix cores, ngemm_kernels.hip)
  *   SDA_NO_WIDE_GROUP 1        three-digit limb-31 shapes of 9 .. 12 terms (BASELINE config 4's (8,2)): the 7 + rest grouping even where
  *                              the constants admit the dot product as ONE group (default: one group, one reduction, no normalisation)
+ *   SDA_NO_KARATSUBA 1         ... the one-group form with four multiply-adds per term even where the constants admit the Karatsuba form
+ *                              (three per term, round 6)
  *   SDA_NGEMM_CLERK_WG 1       limb GEMM, dual-role launch: the clerk sum in clerk WORKGROUPS at fixed grid positions (rounds 4 - 5) instead
  *                              of the clerk WAVES inside every share-generation workgroup (round 6, the default)
  *   SDA_FORCE_COLLECTIVES 1    a one-rank communicator still goes through RCCL send/recv to itself

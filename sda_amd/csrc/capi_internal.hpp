@@ -16,7 +16,7 @@ namespace sda {
 enum Knob {
     KNOB_FORCE_GENERIC, KNOB_FORCE_MONT64, KNOB_FORCE_FFT, KNOB_FORCE_MFMA, KNOB_NO_MFMA, KNOB_NO_SIDE_STREAM,
     KNOB_SIDE_STREAM_WGS, KNOB_SIDE_STREAM_PRIORITY_HIGH, KNOB_FFT_G, KNOB_FFT_THREADS, KNOB_VARINT_PATH /* 1 stream, 2 scan */,
-    KNOB_FORCE_COLLECTIVES, KNOB_NO_NARROW, KNOB_WIRE_WG_PER_CU, KNOB_SBOX_WG_PER_CU, KNOB_NO_LAZY, KNOB_NO_XCD_MAP, KNOB_NO_NGEMM, KNOB_NO_WIDE_GROUP, KNOB_NGEMM_CLERK_WG, KNOB_COUNT
+    KNOB_FORCE_COLLECTIVES, KNOB_NO_NARROW, KNOB_WIRE_WG_PER_CU, KNOB_SBOX_WG_PER_CU, KNOB_NO_LAZY, KNOB_NO_XCD_MAP, KNOB_NO_NGEMM, KNOB_NO_WIDE_GROUP, KNOB_NGEMM_CLERK_WG, KNOB_NO_KARATSUBA, KNOB_COUNT
 };
 long knob(Knob k);             // 0 = unset / default
 // an UNUSED dynamic-LDS request that caps the resident workgroups of a launch at wg_per_cu per CU (0: no cap), so that a

@@ -42,7 +42,8 @@ struct L31Params {
     int32_t  p1;      // p >> 31
     uint32_t pinvB;   // -p^{-1} mod 2^31
     uint32_t wide;    // 1: the three-digit shapes of 9 .. 12 terms run their dot product as ONE group (admitted by the host on the
-                      // actual constants of both share maps, l31_wide_group_ok); 0 everywhere else
+                      // actual constants of both share maps, l31_wide_group_ok); 2: ... in Karatsuba form, three multiply-adds per
+                      // term (round 6; l31_karatsuba_ok admits the halves' cross columns); 0 everywhere else
     uint64_t np, np2; // 2^64 - p and 2^64 - 2p: x + np wraps exactly when x >= p (the conditional subtractions)
 };
 

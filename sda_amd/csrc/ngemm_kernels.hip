@@ -53,7 +53,7 @@ typedef unsigned int ng_v2u __attribute__((ext_vector_type(2)));
 static constexpr int kNgCompute = 8;                // compute waves per workgroup (two per SIMD), one workgroup per CU
 static constexpr int kNgWorkers = 64 * kNgCompute;
 #ifndef NG_CLERK_WAVES
-#define NG_CLERK_WAVES 3                            // (tools/build_ngemm_variant.sh builds A/B variants with other counts; 0 = rounds 4 - 5's nine waves)
+#define NG_CLERK_WAVES 3                            // (tools/build_kernel_variant.sh builds A/B variants with other counts; 0 = rounds 4 - 5's nine waves)
 #endif
 static constexpr int kNgClerkWaves = NG_CLERK_WAVES; // clerk waves of a share-generation workgroup (round 6): one on each SIMD that does not hold the loader
 static constexpr int kNgThreads = kNgWorkers + 64 + 64 * kNgClerkWaves;  // + the loader wave + the clerk waves: three waves on every SIMD

@@ -110,7 +110,7 @@ namespace {
 const char* const kKnobNames[sda::KNOB_COUNT] = {
     "SDA_FORCE_GENERIC", "SDA_FORCE_MONT64", "SDA_FORCE_FFT", "SDA_FORCE_MFMA", "SDA_NO_MFMA", "SDA_NO_SIDE_STREAM",
     "SDA_SIDE_STREAM_WGS", "SDA_SIDE_STREAM_PRIORITY", "SDA_FFT_G", "SDA_FFT_THREADS", "SDA_VARINT_PATH", "SDA_FORCE_COLLECTIVES",
-    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP", "SDA_NO_NGEMM", "SDA_NO_WIDE_GROUP", "SDA_NGEMM_CLERK_WG"};
+    "SDA_NO_NARROW", "SDA_WIRE_WG_PER_CU", "SDA_SBOX_WG_PER_CU", "SDA_NO_LAZY", "SDA_NO_XCD_MAP", "SDA_NO_NGEMM", "SDA_NO_WIDE_GROUP", "SDA_NGEMM_CLERK_WG", "SDA_NO_KARATSUBA"};
 std::atomic<long> g_knobs[sda::KNOB_COUNT];
 }  // namespace
 long sda::knob(sda::Knob k) {
@@ -742,6 +742,25 @@ static bool l31_wide_group_ok(const std::vector<uint64_t>& Mm, uint32_t kt, uint
     return true;
 }
 
+// The Karatsuba form of the wide group (l31_dot3_wide_k): each HALF of the terms keeps one cross column M - C0 - C2, which must fit a
+// signed 64-bit register for any values (limbs of magnitude <= 2^30): sum over the half of (|m0| + |m1|) x 2^30 + slack < 2^63.
+static bool l31_karatsuba_ok(const std::vector<uint64_t>& Mm, uint32_t kt, uint64_t p) {
+    if (!l31_wide_group_ok(Mm, kt, p)) return false;
+    std::vector<uint64_t> packed;
+    l31_pack_matrix(Mm, p, 93, packed);
+    const uint32_t half = (kt + 1) / 2;
+    for (size_t r = 0; r + kt <= Mm.size(); r += kt)
+        for (uint32_t lo = 0; lo < kt; lo += half) {
+            uint64_t s = 0;
+            for (uint32_t i = lo; i < lo + half && i < kt; ++i) {
+                const int64_t m0 = (int32_t)(uint32_t)packed[r + i], m1 = (int32_t)(uint32_t)(packed[r + i] >> 32);
+                s += (uint64_t)(m0 < 0 ? -m0 : m0) + (uint64_t)(m1 < 0 ? -m1 : m1);
+            }
+            if ((s << 30) + (1ull << 33) >= (1ull << 63)) return false;
+        }
+    return true;
+}
+
 // one matrix in the form the limb-31 kernels take: the kernarg copy (compiled / run-time (k, t) kernels) or device memory
 static int l31_place_matrix(sda_share_generator* g, const std::vector<uint64_t>& Mm, MatArg*& arg, DevBuf& dev) {
     std::vector<uint64_t> packed;
@@ -788,6 +807,8 @@ static int build_l31(sda_share_generator* g) {
     SDA_TRY(l31_params(g->mod.m, g->lp));
     if (g->l31 && packed_l31_three_digit_compiled(g->k, g->t))          // both maps, or the 7 + rest form serves the handle
         g->lp.wide = !knob(KNOB_NO_WIDE_GROUP) && l31_wide_group_ok(g->Mmont, g->k + g->t, g->mod.m) && (!g->sys_default || l31_wide_group_ok(g->Msys, g->k + g->t, g->mod.m)) ? 1u : 0u;
+        if (g->lp.wide && !knob(KNOB_NO_KARATSUBA) && l31_karatsuba_ok(g->Mmont, g->k + g->t, g->mod.m) && (!g->sys_default || l31_karatsuba_ok(g->Msys, g->k + g->t, g->mod.m)))
+            g->lp.wide = 2u;                                            // three multiply-adds per term (round 6)
     SDA_TRY(l31_place_matrix(g, g->Mmont, g->matarg, g->d_M));
     if (g->sys_default) SDA_TRY(l31_place_matrix(g, g->Msys, g->matarg_sys, g->d_Msys));
     return SDA_OK;

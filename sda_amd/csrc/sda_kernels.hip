@@ -543,6 +543,44 @@ __device__ __forceinline__ uint64_t l31_dot3(const uint64_t* __restrict__ row, c
     }
 }
 
+// The wide group in KARATSUBA form (round 6): three multiply-adds per term instead of four.  With ms = m0 + m1 and vs = v0 + v1 (both fit a
+// signed 32-bit register: a low limb lies in [-2^30, 2^30 - 1], a high limb in [-2^30, 2^30]) the cross products of a term are
+// ms vs - m0 v0 - m1 v1, so a group needs the columns C0, C2 and ONE middle column M = sum ms vs, and its cross column is
+// M - C0 - C2 - exact in 64-bit wrap-around arithmetic whenever the cross column itself fits, whatever M overflowed to.  The
+// cross column of the WHOLE dot product does not fit (that is why the plain form keeps C1a and C1b apart); the cross column of half
+// of it does for the constants the host admits (l31_karatsuba_ok: sum over the half of |m0| + |m1|, times the 2^30 a value's limb
+// can reach, stays below 2^63 - BASELINE config 4's worst half 7.07 x 2^30 of the 8 x 2^30 allowed; any constants: three terms).
+// So the terms are split in two halves with their own C0, C2, M;
+// the halves' cross columns take the places of C1a and C1b (the reduction only ever uses their sum, in split form), C0 and C2 are
+// the sums of the halves' (within 2^63 by the host's check on the actual constants, l31_wide_group_ok, as before).  Ten terms: 30
+// multiply-adds + 34 + 12 additions instead of 40 + 34; ms is a scalar addition (the constants live in SGPRs), vs is formed once
+// per batch for all rows.  Model: tests/test_limb31_r93_model.py (test_karatsuba_halves_*).
+template <int KT>
+__device__ __forceinline__ uint64_t l31_dot3_wide_k(const uint64_t* __restrict__ row, const int32_t (&v0)[KT], const int32_t (&v1)[KT],
+                                                    const int32_t (&vs)[KT], const L31Params& P) {
+    static_assert(KT >= 9 && KT <= 12, "the wide group is compiled for 9 .. 12 terms");
+    constexpr int HALF = (KT + 1) / 2;
+    int64_t C0[2], C2[2], M[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = h * HALF; i < (h ? KT : HALF); ++i) {
+            const int32_t m0 = (int32_t)(uint32_t)row[i];
+            const int32_t m1 = (int32_t)(uint32_t)(row[i] >> 32);
+            const int32_t ms = m0 + m1;
+            if (i == h * HALF) { C0[h] = mul_sv(m0, v0[i]); C2[h] = mul_sv(m1, v1[i]); M[h] = mul_sv(ms, vs[i]); }
+            else { C0[h] = mad_sv(m0, v0[i], C0[h]); C2[h] = mad_sv(m1, v1[i], C2[h]); M[h] = mad_sv(ms, vs[i], M[h]); }
+        }
+    }
+    L31Cols c;
+    c.C1a = (int64_t)((uint64_t)M[0] - (uint64_t)C0[0] - (uint64_t)C2[0]);
+    c.C1b = (int64_t)((uint64_t)M[1] - (uint64_t)C0[1] - (uint64_t)C2[1]);
+    c.C0 = C0[0] + C0[1];
+    c.C2 = C2[0] + C2[1];
+    c.C3 = 0;
+    return l31_redc3<true, false>(c, P);
+}
+
 // which compiled (k, t) shapes use the three-digit form: those with a compiled instance in BOTH the plain and the dual-role
 // launchers (every other shape may be served by the run-time (k, t) kernels, whose constants carry R = 2^62) and a term
 // count it pays for
@@ -646,6 +684,18 @@ __device__ __forceinline__ void packed_gen_l31_body(const GenLayout& L, uint32_t
         for (int i = 0; i < T; ++i) store_pair<VEC>(op + (size_t)i * L.out_stride_clerk, s0[K + i], s1[K + i], in0, in1);
     }
     if constexpr (L31UseR93<K, T>::value && KT >= 9 && KT <= 12) {
+        if (lp.wide == 2) {                                                  // uniform: ... and its Karatsuba form
+            int32_t as[KT], cs[KT];                                          // v0 + v1 of every term: the third operand
+#pragma unroll
+            for (int i = 0; i < KT; ++i) { as[i] = a0[i] + a1[i]; cs[i] = c0[i] + c1[i]; }
+            for (uint32_t j = direct; j < n; ++j) {
+                const uint64_t* row = &M.e[(size_t)(j - direct) * KT];
+                const uint64_t a = l31_dot3_wide_k<KT>(row, a0, a1, as, lp);
+                const uint64_t b = l31_dot3_wide_k<KT>(row, c0, c1, cs, lp);
+                store_pair<VEC>(op + (size_t)j * L.out_stride_clerk, a, b, in0, in1);
+            }
+            return;
+        }
         if (lp.wide) {                                                       // uniform: the host admitted the one-group form
             for (uint32_t j = direct; j < n; ++j) {
                 const uint64_t* row = &M.e[(size_t)(j - direct) * KT];

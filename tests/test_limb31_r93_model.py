@@ -237,3 +237,101 @@ def test_run_time_three_digit_form_up_to_64_terms(kt):
                 row = [rnd.randrange(p) for _ in range(kt)]
                 vals = [rnd.randrange(p) for _ in range(kt)]
             assert dot3(p, row, vals, runtime=True) == sum(m * v for m, v in zip(row, vals)) % p
+
+
+def wrap64(x):
+    """a signed 64-bit register after wrap-around arithmetic (v_mad_i64_i32 and 64-bit adds / subs wrap modulo 2^64)"""
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def i32(x):
+    assert -(1 << 31) <= x < (1 << 31), x
+    return x
+
+
+def host_admits_karatsuba(cons):
+    """sda_capi.cpp l31_karatsuba_ok: the wide group is admitted AND each half's cross column fits a signed 64-bit register for any
+    values (limbs of magnitude <= 2^30): sum over the half of (|m0| + |m1|) 2^30 + 2^33 < 2^63"""
+    if not host_admits_wide(cons):
+        return False
+    half = (len(cons) + 1) // 2
+    return all((sum(abs(m0) + abs(m1) for m0, m1 in cons[lo:lo + half]) << 30) + (1 << 33) < (1 << 63) for lo in range(0, len(cons), half))
+
+
+def karatsuba_columns(cons, lim):
+    """l31_dot3_wide_k (round 6): two halves, each with C0, C2 and a middle column M = sum (m0 + m1)(v0 + v1) in WRAP-AROUND
+    arithmetic; the halves' cross columns M - C0 - C2 take the places of C1a and C1b.  Returns (C0, C1a, C1b, C2) and asserts
+    every operand / result the kernel relies on: the 32-bit sums, the halves' cross columns, the summed C0 and C2."""
+    kt = len(cons)
+    half = (kt + 1) // 2
+    parts = []
+    for lo, hi in ((0, half), (half, kt)):
+        C0 = C2 = M = 0
+        for (m0, m1), (v0, v1) in zip(cons[lo:hi], lim[lo:hi]):
+            ms, vs = i32(m0 + m1), i32(v0 + v1)                  # both fit a signed 32-bit register
+            C0 = wrap64(C0 + m0 * v0)
+            C2 = wrap64(C2 + m1 * v1)
+            M = wrap64(M + ms * vs)                              # may have wrapped: only M - C0 - C2 is used
+        cross = wrap64(M - C0 - C2)
+        exact = sum(m0 * v1 + m1 * v0 for (m0, m1), (v0, v1) in zip(cons[lo:hi], lim[lo:hi]))
+        assert cross == exact and -(1 << 63) <= exact < (1 << 63), (cross, exact)
+        parts.append((C0, C2, cross, sum(m0 * v0 for (m0, _), (v0, _) in zip(cons[lo:hi], lim[lo:hi])),
+                      sum(m1 * v1 for (_, m1), (_, v1) in zip(cons[lo:hi], lim[lo:hi]))))
+    C0 = i64(parts[0][3] + parts[1][3])                          # the host's check keeps the WHOLE columns inside 64 bits,
+    C2 = i64(parts[0][4] + parts[1][4])                          # so the halves never wrapped either
+    assert parts[0][0] == parts[0][3] and parts[1][0] == parts[1][3] and parts[0][1] == parts[0][4] and parts[1][1] == parts[1][4]
+    return C0, parts[0][2], parts[1][2], C2
+
+
+@pytest.mark.parametrize("kt", [9, 10, 11, 12])
+def test_karatsuba_halves_give_the_plain_columns(kt):
+    """the Karatsuba form of the wide group: for constants the host admits, ANY values (random, and the worst ones: every limb at
+    its extreme, signs aligned with the constants so that the middle column wraps as far as it can) give C0, C2 and a pair of
+    cross columns whose SUM is the plain form's C1a + C1b - which is all l31_redc3 uses - with every half's cross column inside
+    a signed 64-bit register - for the constants the host ADMITS (host_admits_karatsuba); constants it refuses do overflow on the
+    extreme values, which the last lines show"""
+    p = 4611686006577364993
+    rnd = random.Random(100 + kt)
+    checked = wrapped = 0
+    refused = []
+    for trial in range(400):
+        row = [rnd.randrange(p) for _ in range(kt)]
+        cons = [bal(centre(m * R93 % p, p)) for m in row]
+        if not host_admits_karatsuba(cons):
+            refused.append(cons)
+            continue
+        extremes = []
+        for m0, m1 in cons:
+            s0, s1 = (1 if m0 >= 0 else -1), (1 if m1 >= 0 else -1)
+            extremes.append(((1 << 30) - 1 if s0 > 0 else -(1 << 30), (1 << 30) if s1 > 0 else -(1 << 30)))
+        rand_lim = [bal(centre(rnd.randrange(p), p)) for _ in range(kt)]
+        for lim in (extremes, rand_lim, [(-(1 << 30), -(1 << 30))] * kt, [((1 << 30) - 1, 1 << 30)] * kt):
+            C0, C1a, C1b, C2 = karatsuba_columns(cons, lim)
+            assert C0 == sum(m0 * v0 for (m0, _), (v0, _) in zip(cons, lim))
+            assert C2 == sum(m1 * v1 for (_, m1), (_, v1) in zip(cons, lim))
+            assert C1a + C1b == sum(m0 * v1 + m1 * v0 for (m0, m1), (v0, v1) in zip(cons, lim))
+            mid = sum((m0 + m1) * (v0 + v1) for (m0, m1), (v0, v1) in zip(cons[:(kt + 1) // 2], lim[:(kt + 1) // 2]))
+            wrapped += not -(1 << 63) <= mid < (1 << 63)
+            checked += 1
+    assert checked > (400 if kt <= 10 else 0) and (wrapped > 0 or checked == 0), (checked, wrapped)   # the middle column DID wrap: the identity held anyway
+    # constants with every limb at its extreme are refused, and rightly: their halves' cross columns leave the register
+    bad = [((1 << 30) - 1, 1 << 30)] * kt
+    assert not host_admits_karatsuba(bad)
+    with pytest.raises(AssertionError):
+        karatsuba_columns(bad, [((1 << 30) - 1, 1 << 30)] * kt)
+    # BASELINE config 4's own constants (tss's map): admitted
+    if kt == 10:
+        w2, w3 = 2589100645267092065, 365137883145458390
+        nodes = [pow(w2, e, p) for e in range(11)]
+        for j in range(26):
+            x = pow(w3, j + 1, p)
+            row = []
+            for a, xa in enumerate(nodes):
+                num = den = 1
+                for b, xb in enumerate(nodes):
+                    if a != b:
+                        num = num * (x - xb) % p
+                        den = den * (xa - xb) % p
+                row.append(num * pow(den, p - 2, p) % p)
+            assert host_admits_karatsuba([bal(centre(m * R93 % p, p)) for m in row[1:]]), j

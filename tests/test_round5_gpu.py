@@ -232,17 +232,20 @@ def test_the_library_reports_the_kernels_it_ran(gpu):
     assert len(lib.sda_build_id()) == 16
 
 
-@pytest.mark.parametrize("wide", [True, False])
+@pytest.mark.parametrize("wide", ["karatsuba", "plain", False])
 def test_config4_dot_product_as_one_group_and_as_seven_plus_three(gpu, wide):
-    """BASELINE config 4's (8,2,26): the 10-term dot product as ONE three-digit group (default where the host admits it on the
-    constants of both share maps) and in the 7 + 3 grouping (knob SDA_NO_WIDE_GROUP) - both against the oracle, on random and
-    on adversarial operands (every balanced limb +-2^30, alike within a batch), injected randomness and the device CSPRNG,
-    separate and dual-role launches"""
+    """BASELINE config 4's (8,2,26): the 10-term dot product as ONE three-digit group in its Karatsuba form (round 6, three
+    multiply-adds per term: the default where the host admits it on the constants of both share maps), in the plain one-group form
+    (knob SDA_NO_KARATSUBA) and in the 7 + 3 grouping (knob SDA_NO_WIDE_GROUP) - all against the oracle, on random and on
+    adversarial operands (every balanced limb +-2^30, alike within a batch: the Karatsuba form's middle column wraps there),
+    injected randomness and the device CSPRNG, separate and dual-role launches"""
     from sda_amd import crypto
     from sda_amd.device import DeviceBuffer
     from oracle import coracle
     if not wide:
         set_knob("SDA_NO_WIDE_GROUP", 1)
+    elif wide == "plain":
+        set_knob("SDA_NO_KARATSUBA", 1)
     k, t, n = 8, 2, 26
     sch = crypto.PackedShamir(k, n, t, P62, W[16], W[27])
     gen = crypto.ShareGenerator(sch)

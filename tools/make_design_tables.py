@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 DOCS = ["DESIGN.md", "BASELINE.md", "README.md"]
 # the builder's runs of THIS round's final code (compact stdout lines of bench.py), in the order they are listed
 BUILDER_RUNS = ["profiles/r06/lines/bench_line_driver_form_1.json", "profiles/r06/lines/bench_line_driver_form_2.json",
-                "profiles/r06/lines/bench_line_default.json"]
+                "profiles/r06/lines/bench_line_default.json", "profiles/r06/lines/box2/bench_line_driver_form_1.json",
+                "profiles/r06/lines/box2/bench_line_driver_form_2.json", "profiles/r06/lines/box2/bench_line_default.json"]
 ROUND = 6
 
 LEGS = [  # (key on the line, what it is)
