@@ -1,5 +1,5 @@
 #!/bin/bash
-# interleaved A/B of limb GEMM variants (tools/build_kernel_variant.sh): usage  bash tools/ab_ngemm_libs.sh NAME [NAME ...]
+# interleaved A/B of limb GEMM variants (bash tools/build_kernel_variant.sh ngemm_kernels.hip NAME [-D...]): usage  bash tools/ab_ngemm_libs.sh NAME [NAME ...]
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out
 fused() { timeout 300 python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-additional --full-line "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%.2f Gelem/s frac %.3f launch %.3f ms first(gen only) %.3f last(clerk only) %.3f verified %s' % (d['value']/1e9, r['frac'], r.get('both_roles_launch_ms') or 0, r.get('first_launch_ms_share_gen_only') or 0, r.get('last_launch_ms_clerk_sum_only') or 0, d['verified_reconstruct_equals_sum']))"; }
 for rep in 1 2 3; do
