@@ -428,7 +428,11 @@ __device__ __forceinline__ void ng_clerk_wait(NgClerkSet& S) {
                  : "memory");
 }
 
-__device__ __forceinline__ void ng_clerk_wave(const NgFuse& F, uint64_t slot, uint32_t lane, uint32_t n_barriers) {
+// `extra`: two bits per staging step - that many PAIRS of quanta more before the step's first barrier.  The staging steps that draw
+// from the CSPRNG keep the compute waves busy for 5 - 10 us (two ChaCha20 blocks per lane and more) while HBM idles; a clerk wave
+// that did one quantum per barrier there summed a quarter of what it sums per microsecond in the row tiles, and 12 % of a
+// PSS_155_728_100 tile was left to the follow-up kernel.
+__device__ __forceinline__ void ng_clerk_wave(const NgFuse& F, uint64_t slot, uint32_t lane, uint32_t n_barriers, uint32_t extra) {
     if (F.cw_items == 0) {                                           // a launch without a previous tile: the barriers, nothing else
         for (uint32_t b = 0; b < n_barriers; ++b) __builtin_amdgcn_s_barrier();
         return;
@@ -494,6 +498,20 @@ __device__ __forceinline__ void ng_clerk_wave(const NgFuse& F, uint64_t slot, ui
     A.al = A.ah = B.al = B.ah = ll2{0, 0};
     uint32_t b = 0;
     for (; b + 1 < n_barriers; b += 2) {
+        // (barrier b = 2 x step is a staging step's first barrier; `extra` holds that step's two bits at position b, zeros beyond the steps)
+        const uint32_t e = b < 32u ? (extra >> b) & 3u : 0u;
+        if (e >= 1u) {
+            ng_clerk_wait<kNgClerkRows>(A);
+            consume(A, validA); issue(A, validA);
+            ng_clerk_wait<kNgClerkRows>(B);
+            consume(B, validB); issue(B, validB);
+        }
+        if (e >= 2u) {
+            ng_clerk_wait<kNgClerkRows>(A);
+            consume(A, validA); issue(A, validA);
+            ng_clerk_wait<kNgClerkRows>(B);
+            consume(B, validB); issue(B, validB);
+        }
         ng_clerk_wait<kNgClerkRows>(A);                              // B's rows (asked for one step ago) stay in flight
         consume(A, validA); issue(A, validA);
         __builtin_amdgcn_s_barrier();
@@ -638,7 +656,17 @@ __global__ __launch_bounds__(kNgThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     }
     if (wave > (uint32_t)kNgCompute) {                              // a clerk wave: every barrier of the workgroup, nothing else of it
         const uint32_t cw = __builtin_amdgcn_readfirstlane(wave) - (uint32_t)kNgCompute - 1u;
-        ng_clerk_wave(F, item * (uint64_t)kNgClerkWaves + cw, lane, 2u * (uint32_t)KS + P.row_tiles);
+        // pairs of quanta more in the staging steps that draw (no injected randomness): two for 48 draws and more, one for 24
+        uint32_t extra = 0;
+        if (!L.rand) {
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const uint32_t lo = 64u * st > P.k ? 64u * st : P.k, hi = 64u * st + 64u < P.k + P.t ? 64u * st + 64u : P.k + P.t;
+                const uint32_t draws = hi > lo ? hi - lo : 0u;
+                extra |= (draws >= 48u ? 2u : draws >= 24u ? 1u : 0u) << (2 * st);      // two bits at the step's first barrier index, 2 st
+            }
+        }
+        ng_clerk_wave(F, item * (uint64_t)kNgClerkWaves + cw, lane, 2u * (uint32_t)KS + P.row_tiles, extra);
         return;
     }
     const uint64_t p = item / chunks, chunk = item - p * chunks;
